@@ -1,0 +1,78 @@
+"""Shared helpers for the parity tests (seeded inputs, oracle drivers, comparison metrics)."""
+import math
+
+import torch
+
+from oracle import model_torch as OM
+from oracle import raster_torch as OR
+from vcr_gaus_amd import synthetic
+from vcr_gaus_amd.graphics_utils import get_all_px_dir
+
+
+def make_case(n, width, height, focal, seed=0, scale_mult=1.0, view=0, n_views=3, sem=0, sh_degree=3):
+    raw = synthetic.make_gaussians(n, seed=seed, sem_channels=sem)
+    raw["scaling"] = raw["scaling"] + math.log(scale_mult)
+    cam = synthetic.make_cameras(n_views, width, height, focal)[view]
+    act = OM.activations(raw)
+    nw = OM.get_normal(act["rotation"], act["scaling"])
+    ncam = OM.camera_normals(nw, act["xyz"], cam.camera_center, cam.R_w2c)
+    inputs = dict(means3D=act["xyz"], shs=act["shs"], normals=ncam.contiguous(), opac=act["opacity"],
+                  scales=act["scaling"], rots=act["rotation"],
+                  sem=raw["obj_dc"].squeeze(1).contiguous() if sem else None)
+    dirs = get_all_px_dir(cam.intr, height, width)
+    return cam, inputs, dirs
+
+
+def settings_for(cam, bg, cls, sh_degree=3, f_count=0, device=None):
+    mv = (lambda t: t.to(device)) if device is not None else (lambda t: t)
+    return cls(image_height=cam.image_height, image_width=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
+               tanfovy=math.tan(cam.FoVy * 0.5), bg=mv(bg), scale_modifier=1.0, viewmatrix=mv(cam.world_view_transform),
+               projmatrix=mv(cam.full_proj_transform), sh_degree=sh_degree, campos=mv(cam.camera_center),
+               prefiltered=False, debug=False, f_count=f_count)
+
+
+def oracle_forward(cam, inp, dirs, bg, dtype=torch.float64, requires_grad=False, sh_degree=3, f_count=0,
+                   use_normals=True):
+    s = settings_for(cam, bg, OR.Settings, sh_degree=sh_degree, f_count=f_count)
+    leaf = {}
+    for k, v in inp.items():
+        if v is None:
+            leaf[k] = None
+        else:
+            leaf[k] = v.detach().to(dtype).clone().requires_grad_(requires_grad)
+    N = inp["means3D"].shape[0]
+    leaf["m2"] = torch.zeros(N, 3, dtype=dtype, requires_grad=requires_grad)
+    leaf["m2d"] = torch.zeros(N, 3, dtype=dtype, requires_grad=requires_grad)
+    res = OR.rasterize(s, leaf["means3D"], leaf["m2"], leaf["m2d"], leaf["shs"], None,
+                       leaf["normals"] if use_normals else None, leaf["sem"], leaf["opac"], leaf["scales"],
+                       leaf["rots"], None, dirs if use_normals else None)
+    return res, leaf
+
+
+def hip_forward(cam, inp, dirs, bg, device, requires_grad=False, sh_degree=3, f_count=0, use_normals=True):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    s = settings_for(cam, bg, GaussianRasterizationSettings, sh_degree=sh_degree, f_count=f_count, device=device)
+    leaf = {}
+    for k, v in inp.items():
+        leaf[k] = None if v is None else v.detach().float().to(device).clone().requires_grad_(requires_grad)
+    N = inp["means3D"].shape[0]
+    leaf["m2"] = torch.zeros(N, 3, device=device, requires_grad=requires_grad)
+    leaf["m2d"] = torch.zeros(N, 3, device=device, requires_grad=requires_grad)
+    rast = GaussianRasterizer(raster_settings=s)
+    res = rast(means3D=leaf["means3D"], means2D=leaf["m2"], means2D_densify=leaf["m2d"] if f_count == 0 else None,
+               shs=leaf["shs"], colors_precomp=None, normals_precomp=leaf["normals"] if use_normals else None,
+               semantics_precomp=leaf["sem"], opacities=leaf["opac"], scales=leaf["scales"], rotations=leaf["rots"],
+               cov3D_precomp=None, dirs=dirs.to(device) if (use_normals and dirs is not None) else None, inside=None)
+    return res, leaf
+
+
+def frac_bad(a, b, rtol, atol):
+    """fraction of elements with |a-b| > atol + rtol*|b|"""
+    a, b = a.double().cpu(), b.double().cpu()
+    return float(((a - b).abs() > atol + rtol * b.abs()).double().mean())
+
+
+def rel_err(a, b):
+    """max-norm relative error of a tensor against its reference."""
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))

@@ -1,0 +1,83 @@
+"""ctypes binding of libvcr_raster.so (C ABI: include/vcr_raster.h).
+
+There is deliberately NO fallback: if the HIP library is missing or does not load, importing this
+module raises, so a product path can never silently run on something else.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvcr_raster.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int32)
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
+BUF_GEOM, BUF_BINNING, BUF_IMAGE, BUF_SCRATCH = 0, 1, 2, 3
+
+
+class VcrRasterArgs(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("S", C.c_int32), ("K", C.c_int32),
+        ("sh_degree", C.c_int32), ("f_count", C.c_int32), ("num_dist", C.c_int32), ("debug", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+        ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+        ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("normals_precomp", C.c_void_p), ("semantics_precomp", C.c_void_p), ("opacities", C.c_void_p),
+        ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("dirs", C.c_void_p),
+    ]
+
+
+class VcrForwardOut(C.Structure):
+    _fields_ = [
+        ("out", C.c_void_p), ("radii", C.c_void_p), ("count", C.c_void_p), ("score", C.c_void_p),
+        ("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p),
+        ("num_rendered", C.c_int64), ("num_visible", C.c_int32), ("max_tile_len", C.c_int32),
+    ]
+
+
+class VcrBackwardIO(C.Structure):
+    _fields_ = [
+        ("dL_dout", C.c_void_p), ("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p),
+        ("radii", C.c_void_p), ("num_rendered", C.c_int64),
+        ("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dmeans2D_densify", C.c_void_p),
+        ("dL_dshs", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_dnormals", C.c_void_p),
+        ("dL_dsemantics", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
+        ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
+    ]
+
+
+# symbol -> (restype, argtypes); tests check that every one of these is exported.
+SYMBOLS = {
+    "vcr_abi_version": (C.c_int, []),
+    "vcr_last_error": (C.c_char_p, []),
+    "vcr_rasterize_forward": (C.c_int, [C.POINTER(VcrRasterArgs), C.POINTER(VcrForwardOut), ALLOC_FN, C.c_void_p, C.c_void_p]),
+    "vcr_rasterize_backward": (C.c_int, [C.POINTER(VcrRasterArgs), C.POINTER(VcrBackwardIO), ALLOC_FN, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle.  torch must be imported first so that the HIP
+    runtime already mapped by torch (SONAME libamdhip64.so.7) is the one the library binds to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (maps libamdhip64 before our library resolves it)
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). No CPU fallback exists.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.vcr_abi_version() != 1:
+        raise ImportError("libvcr_raster.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().vcr_last_error().decode()

@@ -1,0 +1,177 @@
+// extern "C" entry points of libvcr_raster.so (declared in include/vcr_raster.h).
+#include "vcr_common.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void vcr_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+struct Readback { uint32_t R; uint32_t V; };
+
+Readback* pinned_readback() {
+    static thread_local Readback* p = nullptr;
+    if (!p && hipHostMalloc((void**)&p, sizeof(Readback), hipHostMallocDefault) != hipSuccess) p = nullptr;
+    return p;
+}
+
+__global__ void count_visible_kernel(int N, const uint32_t* __restrict__ tiles, uint32_t* __restrict__ counter) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool v = i < N && tiles[i] != 0;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(v);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (uint32_t)__popcll(m));
+}
+
+__global__ void fill_background_kernel(int P, int C, const float* __restrict__ bg, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    for (int c = 0; c < C; ++c) out[(size_t)c * P + i] = c < 3 ? bg[c] : 0.f;
+}
+
+int validate(const VcrRasterArgs* a) {
+    if (!a) { vcr_set_error("args is NULL"); return 1; }
+    if (a->N < 0 || a->H <= 0 || a->W <= 0) { vcr_set_error("bad sizes N=%d H=%d W=%d", a->N, a->H, a->W); return 1; }
+    if (a->S < 0 || a->S > VCR_MAX_SEM) { vcr_set_error("semantic channels S=%d unsupported (0..%d)", a->S, VCR_MAX_SEM); return 1; }
+    if (a->num_dist != 0) { vcr_set_error("num_dist=%d: trailing distortion channels are not built yet", a->num_dist); return 1; }
+    if ((a->shs == nullptr) == (a->colors_precomp == nullptr)) { vcr_set_error("provide exactly one of shs / colors_precomp"); return 1; }
+    const bool sr = a->scales != nullptr && a->rotations != nullptr;
+    if (sr == (a->cov3D_precomp != nullptr)) { vcr_set_error("provide exactly one of (scales, rotations) / cov3D_precomp"); return 1; }
+    if (a->shs && (a->sh_degree < 0 || a->sh_degree > 3 || (a->sh_degree + 1) * (a->sh_degree + 1) > a->K)) {
+        vcr_set_error("sh_degree=%d incompatible with K=%d", a->sh_degree, a->K); return 1;
+    }
+    if (a->S > 0 && !a->semantics_precomp) { vcr_set_error("S>0 but semantics_precomp is NULL"); return 1; }
+    if (!a->bg || !a->viewmatrix || !a->projmatrix || !a->campos || !a->means3D || !a->opacities) {
+        vcr_set_error("required pointer is NULL"); return 1;
+    }
+    return 0;
+}
+
+int tile_bits_for(int T) {
+    int b = 1;
+    while ((1 << b) < T) ++b;
+    return b;
+}
+
+}  // namespace
+
+extern "C" int vcr_abi_version(void) { return VCR_ABI_VERSION; }
+extern "C" const char* vcr_last_error(void) { return g_err; }
+
+extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* out, vcr_alloc_fn alloc, void* user,
+                                     void* stream) {
+    if (validate(args)) return 1;
+    if (!out || !alloc) { vcr_set_error("out/alloc is NULL"); return 1; }
+    const VcrRasterArgs& a = *args;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = a.N, P = a.H * a.W;
+    const int gx = (a.W + VCR_TILE - 1) / VCR_TILE, gy = (a.H + VCR_TILE - 1) / VCR_TILE;
+    const int T = gx * gy;
+    const int C = 8 + a.S + a.num_dist;
+    if (a.f_count != 3 && !out->out) { vcr_set_error("out buffer is NULL"); return 1; }
+    if (a.f_count != 0 && !out->count) { vcr_set_error("count buffer is NULL for f_count=%d", a.f_count); return 1; }
+    if ((a.f_count == 1 || a.f_count == 2) && !out->score) { vcr_set_error("score buffer is NULL"); return 1; }
+    out->num_rendered = 0; out->num_visible = 0; out->max_tile_len = -1;
+    out->geom = out->binning = out->image = nullptr;
+
+    void* geom_p = alloc(user, VCR_BUF_GEOM, GeomState::bytes(N > 0 ? N : 1, a.S));
+    void* img_p = alloc(user, VCR_BUF_IMAGE, ImageState::bytes(P));
+    if (!geom_p || !img_p) { vcr_set_error("allocator returned NULL"); return 1; }
+    GeomState g = GeomState::view(geom_p, N > 0 ? N : 1, a.S);
+    ImageState im = ImageState::view(img_p, P);
+    out->geom = geom_p; out->image = img_p;
+
+    int64_t R = 0;
+    if (N > 0) {
+        if (!out->radii) { vcr_set_error("radii buffer is NULL"); return 1; }
+        const int tbits = tile_bits_for(T);
+        const size_t tmp1 = vcr_binning_temp_bytes(N, 0, tbits);
+        const size_t nb = vcr_align(sizeof(uint32_t) * (size_t)N);
+        char* s1 = (char*)alloc(user, VCR_BUF_SCRATCH, 5 * nb + 256 + tmp1);
+        if (!s1) { vcr_set_error("allocator returned NULL"); return 1; }
+        uint32_t* depth_key = (uint32_t*)s1;
+        uint32_t* ids = (uint32_t*)(s1 + nb);
+        uint32_t* key_sorted = (uint32_t*)(s1 + 2 * nb);
+        uint32_t* ids_sorted = (uint32_t*)(s1 + 3 * nb);
+        uint32_t* offsets = (uint32_t*)(s1 + 4 * nb);
+        uint32_t* vis_counter = (uint32_t*)(s1 + 5 * nb);
+        void* temp1 = s1 + 5 * nb + 256;
+        VCR_HIP_CHECK(hipMemsetAsync(vis_counter, 0, sizeof(uint32_t), st));
+        if (vcr_launch_preprocess(a, g, out->radii, depth_key, ids, st)) return 1;
+        hipLaunchKernelGGL(count_visible_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, g.tiles, vis_counter);
+        if (vcr_depth_sort_and_scan(N, depth_key, ids, key_sorted, ids_sorted, g.tiles, offsets, temp1, tmp1, st)) return 1;
+        Readback* rb = pinned_readback();
+        if (!rb) { vcr_set_error("hipHostMalloc for the readback word failed"); return 1; }
+        VCR_HIP_CHECK(hipMemcpyAsync(&rb->R, offsets + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        VCR_HIP_CHECK(hipMemcpyAsync(&rb->V, vis_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        VCR_HIP_CHECK(hipStreamSynchronize(st));
+        R = rb->R;
+        out->num_visible = (int32_t)rb->V;
+
+        void* bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(R, T));
+        if (!bin_p) { vcr_set_error("allocator returned NULL"); return 1; }
+        BinState b = BinState::view(bin_p, R, T);
+        out->binning = bin_p;
+        const size_t tmp2 = vcr_binning_temp_bytes(N, R, tbits);
+        const size_t rbts = vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1));
+        char* s2 = (char*)alloc(user, VCR_BUF_SCRATCH, 3 * rbts + tmp2);
+        if (!s2) { vcr_set_error("allocator returned NULL"); return 1; }
+        if (vcr_duplicate_and_sort(a, g, out->radii, ids_sorted, offsets, R, tbits, (uint32_t*)s2, (uint32_t*)(s2 + rbts),
+                                   (uint32_t*)(s2 + 2 * rbts), b.point_list, b.ranges, T, s2 + 3 * rbts, tmp2, st))
+            return 1;
+        out->num_rendered = R;
+        if (vcr_launch_composite_forward(a, g, b, im, *out, st)) return 1;
+    } else {
+        void* bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(0, T));
+        if (!bin_p) { vcr_set_error("allocator returned NULL"); return 1; }
+        BinState b = BinState::view(bin_p, 0, T);
+        out->binning = bin_p;
+        VCR_HIP_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * (size_t)T, st));
+        if (a.f_count != 3)
+            hipLaunchKernelGGL(fill_background_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, a.f_count ? 3 : C, a.bg,
+                               out->out);
+        VCR_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* io, vcr_alloc_fn alloc, void* user,
+                                      void* stream) {
+    if (validate(args)) return 1;
+    if (!io || !alloc) { vcr_set_error("io/alloc is NULL"); return 1; }
+    const VcrRasterArgs& a = *args;
+    if (a.f_count != 0) { vcr_set_error("backward is defined for f_count=0 only"); return 1; }
+    hipStream_t st = (hipStream_t)stream;
+    const int N = a.N, P = a.H * a.W;
+    if (N == 0) return 0;
+    if (!io->dL_dout || !io->geom || !io->binning || !io->image || !io->radii || !io->dL_dmeans3D || !io->dL_dmeans2D ||
+        !io->dL_dopacities) { vcr_set_error("backward: required pointer is NULL"); return 1; }
+    if (a.shs && !io->dL_dshs) { vcr_set_error("backward: dL_dshs is NULL"); return 1; }
+    if (a.scales && (!io->dL_dscales || !io->dL_drotations)) { vcr_set_error("backward: dL_dscales/rotations NULL"); return 1; }
+    if (a.cov3D_precomp && !io->dL_dcov3D) { vcr_set_error("backward: dL_dcov3D is NULL"); return 1; }
+    const int gx = (a.W + VCR_TILE - 1) / VCR_TILE, gy = (a.H + VCR_TILE - 1) / VCR_TILE;
+    GeomState g = GeomState::view(const_cast<void*>(io->geom), N, a.S);
+    BinState b = BinState::view(const_cast<void*>(io->binning), io->num_rendered, gx * gy);
+    ImageState im = ImageState::view(const_cast<void*>(io->image), P);
+    const size_t gb = vcr_align(sizeof(GradRec) * (size_t)N);
+    const size_t sb = vcr_align(sizeof(float) * (size_t)N * (a.S > 0 ? a.S : 1));
+    char* s = (char*)alloc(user, VCR_BUF_SCRATCH, gb + sb);
+    if (!s) { vcr_set_error("allocator returned NULL"); return 1; }
+    GradRec* sgrad = (GradRec*)s;
+    float* sgrad_sem = (float*)(s + gb);
+    VCR_HIP_CHECK(hipMemsetAsync(s, 0, gb + sb, st));
+    if (io->num_rendered > 0)
+        if (vcr_launch_composite_backward(a, g, b, im, io->dL_dout, sgrad, sgrad_sem, st)) return 1;
+    VcrBackwardIO io2 = *io;
+    if (!a.normals_precomp) io2.dL_dnormals = nullptr;
+    if (a.S == 0) io2.dL_dsemantics = nullptr;
+    if (a.colors_precomp == nullptr) io2.dL_dcolors = nullptr;
+    return vcr_launch_preprocess_backward(a, g, io->radii, sgrad, sgrad_sem, io2, st);
+}

@@ -1,0 +1,413 @@
+// K1 / K8: per-Gaussian projection stage and its adjoint, one lane per Gaussian (HBM-streaming).
+//
+// Contract: SURVEY.md Appendix A.3 steps 1-7, restated in oracle/raster_torch.py::preprocess.
+// Reference call sites: gaussian_renderer/__init__.py:61-120 (inputs), :83-87 (colour rule),
+// tools/general_utils.py:98-130 (covariance from scale/rotation), scene/cameras.py:68-70 (matrices).
+#include "vcr_common.h"
+
+namespace {
+
+struct Cam {
+    float V[16], P[16], c[3];
+};
+
+__device__ __forceinline__ Cam load_cam(const VcrRasterArgs& a) {
+    Cam cam;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { cam.V[k] = a.viewmatrix[k]; cam.P[k] = a.projmatrix[k]; }
+    cam.c[0] = a.campos[0]; cam.c[1] = a.campos[1]; cam.c[2] = a.campos[2];
+    return cam;
+}
+
+__device__ __forceinline__ void quat_to_R(const float4 q, float R[9]) {
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z); R[2] = 2.f * (x * z + r * y);
+    R[3] = 2.f * (x * y + r * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
+    R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma (xx,xy,xz,yy,yz,zz)
+__device__ __forceinline__ void load_cov3d(const VcrRasterArgs& a, int i, float S[6], float R[9], float s[3]) {
+    if (a.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S[k] = a.cov3D_precomp[6 * (size_t)i + k];
+        return;
+    }
+    const float4 q = reinterpret_cast<const float4*>(a.rotations)[i];
+    quat_to_R(q, R);
+    s[0] = a.scales[3 * (size_t)i + 0] * a.scale_modifier;
+    s[1] = a.scales[3 * (size_t)i + 1] * a.scale_modifier;
+    s[2] = a.scales[3 * (size_t)i + 2] * a.scale_modifier;
+    const float s0 = s[0] * s[0], s1 = s[1] * s[1], s2 = s[2] * s[2];
+    S[0] = R[0] * R[0] * s0 + R[1] * R[1] * s1 + R[2] * R[2] * s2;
+    S[1] = R[0] * R[3] * s0 + R[1] * R[4] * s1 + R[2] * R[5] * s2;
+    S[2] = R[0] * R[6] * s0 + R[1] * R[7] * s1 + R[2] * R[8] * s2;
+    S[3] = R[3] * R[3] * s0 + R[4] * R[4] * s1 + R[5] * R[5] * s2;
+    S[4] = R[3] * R[6] * s0 + R[4] * R[7] * s1 + R[5] * R[8] * s2;
+    S[5] = R[6] * R[6] * s0 + R[7] * R[7] * s1 + R[8] * R[8] * s2;
+}
+
+struct Proj {
+    float t[3];          // view-space position
+    float u, v;          // clamped tx/tz, ty/tz
+    bool uc, vc;         // clamp active
+    float M0[3], M1[3];  // rows of J * Rv
+    float fx, fy;
+};
+
+__device__ __forceinline__ void project(const VcrRasterArgs& a, const Cam& cam, const float p[3], Proj& pr) {
+    const float* V = cam.V;
+    pr.t[0] = p[0] * V[0] + p[1] * V[4] + p[2] * V[8] + V[12];
+    pr.t[1] = p[0] * V[1] + p[1] * V[5] + p[2] * V[9] + V[13];
+    pr.t[2] = p[0] * V[2] + p[1] * V[6] + p[2] * V[10] + V[14];
+    pr.fx = a.W / (2.f * a.tanfovx);
+    pr.fy = a.H / (2.f * a.tanfovy);
+}
+
+__device__ __forceinline__ void jacobian_rows(const VcrRasterArgs& a, const Cam& cam, Proj& pr) {
+    const float* V = cam.V;
+    const float tz = pr.t[2], itz = 1.f / tz;
+    const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
+    const float ru = pr.t[0] * itz, rv = pr.t[1] * itz;
+    pr.uc = (ru < -limx) || (ru > limx);
+    pr.vc = (rv < -limy) || (rv > limy);
+    pr.u = fminf(limx, fmaxf(-limx, ru));
+    pr.v = fminf(limy, fmaxf(-limy, rv));
+    const float J00 = pr.fx * itz, J02 = -pr.fx * pr.u * itz;
+    const float J11 = pr.fy * itz, J12 = -pr.fy * pr.v * itz;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {           // Rv[c][k] = V[k*4+c]
+        pr.M0[k] = J00 * V[k * 4 + 0] + J02 * V[k * 4 + 2];
+        pr.M1[k] = J11 * V[k * 4 + 1] + J12 * V[k * 4 + 2];
+    }
+}
+
+__device__ __forceinline__ void sym_mul(const float S[6], const float m[3], float o[3]) {
+    o[0] = S[0] * m[0] + S[1] * m[1] + S[2] * m[2];
+    o[1] = S[1] * m[0] + S[3] * m[1] + S[4] * m[2];
+    o[2] = S[2] * m[0] + S[4] * m[1] + S[5] * m[2];
+}
+
+// SH basis of tools/sh_utils.py:57-112 with signs folded in; optional derivatives w.r.t. the direction.
+template <bool GRAD>
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float b[16], float bx[16], float by[16],
+                                         float bz[16]) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        b[k] = 0.f;
+        if (GRAD) { bx[k] = 0.f; by[k] = 0.f; bz[k] = 0.f; }
+    }
+    b[0] = SH_C0;
+    if (deg < 1) return;
+    b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+    if (GRAD) { by[1] = -SH_C1; bz[2] = SH_C1; bx[3] = -SH_C1; }
+    if (deg < 2) return;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    b[4] = SH_C2_0 * xy; b[5] = SH_C2_1 * yz; b[6] = SH_C2_2 * (2.f * zz - xx - yy);
+    b[7] = SH_C2_3 * xz; b[8] = SH_C2_4 * (xx - yy);
+    if (GRAD) {
+        bx[4] = SH_C2_0 * y; by[4] = SH_C2_0 * x;
+        by[5] = SH_C2_1 * z; bz[5] = SH_C2_1 * y;
+        bx[6] = -2.f * SH_C2_2 * x; by[6] = -2.f * SH_C2_2 * y; bz[6] = 4.f * SH_C2_2 * z;
+        bx[7] = SH_C2_3 * z; bz[7] = SH_C2_3 * x;
+        bx[8] = 2.f * SH_C2_4 * x; by[8] = -2.f * SH_C2_4 * y;
+    }
+    if (deg < 3) return;
+    b[9] = SH_C3_0 * y * (3.f * xx - yy);
+    b[10] = SH_C3_1 * xy * z;
+    b[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
+    b[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+    b[13] = SH_C3_4 * x * (4.f * zz - xx - yy);
+    b[14] = SH_C3_5 * z * (xx - yy);
+    b[15] = SH_C3_6 * x * (xx - 3.f * yy);
+    if (GRAD) {
+        bx[9] = SH_C3_0 * 6.f * xy; by[9] = SH_C3_0 * (3.f * xx - 3.f * yy);
+        bx[10] = SH_C3_1 * yz; by[10] = SH_C3_1 * xz; bz[10] = SH_C3_1 * xy;
+        bx[11] = SH_C3_2 * (-2.f * xy); by[11] = SH_C3_2 * (4.f * zz - xx - 3.f * yy); bz[11] = SH_C3_2 * 8.f * yz;
+        bx[12] = SH_C3_3 * (-6.f * xz); by[12] = SH_C3_3 * (-6.f * yz); bz[12] = SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy);
+        bx[13] = SH_C3_4 * (4.f * zz - 3.f * xx - yy); by[13] = SH_C3_4 * (-2.f * xy); bz[13] = SH_C3_4 * 8.f * xz;
+        bx[14] = SH_C3_5 * 2.f * xz; by[14] = SH_C3_5 * (-2.f * yz); bz[14] = SH_C3_5 * (xx - yy);
+        bx[15] = SH_C3_6 * (3.f * xx - 3.f * yy); by[15] = SH_C3_6 * (-6.f * xy);
+    }
+}
+
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, GeomState g, int32_t* __restrict__ radii,
+                                                             uint32_t* __restrict__ depth_key,
+                                                             uint32_t* __restrict__ ids) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.N) return;
+    ids[i] = i;
+    radii[i] = 0;
+    g.tiles[i] = 0;
+    depth_key[i] = 0xFFFFFFFFu;
+
+    const Cam cam = load_cam(a);
+    const float p[3] = {a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2]};
+    Proj pr;
+    project(a, cam, p, pr);
+    if (pr.t[2] <= VCR_NEAR) return;
+
+    const float* P = cam.P;
+    const float hx = p[0] * P[0] + p[1] * P[4] + p[2] * P[8] + P[12];
+    const float hy = p[0] * P[1] + p[1] * P[5] + p[2] * P[9] + P[13];
+    const float hw = p[0] * P[3] + p[1] * P[7] + p[2] * P[11] + P[15];
+    const float pw = 1.f / (hw + 1e-7f);
+
+    float S[6], R[9], s[3];
+    load_cov3d(a, i, S, R, s);
+    jacobian_rows(a, cam, pr);
+    float SM0[3], SM1[3];
+    sym_mul(S, pr.M0, SM0);
+    sym_mul(S, pr.M1, SM1);
+    const float ca = pr.M0[0] * SM0[0] + pr.M0[1] * SM0[1] + pr.M0[2] * SM0[2] + VCR_LOWPASS;
+    const float cb = pr.M0[0] * SM1[0] + pr.M0[1] * SM1[1] + pr.M0[2] * SM1[2];
+    const float cc = pr.M1[0] * SM1[0] + pr.M1[1] * SM1[1] + pr.M1[2] * SM1[2] + VCR_LOWPASS;
+    const float det = ca * cc - cb * cb;
+    if (det == 0.f) return;
+    const float idet = 1.f / det;
+    const float mid = 0.5f * (ca + cc);
+    const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float rad = ceilf(3.f * sqrtf(lam));
+
+    const float px = ((hx * pw + 1.f) * a.W - 1.f) * 0.5f;
+    const float py = ((hy * pw + 1.f) * a.H - 1.f) * 0.5f;
+    const int gx = (a.W + VCR_TILE - 1) / VCR_TILE, gy = (a.H + VCR_TILE - 1) / VCR_TILE;
+    const int xmin = min(gx, max(0, (int)floorf((px - rad) / VCR_TILE)));
+    const int xmax = min(gx, max(0, (int)floorf((px + rad + VCR_TILE - 1) / VCR_TILE)));
+    const int ymin = min(gy, max(0, (int)floorf((py - rad) / VCR_TILE)));
+    const int ymax = min(gy, max(0, (int)floorf((py + rad + VCR_TILE - 1) / VCR_TILE)));
+    const int ntiles = (xmax - xmin) * (ymax - ymin);
+    if (ntiles <= 0) return;
+
+    GeomRec rec;
+    uint8_t clampbits = 0;
+    if (a.colors_precomp) {
+        rec.r = a.colors_precomp[3 * (size_t)i]; rec.g = a.colors_precomp[3 * (size_t)i + 1];
+        rec.b = a.colors_precomp[3 * (size_t)i + 2];
+    } else {
+        float dx = p[0] - cam.c[0], dy = p[1] - cam.c[1], dz = p[2] - cam.c[2];
+        const float il = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+        dx *= il; dy *= il; dz *= il;
+        float b[16];
+        sh_basis<false>(a.sh_degree, dx, dy, dz, b, nullptr, nullptr, nullptr);
+        const float* sh = a.shs + (size_t)i * a.K * 3;
+        const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
+        float c0 = 0.5f, c1 = 0.5f, c2 = 0.5f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k < nb) {
+                c0 += b[k] * sh[3 * k]; c1 += b[k] * sh[3 * k + 1]; c2 += b[k] * sh[3 * k + 2];
+            }
+        }
+        if (c0 < 0.f) { c0 = 0.f; clampbits |= 1; }
+        if (c1 < 0.f) { c1 = 0.f; clampbits |= 2; }
+        if (c2 < 0.f) { c2 = 0.f; clampbits |= 4; }
+        rec.r = c0; rec.g = c1; rec.b = c2;
+    }
+    rec.px = px; rec.py = py; rec.z = pr.t[2]; rec.opacity = a.opacities[i];
+    rec.ca = cc * idet; rec.cb = -cb * idet; rec.cc = ca * idet;
+    if (a.normals_precomp) {
+        rec.nx = a.normals_precomp[3 * (size_t)i]; rec.ny = a.normals_precomp[3 * (size_t)i + 1];
+        rec.nz = a.normals_precomp[3 * (size_t)i + 2];
+        rec.plane = rec.nx * pr.t[0] + rec.ny * pr.t[1] + rec.nz * pr.t[2];
+    } else {
+        rec.nx = rec.ny = rec.nz = 0.f; rec.plane = 0.f;
+    }
+    rec.pad0 = 0.f; rec.pad1 = 0.f;
+    float4* dst = reinterpret_cast<float4*>(g.rec + i);
+    const float4* src = reinterpret_cast<const float4*>(&rec);
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    for (int k = 0; k < a.S; ++k) g.sem[(size_t)i * a.S + k] = a.semantics_precomp[(size_t)i * a.S + k];
+    g.clamped[i] = clampbits;
+    g.tiles[i] = (uint32_t)ntiles;
+    radii[i] = (int32_t)rad;
+    depth_key[i] = __float_as_uint(pr.t[2]);
+}
+
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, GeomState g, const int32_t* __restrict__ radii,
+                                                             const GradRec* __restrict__ sgrad,
+                                                             const float* __restrict__ sgrad_sem, VcrBackwardIO io) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.N) return;
+    const size_t i3 = 3 * (size_t)i;
+    const bool vis = radii[i] > 0;
+    const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
+
+    float dp[3] = {0.f, 0.f, 0.f};                 // dL/dmeans3D
+    float dm2[2] = {0.f, 0.f}, dm2a[2] = {0.f, 0.f};
+    float dn[3] = {0.f, 0.f, 0.f};
+    float dop = 0.f;
+    float dS[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // dL/dSigma (symmetric, full-matrix entries)
+    float dcol[3] = {0.f, 0.f, 0.f};
+    float R[9], s[3], S[6];
+    float dsc[3] = {0.f, 0.f, 0.f};
+    float dq[4] = {0.f, 0.f, 0.f, 0.f};
+
+    if (vis) {
+        const Cam cam = load_cam(a);
+        const float* V = cam.V;
+        const float* P = cam.P;
+        const GradRec gr = sgrad[i];
+        const float p[3] = {a.means3D[i3], a.means3D[i3 + 1], a.means3D[i3 + 2]};
+        Proj pr;
+        project(a, cam, p, pr);
+        load_cov3d(a, i, S, R, s);
+        jacobian_rows(a, cam, pr);
+        float SM0[3], SM1[3];
+        sym_mul(S, pr.M0, SM0);
+        sym_mul(S, pr.M1, SM1);
+        const float ca = pr.M0[0] * SM0[0] + pr.M0[1] * SM0[1] + pr.M0[2] * SM0[2] + VCR_LOWPASS;
+        const float cb = pr.M0[0] * SM1[0] + pr.M0[1] * SM1[1] + pr.M0[2] * SM1[2];
+        const float cc = pr.M1[0] * SM1[0] + pr.M1[1] * SM1[1] + pr.M1[2] * SM1[2] + VCR_LOWPASS;
+        const float det = ca * cc - cb * cb;
+        const float id2 = 1.f / (det * det);
+        // conic (A,B,C) = (c,-b,a)/det  ->  cov2D (a,b,c)
+        const float gA = gr.ca, gB = gr.cb, gC = gr.cc;
+        const float ga = (-cc * cc * gA + cb * cc * gB - cb * cb * gC) * id2;
+        const float gc = (-ca * ca * gC + ca * cb * gB - cb * cb * gA) * id2;
+        const float gb = (2.f * cb * cc * gA - (ca * cc + cb * cb) * gB + 2.f * ca * cb * gC) * id2;
+        const float hb = 0.5f * gb;
+        // dSigma = M^T G M
+        const float* M0 = pr.M0; const float* M1 = pr.M1;
+        dS[0] = ga * M0[0] * M0[0] + gb * M0[0] * M1[0] + gc * M1[0] * M1[0];
+        dS[3] = ga * M0[1] * M0[1] + gb * M0[1] * M1[1] + gc * M1[1] * M1[1];
+        dS[5] = ga * M0[2] * M0[2] + gb * M0[2] * M1[2] + gc * M1[2] * M1[2];
+        dS[1] = ga * M0[0] * M0[1] + hb * (M0[0] * M1[1] + M1[0] * M0[1]) + gc * M1[0] * M1[1];
+        dS[2] = ga * M0[0] * M0[2] + hb * (M0[0] * M1[2] + M1[0] * M0[2]) + gc * M1[0] * M1[2];
+        dS[4] = ga * M0[1] * M0[2] + hb * (M0[1] * M1[2] + M1[1] * M0[2]) + gc * M1[1] * M1[2];
+        // dM = 2 G M Sigma
+        float dM0[3], dM1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            dM0[k] = 2.f * (ga * SM0[k] + hb * SM1[k]);
+            dM1[k] = 2.f * (hb * SM0[k] + gc * SM1[k]);
+        }
+        // dJ = dM Rv^T, Rv[c][k] = V[k*4+c]
+        const float dJ00 = dM0[0] * V[0] + dM0[1] * V[4] + dM0[2] * V[8];
+        const float dJ02 = dM0[0] * V[2] + dM0[1] * V[6] + dM0[2] * V[10];
+        const float dJ11 = dM1[0] * V[1] + dM1[1] * V[5] + dM1[2] * V[9];
+        const float dJ12 = dM1[0] * V[2] + dM1[1] * V[6] + dM1[2] * V[10];
+        const float tz = pr.t[2], itz = 1.f / tz, itz2 = itz * itz;
+        float dt[3] = {0.f, 0.f, 0.f};
+        dt[2] = (-dJ00 * pr.fx + dJ02 * pr.fx * pr.u - dJ11 * pr.fy + dJ12 * pr.fy * pr.v) * itz2;
+        const float du = -dJ02 * pr.fx * itz, dv = -dJ12 * pr.fy * itz;
+        if (!pr.uc) { dt[0] += du * itz; dt[2] -= du * pr.t[0] * itz2; }
+        if (!pr.vc) { dt[1] += dv * itz; dt[2] -= dv * pr.t[1] * itz2; }
+        // depth and plane offset
+        dt[2] += gr.z;
+        if (a.normals_precomp) {
+            const float n[3] = {a.normals_precomp[i3], a.normals_precomp[i3 + 1], a.normals_precomp[i3 + 2]};
+            dt[0] += n[0] * gr.plane; dt[1] += n[1] * gr.plane; dt[2] += n[2] * gr.plane;
+            dn[0] = gr.nx + pr.t[0] * gr.plane; dn[1] = gr.ny + pr.t[1] * gr.plane; dn[2] = gr.nz + pr.t[2] * gr.plane;
+        }
+        // t = p Rv^T + tv  ->  dp_k += sum_c dt_c V[k*4+c]
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dp[k] += dt[0] * V[k * 4 + 0] + dt[1] * V[k * 4 + 1] + dt[2] * V[k * 4 + 2];
+        // pixel position through the full projection
+        const float hx = p[0] * P[0] + p[1] * P[4] + p[2] * P[8] + P[12];
+        const float hy = p[0] * P[1] + p[1] * P[5] + p[2] * P[9] + P[13];
+        const float hw = p[0] * P[3] + p[1] * P[7] + p[2] * P[11] + P[15];
+        const float pw = 1.f / (hw + 1e-7f);
+        dm2[0] = gr.gx * 0.5f * a.W; dm2[1] = gr.gy * 0.5f * a.H;
+        dm2a[0] = gr.agx * 0.5f * a.W; dm2a[1] = gr.agy * 0.5f * a.H;
+        const float dhx = dm2[0] * pw, dhy = dm2[1] * pw;
+        const float dhw = -(hx * dm2[0] + hy * dm2[1]) * pw * pw;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dp[k] += P[k * 4 + 0] * dhx + P[k * 4 + 1] * dhy + P[k * 4 + 3] * dhw;
+        dop = gr.opacity;
+        // colour
+        dcol[0] = gr.r; dcol[1] = gr.g; dcol[2] = gr.b;
+        if (!a.colors_precomp) {
+            const uint8_t cl = g.clamped[i];
+            if (cl & 1) dcol[0] = 0.f;
+            if (cl & 2) dcol[1] = 0.f;
+            if (cl & 4) dcol[2] = 0.f;
+            float dx = p[0] - cam.c[0], dy = p[1] - cam.c[1], dz = p[2] - cam.c[2];
+            const float il = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+            dx *= il; dy *= il; dz *= il;
+            float b[16], bx[16], by[16], bz[16];
+            sh_basis<true>(a.sh_degree, dx, dy, dz, b, bx, by, bz);
+            const float* sh = a.shs + (size_t)i * a.K * 3;
+            float* dsh = io.dL_dshs + (size_t)i * a.K * 3;
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < nb) {
+                    const float w = sh[3 * k] * dcol[0] + sh[3 * k + 1] * dcol[1] + sh[3 * k + 2] * dcol[2];
+                    ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;
+                    dsh[3 * k] = b[k] * dcol[0]; dsh[3 * k + 1] = b[k] * dcol[1]; dsh[3 * k + 2] = b[k] * dcol[2];
+                }
+            }
+            for (int k = nb; k < a.K; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+            const float dot = dx * ddx + dy * ddy + dz * ddz;       // through normalize()
+            dp[0] += (ddx - dx * dot) * il; dp[1] += (ddy - dy * dot) * il; dp[2] += (ddz - dz * dot) * il;
+        }
+        // Sigma = (R s)(R s)^T
+        if (!a.cov3D_precomp) {
+            float dR[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float d0 = (r == 0 ? dS[0] : (r == 1 ? dS[1] : dS[2]));
+                const float d1 = (r == 0 ? dS[1] : (r == 1 ? dS[3] : dS[4]));
+                const float d2 = (r == 0 ? dS[2] : (r == 1 ? dS[4] : dS[5]));
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    // dL_rk = 2 * sum_j dSigma[r][j] L[j][k], L[j][k] = R[j][k] s_k
+                    const float dL = 2.f * (d0 * R[0 * 3 + k] + d1 * R[1 * 3 + k] + d2 * R[2 * 3 + k]) * s[k];
+                    dsc[k] += dL * R[r * 3 + k];
+                    dR[r * 3 + k] = dL * s[k];
+                }
+            }
+            const float4 q = reinterpret_cast<const float4*>(a.rotations)[i];
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            dq[0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+            dq[1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
+            dq[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
+            dq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+            dsc[0] *= a.scale_modifier; dsc[1] *= a.scale_modifier; dsc[2] *= a.scale_modifier;
+        }
+    } else if (io.dL_dshs) {
+        float* dsh = io.dL_dshs + (size_t)i * a.K * 3;
+        for (int k = 0; k < a.K * 3; ++k) dsh[k] = 0.f;
+    }
+
+    io.dL_dmeans3D[i3] = dp[0]; io.dL_dmeans3D[i3 + 1] = dp[1]; io.dL_dmeans3D[i3 + 2] = dp[2];
+    io.dL_dmeans2D[i3] = dm2[0]; io.dL_dmeans2D[i3 + 1] = dm2[1]; io.dL_dmeans2D[i3 + 2] = 0.f;
+    if (io.dL_dmeans2D_densify) {
+        io.dL_dmeans2D_densify[i3] = dm2a[0]; io.dL_dmeans2D_densify[i3 + 1] = dm2a[1];
+        io.dL_dmeans2D_densify[i3 + 2] = 0.f;
+    }
+    io.dL_dopacities[i] = dop;
+    if (io.dL_dcolors) { io.dL_dcolors[i3] = dcol[0]; io.dL_dcolors[i3 + 1] = dcol[1]; io.dL_dcolors[i3 + 2] = dcol[2]; }
+    if (io.dL_dnormals) { io.dL_dnormals[i3] = dn[0]; io.dL_dnormals[i3 + 1] = dn[1]; io.dL_dnormals[i3 + 2] = dn[2]; }
+    if (io.dL_dsemantics)
+        for (int k = 0; k < a.S; ++k) io.dL_dsemantics[(size_t)i * a.S + k] = vis ? sgrad_sem[(size_t)i * a.S + k] : 0.f;
+    if (io.dL_dscales) {
+        io.dL_dscales[i3] = dsc[0]; io.dL_dscales[i3 + 1] = dsc[1]; io.dL_dscales[i3 + 2] = dsc[2];
+        reinterpret_cast<float4*>(io.dL_drotations)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    }
+    if (io.dL_dcov3D) {
+        float* d = io.dL_dcov3D + 6 * (size_t)i;
+        d[0] = dS[0]; d[1] = 2.f * dS[1]; d[2] = 2.f * dS[2]; d[3] = dS[3]; d[4] = 2.f * dS[4]; d[5] = dS[5];
+    }
+}
+
+}  // namespace
+
+int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key, uint32_t* ids,
+                          hipStream_t st) {
+    if (a.N == 0) return 0;
+    const int blocks = (a.N + 255) / 256;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, st, a, g, radii, depth_key, ids);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const GradRec* sgrad,
+                                   const float* sgrad_sem, VcrBackwardIO& io, hipStream_t st) {
+    if (a.N == 0) return 0;
+    const int blocks = (a.N + 255) / 256;
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(blocks), dim3(256), 0, st, a, g, radii, sgrad, sgrad_sem, io);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}

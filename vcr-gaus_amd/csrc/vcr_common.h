@@ -1,0 +1,132 @@
+// Internal definitions shared by the gfx950 kernels of libvcr_raster.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vcr_raster.h"
+
+#define VCR_TILE 16
+#define VCR_TILE_PIX 256
+#define VCR_ALPHA_MIN (1.0f / 255.0f)
+#define VCR_ALPHA_MAX 0.99f
+#define VCR_T_EPS 1e-4f
+#define VCR_NEAR 0.2f
+#define VCR_LOWPASS 0.3f
+#define VCR_PLANE_EPS 1e-4f
+#define VCR_MAX_SEM 4
+
+// Per-Gaussian screen-space record consumed by the compositing kernels: one 64-byte line, so a
+// gather by sorted id touches exactly one half cache line.
+struct __attribute__((aligned(16))) GeomRec {
+    float px, py, z, opacity;     // q0: pixel-space centre, view-space depth, opacity
+    float ca, cb, cc, plane;      // q1: conic (A,B,C), plane offset n . mu_cam
+    float r, g, b, pad0;          // q2: colour
+    float nx, ny, nz, pad1;       // q3: camera-space normal
+};
+static_assert(sizeof(GeomRec) == 64, "GeomRec must be one 64-byte line");
+
+// Per-Gaussian screen-space gradient record written by the compositing backward (atomics) and
+// consumed by the preprocess backward.
+struct __attribute__((aligned(16))) GradRec {
+    float gx, gy, agx, agy;       // dL/dpx, dL/dpy, sum|dL/dpx|, sum|dL/dpy|
+    float ca, cb, cc, opacity;    // dL/dconic, dL/dopacity
+    float r, g, b, z;             // dL/drgb, dL/dz (centre depth)
+    float plane, nx, ny, nz;      // dL/dplane, dL/dnormal
+};
+static_assert(sizeof(GradRec) == 64, "GradRec must be 64 bytes");
+#define VCR_GRAD_FLOATS 16
+
+static inline size_t vcr_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ---- state buffer views -------------------------------------------------------------------
+struct GeomState {
+    GeomRec* rec;        // [N]
+    float* sem;          // [N,S]
+    uint32_t* tiles;     // [N] tiles touched (0 = culled)
+    uint8_t* clamped;    // [N] bit c set when colour channel c was clamped at 0
+    static size_t bytes(int N, int S) {
+        return vcr_align(sizeof(GeomRec) * (size_t)N) + vcr_align(sizeof(float) * (size_t)N * (S > 0 ? S : 1)) +
+               vcr_align(sizeof(uint32_t) * (size_t)N) + vcr_align((size_t)N);
+    }
+    static GeomState view(void* p, int N, int S) {
+        GeomState g;
+        char* c = (char*)p;
+        g.rec = (GeomRec*)c;      c += vcr_align(sizeof(GeomRec) * (size_t)N);
+        g.sem = (float*)c;        c += vcr_align(sizeof(float) * (size_t)N * (S > 0 ? S : 1));
+        g.tiles = (uint32_t*)c;   c += vcr_align(sizeof(uint32_t) * (size_t)N);
+        g.clamped = (uint8_t*)c;
+        return g;
+    }
+};
+
+struct BinState {
+    uint32_t* point_list;  // [R] Gaussian ids, (tile, depth, id)-ordered
+    uint2* ranges;         // [T] per-tile [begin,end)
+    static size_t bytes(int64_t R, int T) {
+        return vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1)) + vcr_align(sizeof(uint2) * (size_t)T);
+    }
+    static BinState view(void* p, int64_t R, int T) {
+        BinState b;
+        char* c = (char*)p;
+        b.point_list = (uint32_t*)c;  c += vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1));
+        b.ranges = (uint2*)c;
+        return b;
+    }
+};
+
+struct ImageState {
+    float* final_T;        // [H*W]
+    uint32_t* n_contrib;   // [H*W] index (1-based, within the tile list) of the last contributor
+    static size_t bytes(int P) { return vcr_align(sizeof(float) * (size_t)P) + vcr_align(sizeof(uint32_t) * (size_t)P); }
+    static ImageState view(void* p, int P) {
+        ImageState s;
+        char* c = (char*)p;
+        s.final_T = (float*)c;  c += vcr_align(sizeof(float) * (size_t)P);
+        s.n_contrib = (uint32_t*)c;
+        return s;
+    }
+};
+
+// ---- SH constants (tools/sh_utils.py:24-52) -------------------------------------------------
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+#define SH_C2_0 1.0925484305920792f
+#define SH_C2_1 -1.0925484305920792f
+#define SH_C2_2 0.31539156525252005f
+#define SH_C2_3 -1.0925484305920792f
+#define SH_C2_4 0.5462742152960396f
+#define SH_C3_0 -0.5900435899266435f
+#define SH_C3_1 2.890611442640554f
+#define SH_C3_2 -0.4570457994644658f
+#define SH_C3_3 0.3731763325901154f
+#define SH_C3_4 -0.4570457994644658f
+#define SH_C3_5 1.445305721320277f
+#define SH_C3_6 -0.5900435899266435f
+
+void vcr_set_error(const char* fmt, ...);
+#define VCR_HIP_CHECK(expr)                                                                     \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            vcr_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                           \
+        }                                                                                       \
+    } while (0)
+
+// ---- stage launchers (defined in the .hip files) ----------------------------------------------
+int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key,
+                          uint32_t* ids, hipStream_t st);
+int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const int32_t* radii,
+                                   const GradRec* sgrad, const float* sgrad_sem, VcrBackwardIO& io,
+                                   hipStream_t st);
+size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits);
+int vcr_depth_sort_and_scan(int N, const uint32_t* depth_key, const uint32_t* ids, uint32_t* key_sorted,
+                            uint32_t* ids_sorted, const uint32_t* tiles, uint32_t* offsets, void* temp,
+                            size_t temp_bytes, hipStream_t st);
+int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const uint32_t* ids_sorted,
+                           const uint32_t* offsets, int64_t R, int tile_bits, uint32_t* keys_a, uint32_t* vals_a,
+                           uint32_t* keys_b, uint32_t* point_list, uint2* ranges, int num_tiles, void* temp,
+                           size_t temp_bytes, hipStream_t st);
+int vcr_launch_composite_forward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o,
+                                 hipStream_t st);
+int vcr_launch_composite_backward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
+                                  const float* dL_dout, GradRec* sgrad, float* sgrad_sem, hipStream_t st);

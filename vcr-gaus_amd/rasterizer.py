@@ -1,0 +1,173 @@
+"""`GaussianRasterizationSettings` / `GaussianRasterizer`: the Python face of the drop-in boundary.
+
+Same names, keyword arguments, return tuples and error behaviour as the reference's un-vendored
+extension (call sites `gaussian_renderer/__init__.py:43-59,107-120,332-344,441-453,550-562`);
+the arithmetic is in libvcr_raster.so (HIP, gfx950) reached through ctypes.
+"""
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool = False
+    debug: bool = False
+    f_count: int = 0          # optional: `render_fast` omits it (gaussian_renderer/__init__.py:183-196)
+
+
+class _Allocator:
+    """Backs the C-side allocation callback with torch's caching allocator (stream-ordered reuse)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = {}
+        self.scratch = []
+
+        def _cb(_user, tag, nbytes):
+            t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
+            if tag == _lib.BUF_SCRATCH:
+                self.scratch.append(t)
+            else:
+                self.bufs[tag] = t
+            return t.data_ptr()
+
+        self.cb = _lib.ALLOC_FN(_cb)
+
+
+def _f32(t):
+    return None if t is None else t.detach().contiguous().float()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError("vcr_raster: " + _lib.last_error())
+
+
+last_stats = {}   # R / V of the most recent forward (for benchmarks; not part of the reference API)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, means2D_densify, sh, colors_precomp, normals_precomp,
+                semantics_precomp, opacities, scales, rotations, cov3Ds_precomp, dirs, rs):
+        lib = _lib.load()
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise RuntimeError("vcr_raster: tensors must live on a HIP device (no CPU path exists)")
+        N = means3D.shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        t = dict(means3D=_f32(means3D), shs=_f32(sh), colors=_f32(colors_precomp), normals=_f32(normals_precomp),
+                 sem=_f32(semantics_precomp), opac=_f32(opacities), scales=_f32(scales), rots=_f32(rotations),
+                 cov=_f32(cov3Ds_precomp), dirs=_f32(dirs), bg=_f32(rs.bg).to(dev), view=_f32(rs.viewmatrix).to(dev),
+                 proj=_f32(rs.projmatrix).to(dev), campos=_f32(rs.campos).to(dev))
+        S = 0 if t["sem"] is None else int(t["sem"].shape[1])
+        K = 0 if t["shs"] is None else int(t["shs"].shape[1])
+        a = _lib.VcrRasterArgs(N=N, H=H, W=W, S=S, K=K, sh_degree=int(rs.sh_degree), f_count=int(rs.f_count),
+                               num_dist=0, debug=int(bool(rs.debug)), tanfovx=float(rs.tanfovx),
+                               tanfovy=float(rs.tanfovy), scale_modifier=float(rs.scale_modifier),
+                               bg=_ptr(t["bg"]), viewmatrix=_ptr(t["view"]), projmatrix=_ptr(t["proj"]),
+                               campos=_ptr(t["campos"]), means3D=_ptr(t["means3D"]), shs=_ptr(t["shs"]),
+                               colors_precomp=_ptr(t["colors"]), normals_precomp=_ptr(t["normals"]),
+                               semantics_precomp=_ptr(t["sem"]), opacities=_ptr(t["opac"]), scales=_ptr(t["scales"]),
+                               rotations=_ptr(t["rots"]), cov3D_precomp=_ptr(t["cov"]), dirs=_ptr(t["dirs"]))
+        fc = int(rs.f_count)
+        C = 8 + S
+        out = torch.empty((C if fc == 0 else 3, H, W), dtype=torch.float32, device=dev) if fc != 3 else None
+        radii = torch.zeros(N, dtype=torch.int32, device=dev)
+        count = torch.zeros(N, dtype=torch.int32, device=dev) if fc != 0 else None
+        score = torch.zeros(N, dtype=torch.float32, device=dev) if fc in (1, 2) else None
+        fo = _lib.VcrForwardOut(out=_ptr(out), radii=_ptr(radii), count=_ptr(count), score=_ptr(score))
+        al = _Allocator(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _check(lib.vcr_rasterize_forward(a, fo, al.cb, None, stream))
+        last_stats.update(R=int(fo.num_rendered), V=int(fo.num_visible), N=N)
+        if fc == 0:
+            ctx.rs, ctx.args_t, ctx.state = rs, t, al.bufs
+            ctx.num_rendered = int(fo.num_rendered)
+            ctx.has = (means2D_densify is not None)
+            ctx.save_for_backward(radii)
+            ctx.mark_non_differentiable(radii)
+            return out, radii
+        if fc in (1, 2):
+            return count, score, out, radii
+        return count, radii
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_radii=None):
+        lib = _lib.load()
+        rs, t = ctx.rs, ctx.args_t
+        (radii,) = ctx.saved_tensors
+        dev = radii.device
+        N = t["means3D"].shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        S = 0 if t["sem"] is None else int(t["sem"].shape[1])
+        K = 0 if t["shs"] is None else int(t["shs"].shape[1])
+        a = _lib.VcrRasterArgs(N=N, H=H, W=W, S=S, K=K, sh_degree=int(rs.sh_degree), f_count=0, num_dist=0,
+                               debug=int(bool(rs.debug)), tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy),
+                               scale_modifier=float(rs.scale_modifier), bg=_ptr(t["bg"]), viewmatrix=_ptr(t["view"]),
+                               projmatrix=_ptr(t["proj"]), campos=_ptr(t["campos"]), means3D=_ptr(t["means3D"]),
+                               shs=_ptr(t["shs"]), colors_precomp=_ptr(t["colors"]), normals_precomp=_ptr(t["normals"]),
+                               semantics_precomp=_ptr(t["sem"]), opacities=_ptr(t["opac"]), scales=_ptr(t["scales"]),
+                               rotations=_ptr(t["rots"]), cov3D_precomp=_ptr(t["cov"]), dirs=_ptr(t["dirs"]))
+        g = grad_out.contiguous().float()
+
+        def new(*shape):
+            return torch.empty(shape, dtype=torch.float32, device=dev)
+
+        d_means3D, d_means2D, d_opac = new(N, 3), new(N, 3), new(N, 1)
+        d_dens = new(N, 3) if ctx.has else None
+        d_shs = new(N, K, 3) if t["shs"] is not None else None
+        d_col = new(N, 3) if t["colors"] is not None else None
+        d_nrm = new(N, 3) if t["normals"] is not None else None
+        d_sem = new(N, S) if t["sem"] is not None else None
+        d_sc = new(N, 3) if t["scales"] is not None else None
+        d_rot = new(N, 4) if t["rots"] is not None else None
+        d_cov = new(N, 6) if t["cov"] is not None else None
+        io = _lib.VcrBackwardIO(dL_dout=_ptr(g), geom=_ptr(ctx.state[_lib.BUF_GEOM]),
+                                binning=_ptr(ctx.state[_lib.BUF_BINNING]), image=_ptr(ctx.state[_lib.BUF_IMAGE]),
+                                radii=_ptr(radii), num_rendered=ctx.num_rendered, dL_dmeans3D=_ptr(d_means3D),
+                                dL_dmeans2D=_ptr(d_means2D), dL_dmeans2D_densify=_ptr(d_dens), dL_dshs=_ptr(d_shs),
+                                dL_dcolors=_ptr(d_col), dL_dnormals=_ptr(d_nrm), dL_dsemantics=_ptr(d_sem),
+                                dL_dopacities=_ptr(d_opac), dL_dscales=_ptr(d_sc), dL_drotations=_ptr(d_rot),
+                                dL_dcov3D=_ptr(d_cov))
+        al = _Allocator(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _check(lib.vcr_rasterize_backward(a, io, al.cb, None, stream))
+        return (d_means3D, d_means2D, d_dens, d_shs, d_col, d_nrm, d_sem, d_opac, d_sc, d_rot, d_cov, None, None)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, means2D_densify=None, shs=None, colors_precomp=None,
+                normals_precomp=None, semantics_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+                dirs=None, inside=None):
+        rs = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        return _RasterizeGaussians.apply(means3D, means2D, means2D_densify, shs, colors_precomp, normals_precomp,
+                                         semantics_precomp, opacities, scales, rotations, cov3D_precomp, dirs, rs)
