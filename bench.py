@@ -1,0 +1,145 @@
+#!/usr/bin/env python
+"""Headline benchmark: one training iteration of the rasterizer hot path per step.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched through
+torch.distributed.run with one rank per GPU (RCCL).  Prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json metric): 1 M synthetic Gaussians, 1920x1080, SH degree 3, intersection depth,
+one camera per rank per step (view-parallel weak scaling: each rank renders its own view, per-Gaussian
+gradients are all-reduced before the optimizer step).  Inputs are resident in HBM before timing starts.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="metric_1m_1080p")
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tile-stride", type=int, default=0, help="0 = auto (~15 s of CPU work)")
+    return ap.parse_args()
+
+
+def cpu_baseline(raw, cam, dirs, stride):
+    """Oracle (torch CPU restatement, fp32, all host cores) on a bounded sample of the SAME workload:
+    full per-Gaussian stage + every `stride`-th tile, forward + autograd backward; the tile part is
+    scaled by tiles_total/tiles_done to estimate a whole iteration."""
+    from oracle import model_torch as OM
+    from oracle import raster_torch as OR
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    act = OM.activations({k: v.cpu() for k, v in raw.items()})
+    leaves = {k: v.clone().requires_grad_(True) for k, v in act.items()}
+    nw = OM.get_normal(leaves["rotation"], leaves["scaling"])
+    ncam = OM.camera_normals(nw, leaves["xyz"], cam.camera_center.cpu(), cam.R_w2c.cpu())
+    s = OR.Settings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
+                    torch.zeros(3), 1.0, cam.world_view_transform.cpu(), cam.full_proj_transform.cpu(), 3,
+                    cam.camera_center.cpu())
+    N = act["xyz"].shape[0]
+    m2 = torch.zeros(N, 3, requires_grad=True)
+    tm = {}
+    t0 = time.perf_counter()
+    out, _, st = OR.rasterize(s, leaves["xyz"], m2, None, leaves["shs"], None, ncam, None, leaves["opacity"],
+                              leaves["scaling"], leaves["rotation"], None, dirs.cpu(), tile_stride=stride, timings=tm)
+    t1 = time.perf_counter()
+    out.abs().mean().backward()
+    t2 = time.perf_counter()
+    scale = tm["tiles_total"] / max(tm["tiles_done"], 1)
+    est = tm["pre_bin_s"] + (tm["tiles_s"] + (t2 - t1)) * scale
+    return {"value": 1.0 / est, "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/raster_torch.py fp32: full per-Gaussian stage + {tm['tiles_done']}/{tm['tiles_total']} "
+                      f"tiles fwd+bwd ({t2 - t0:.1f} s CPU), tile time scaled x{scale:.0f}",
+            "est_s_per_iter": est}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vcr_gaus_amd import _lib, synthetic
+    from vcr_gaus_amd.graphics_utils import get_all_px_dir
+    from vcr_gaus_amd.trainer import BenchTrainer
+
+    n, views, W, H, focal, sem = synthetic.WORKLOADS[args.workload]
+    raw = synthetic.make_gaussians(n, seed=0, sem_channels=sem)
+    cams = synthetic.make_cameras(max(args.views, world), W, H, focal, device=dev)
+    trainer = BenchTrainer(raw, cams, dev, world=world, rank=rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(i)
+    sync()
+    _lib.profile_enable(True)
+    _lib.profile_read()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.step(args.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt)
+
+    if rank == 0:
+        P = W * H
+        R = trainer.last_R
+        ms_fwd = prof["composite_fwd"][0] / max(prof["composite_fwd"][1], 1)
+        alg_bytes = (60 + 4 * sem) * R + (4 * (8 + sem) + 20) * P
+        achieved = alg_bytes / (ms_fwd * 1e-3) / 1e9 if ms_fwd > 0 else 0.0
+        stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
+        raster_fwd_ms = sum(stages[k] for k in ["preprocess", "depth_sort_scan", "binning", "composite_fwd"])
+        line = {
+            "metric": "train iters/sec @1M Gaussians 1080p (full step: render fwd, losses, bwd, optimizer)",
+            "value": world * args.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "gaussians": n, "width": W, "height": H, "sh_degree": 3,
+                       "views_per_step": world, "tile_instances_R": R, "visible_V": trainer.last_V,
+                       "step": trainer.describe()},
+            "raster_mpix_per_s": world * P / (raster_fwd_ms * 1e-3) / 1e6 if raster_fwd_ms > 0 else None,
+            "stage_ms": stages,
+            "roofline": {"kernel": "composite_fwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes": alg_bytes, "avg_ms": ms_fwd},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            stride = args.cpu_tile_stride or max(1, ((W + 15) // 16) * ((H + 15) // 16) // 48)
+            dirs = get_all_px_dir(cams[0].intr, H, W)
+            line["cpu_baseline"] = cpu_baseline(raw, cams[0], dirs, stride)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,6 +107,58 @@ int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* out,
 int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* io,
                            vcr_alloc_fn alloc, void* user, void* stream);
 
+/* ---- per-Gaussian parameter kernels around the rasterizer call -------------------------------------
+ * vcr_activate_*: replaces the chain GaussianModel.get_scaling/get_rotation/get_opacity
+ * (scene/gaussian_model.py:125-162), get_normal (:168-192, tools/general_utils.py:98-119) and the
+ * orientation + camera rotation of gaussian_renderer/__init__.py:95-101 by one pass each way.
+ * R_w2c: [3,3] row-major device matrix with n_cam = R_w2c * n_world (= cam.R.T).  aux: [N] bytes. */
+int vcr_activate_forward(int N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                         const float* xyz, const float* campos, const float* R_w2c, float* scales, float* rots,
+                         float* opac, float* normals_cam /* may be NULL */, uint8_t* aux, void* stream);
+int vcr_activate_backward(int N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                          const float* R_w2c, const uint8_t* aux, const float* d_scales, const float* d_rots,
+                          const float* d_opac, const float* d_normals /* any may be NULL */, float* d_scaling_raw,
+                          float* d_rotation_raw, float* d_opacity_raw, void* stream);
+/* One launch for all parameter groups; semantics of torch.optim.Adam(eps=1e-15) with per-group lr
+ * (scene/gaussian_model.py:247-258).  Pointer arrays are HOST arrays of device pointers (<= 8 tensors).
+ * grad_scale multiplies every gradient (1/world_size after a sum all-reduce). */
+int vcr_adam_step(int ntensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                  float* const* exp_avg_sq, const int64_t* numel, const float* lr, float beta1, float beta2,
+                  float eps, int step, float grad_scale, void* stream);
+/* add_densification_stats + max_radii2D update (scene/gaussian_model.py:669-671, trainer.py:345) */
+int vcr_densify_stats(int N, const float* grad2d /*[N,3]*/, const int32_t* radii, float* accum, float* denom,
+                      float* max_radii, void* stream);
+
+/* ---- image-space kernels of the D-Normal losses ------------------------------------------------------
+ * compute_normals (tools/normal_utils.py:30-41): depth [H,W] -> unit normal [H,W,3]; scratch6: [H*W*6]. */
+int vcr_depth_to_normal_forward(int H, int W, float fx, float fy, float cx, float cy, const float* depth,
+                                float* normal, void* stream);
+int vcr_depth_to_normal_backward(int H, int W, float fx, float fy, float cx, float cy, const float* depth,
+                                 const float* dnormal, float* scratch6, float* ddepth, void* stream);
+/* rendered normal [3,H,W] -> F.normalize -> [H,W,3] (gaussian_renderer/__init__.py:133-134) */
+int vcr_normalize_chw_forward(int P, const float* in_chw, float* out_hwc, void* stream);
+int vcr_normalize_chw_backward(int P, const float* in_chw, const float* dout_hwc, float* din_chw, void* stream);
+/* monosdf_normal_loss with the cos_weight confidence and boolean mask fused in
+ * (tools/loss_utils.py:122-143, trainer.py:261-293).  sums3 (device, fp64) = {sum w|p-g|_1, sum w(1-p.g), count};
+ * loss = (sums[0]+sums[1])/sums[2].  wsrc NULL or exp_t<=0 -> w=1.  dgt may be NULL. */
+int vcr_normal_loss_forward(int P, const float* pred, const float* gt, const float* wsrc, float exp_t,
+                            const uint8_t* mask, double* sums3, void* stream);
+int vcr_normal_loss_backward(int P, const float* pred, const float* gt, const float* wsrc, float exp_t,
+                             const uint8_t* mask, const double* sums3, const float* gout, float* dpred, float* dgt,
+                             void* stream);
+/* l1_loss + ssim (tools/loss_utils.py:36,49-92) in one pass over [3,H,W] images.  sums2 (device, fp64) =
+ * {sum|a-b|, sum ssim_map}; partials9: [9,H,W] scratch kept for backward (NULL for inference). */
+int vcr_l1_ssim_forward(int H, int W, const float* img1, const float* img2, double* sums2, float* partials9, void* stream);
+int vcr_l1_ssim_backward(int H, int W, const float* img1, const float* img2, const float* partials9, const float* g_l1,
+                         const float* g_ssim, float* dimg1, void* stream);
+
+/* Optional per-stage timing with HIP events recorded on the launch stream (used by bench.py for the
+ * live roofline figure; no reference counterpart).  Stage order: preprocess, depth sort+scan,
+ * duplicate+tile sort+ranges, composite forward, composite backward, preprocess backward. */
+void vcr_profile_enable(int on);
+int  vcr_profile_num_stages(void);
+int  vcr_profile_read(float* ms, int32_t* launches, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -286,8 +286,9 @@ def composite_tile(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem):
 
 def rasterize(s: Settings, means3D, means2D=None, means2D_densify=None, shs=None,
               colors_precomp=None, normals_precomp=None, semantics_precomp=None, opacities=None,
-              scales=None, rotations=None, cov3D_precomp=None, dirs=None, inside=None):
-    """Full forward.  f_count==0: (out[C,H,W], radii).  f_count==1/2: (count, score, image, radii).
+              scales=None, rotations=None, cov3D_precomp=None, dirs=None, inside=None, tile_stride=1,
+              timings=None):
+    """Full forward (tile_stride>1 composites only every k-th tile: bounded CPU-baseline sample).  f_count==0: (out[C,H,W], radii).  f_count==1/2: (count, score, image, radii).
     f_count==3: (count, radii).  C = 8 + S (colour3, depth1, normal3, alpha1, sem S)."""
     dt = means3D.dtype
     N = means3D.shape[0]
@@ -295,9 +296,12 @@ def rasterize(s: Settings, means3D, means2D=None, means2D_densify=None, shs=None
     if means2D is None:
         means2D = torch.zeros(N, 3, dtype=dt)
     num_sem = 0 if semantics_precomp is None else semantics_precomp.shape[1]
+    import time as _time
+    _t0 = _time.perf_counter()
     pre = preprocess(s, means3D, means2D, shs, colors_precomp, normals_precomp, semantics_precomp,
                      opacities, scales, rotations, cov3D_precomp)
     owner, beg, end, R = bin_and_sort(pre)
+    _t1 = _time.perf_counter()
     gx, gy = pre["grid"]
     C = 8 + num_sem
     img = torch.zeros(H, W, C, dtype=dt)
@@ -308,6 +312,8 @@ def rasterize(s: Settings, means3D, means2D=None, means2D_densify=None, shs=None
     for ty in range(gy):
         for tx in range(gx):
             t = ty * gx + tx
+            if t % tile_stride:
+                continue
             idx = owner[beg[t]:end[t]]
             xs, ys, out, Tfin, contrib, wgt = composite_tile(
                 s, pre, idx, tx * TILE, ty * TILE, means2D_densify, dirs, num_sem)
@@ -322,6 +328,11 @@ def rasterize(s: Settings, means3D, means2D=None, means2D_densify=None, shs=None
     rgb = img[:, :, :3] + Tmap[:, :, None] * bg[None, None]
     out = torch.cat([rgb, img[:, :, 3:]], -1).permute(2, 0, 1).contiguous()
     stats = dict(R=R, V=int(pre["vis"].sum()), final_T=Tmap)
+    if timings is not None:
+        timings["pre_bin_s"] = _t1 - _t0
+        timings["tiles_s"] = _time.perf_counter() - _t1
+        timings["tiles_done"] = len(range(0, gx * gy, tile_stride))
+        timings["tiles_total"] = gx * gy
     if s.f_count == 0:
         return out, pre["radii"], stats
     if s.f_count in (1, 2):

@@ -1,0 +1,203 @@
+"""CPU suite: the oracle against the reference's golden vectors / known answers, host-side geometry
+against the reference's outputs, and the C-ABI library's exported symbols (no compute without a GPU)."""
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses_torch as OL
+from oracle import raster_torch as OR
+from tests import util
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, name)).items()}
+
+
+# ---- golden vectors captured from the reference's own functions -------------------------------------
+def test_sh_colour_rule_matches_reference():
+    g = load("g3_sh.npz")
+    shs = g["sh"].permute(0, 2, 1).contiguous()          # reference layout [N,3,K] -> ours [N,K,3]
+    for deg in range(4):
+        rgb = torch.clamp_min(OR.eval_sh(deg, shs, g["dirs"]) + 0.5, 0.0)
+        assert torch.allclose(rgb, g[f"rgb_deg{deg}"], atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["a_plane", "a_sphere", "a_rand", "b_plane", "b_sphere", "b_rand"])
+def test_depth_normal_chain_matches_reference(tag):
+    g = load("g1_depth_normal.npz")
+    d = g[f"{tag}_depth"].double().requires_grad_(True)
+    n = OL.compute_normals(d, g[f"{tag}_K"])
+    assert torch.allclose(n.float(), g[f"{tag}_normal"], atol=2e-5)
+    loss = OL.masked_weighted_normal_loss(n, g[f"{tag}_gt"].double(), g[f"{tag}_rn"].double(), 0.01, g[f"{tag}_mask"])
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-5 * max(1.0, abs(float(g[f"{tag}_loss"])))
+    loss.backward()
+    ref = g[f"{tag}_ddepth"].double()
+    assert float((d.grad - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_l1_ssim_matches_reference(tag):
+    g = load("g2_l1_ssim.npz")
+    a = g[f"{tag}_a"].double().requires_grad_(True)
+    b = g[f"{tag}_b"].double()
+    l1, s = OL.l1_loss(a, b), OL.ssim(a, b)
+    assert abs(float(l1) - float(g[f"{tag}_l1"])) < 1e-6
+    assert abs(float(s) - float(g[f"{tag}_ssim"])) < 1e-5
+    (0.8 * l1 + 0.2 * (1 - s)).backward()
+    assert float((a.grad - g[f"{tag}_grad"].double()).abs().max()) < 1e-7
+
+
+def test_camera_conventions_match_reference():
+    from vcr_gaus_amd import graphics_utils as GU
+    from vcr_gaus_amd.cameras import Camera
+    g = np.load(os.path.join(G, "g4_cameras.npz"))
+    for i in range(3):
+        fovx, fovy = g[f"c{i}_fov"]
+        H, W = [int(x) for x in g[f"c{i}_hw"]]
+        cam = Camera(i, g[f"c{i}_R"], g[f"c{i}_T"], float(fovx), float(fovy), width=W, height=H,
+                     trans=g[f"c{i}_trans"], scale=float(g[f"c{i}_scale"]), device="cpu")
+        assert np.allclose(cam.world_view_transform.numpy(), g[f"c{i}_view"], atol=1e-6)
+        assert np.allclose(cam.projection_matrix.numpy(), g[f"c{i}_proj"], atol=1e-6)
+        assert np.allclose(cam.full_proj_transform.numpy(), g[f"c{i}_full"], atol=1e-5)
+        assert np.allclose(cam.camera_center.numpy(), g[f"c{i}_center"], atol=1e-5)
+        assert np.allclose(cam.intr.numpy(), g[f"c{i}_K"], atol=1e-4)
+        dirs = GU.get_all_px_dir(cam.intr, H, W)
+        assert np.allclose(dirs.numpy(), g[f"c{i}_dirs"], atol=1e-5)
+        f = GU.fov2focal(float(fovx), W)
+        assert np.allclose([f, GU.focal2fov(f, W)], g[f"c{i}_focal"])
+
+
+def test_misc_host_functions_match_reference():
+    from vcr_gaus_amd.general_utils import get_expon_lr_func
+    from vcr_gaus_amd.loss_utils import entropy_loss
+    from vcr_gaus_amd.normal_utils import get_edge_aware_distortion_map
+    g = load("g5_misc.npz")
+    lr = get_expon_lr_func(1.6e-4, 1.6e-6, lr_delay_mult=0.01, max_steps=30000)
+    assert np.allclose([lr(int(s)) for s in g["lr_steps"]], g["lr_vals"].numpy(), rtol=1e-12)
+    assert torch.allclose(get_edge_aware_distortion_map(g["img"], g["dist"]), g["edge"], atol=1e-7)
+    assert abs(float(entropy_loss(g["op"])) - float(g["entropy"])) < 1e-7
+    inside = torch.all(torch.abs((g["pts"] - g["trans"]) / g["scale"]) < 1, dim=-1)
+    assert torch.equal(inside, g["inside"])
+
+
+# ---- known answers for the rasterizer restatement (parity unpinned by the reference) ----------
+def _single_gaussian(dtype=torch.float64, opacity=0.8, z=4.0, s=0.05):
+    from vcr_gaus_amd import synthetic
+    W = H = 64
+    cam = synthetic.Camera(0, np.eye(3), np.zeros(3), 2 * math.atan(0.5), 2 * math.atan(0.5), width=W, height=H, device="cpu")
+    st = OR.Settings(H, W, 0.5, 0.5, torch.zeros(3), 1.0, cam.world_view_transform, cam.full_proj_transform, 0,
+                     cam.camera_center)
+    kw = dict(means3D=torch.tensor([[0.0, 0.0, z]], dtype=dtype), shs=None,
+              colors_precomp=torch.tensor([[0.2, 0.5, 0.9]], dtype=dtype),
+              normals_precomp=torch.tensor([[0.0, 0.0, 1.0]], dtype=dtype), opacities=torch.tensor([[opacity]], dtype=dtype),
+              scales=torch.full((1, 3), s, dtype=dtype), rotations=torch.tensor([[1.0, 0, 0, 0]], dtype=dtype))
+    return st, kw, (W, H, z, s, opacity)
+
+
+def test_single_isotropic_gaussian_closed_form():
+    st, kw, (W, H, z, s, o) = _single_gaussian()
+    out, radii, stats = OR.rasterize(st, **kw)
+    f = W / (2 * 0.5)
+    sig2 = (f * s / z) ** 2 + 0.3                     # EWA footprint + low-pass
+    cx = cy = (W - 1) / 2.0                            # NDC 0 -> pixel (W-1)/2
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    a = o * torch.exp(-0.5 * ((xs - cx) ** 2 + (ys - cy) ** 2) / sig2)
+    a = torch.where(a >= 1 / 255, torch.clamp(a, max=0.99), torch.zeros_like(a))
+    rad = math.ceil(3 * math.sqrt(sig2 + math.sqrt(0.1)))   # lambda = mid + sqrt(max(.1, mid^2 - det)), det = mid^2
+    assert int(radii[0]) == rad
+    # inside the tiles the Gaussian was binned to, the closed form holds
+    t0, t1 = int((cx - rad) // 16) * 16, int((cx + rad + 15) // 16) * 16
+    sl = (slice(t0, t1), slice(t0, t1))
+    assert torch.allclose(out[7][sl], a[sl], atol=1e-12)
+    assert torch.allclose(out[0][sl], 0.2 * a[sl], atol=1e-12)
+    assert torch.allclose(out[3][sl], z * a[sl], atol=1e-12)              # traditional depth (no dirs)
+    assert torch.allclose(out[6][sl], a[sl], atol=1e-12)                  # normal z
+    assert stats["R"] == ((t1 - t0) // 16) ** 2
+
+
+def test_fronto_parallel_plane_intersection_depth_is_planar():
+    """A fronto-parallel flattened Gaussian viewed with ray/plane depth renders depth = alpha * z for every
+    pixel (plane z = const), so compute_normals(depth/alpha) = (0,0,1)."""
+    from vcr_gaus_amd import graphics_utils as GU
+    st, kw, (W, H, z, s, o) = _single_gaussian(s=0.6)
+    K = GU.getIntrinsic(2 * math.atan(0.5), 2 * math.atan(0.5), H, W)
+    dirs = GU.get_all_px_dir(K, H, W).double()
+    out, _, _ = OR.rasterize(st, dirs=dirs, **kw)
+    alpha = out[7]
+    sel = alpha > 0.5
+    assert torch.allclose((out[3] / alpha)[sel], torch.full_like(alpha[sel], z), atol=1e-9)
+    n = OL.compute_normals((out[3] / alpha.clamp_min(1e-9))[None], K.double())
+    inner = sel.clone(); inner[:1] = inner[-1:] = False; inner[:, :1] = inner[:, -1:] = False
+    core = inner & torch.roll(sel, 1, 0) & torch.roll(sel, -1, 0) & torch.roll(sel, 1, 1) & torch.roll(sel, -1, 1)
+    assert torch.allclose(n[core], torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64).expand_as(n[core]), atol=1e-6)
+
+
+def test_occlusion_order_swap():
+    st, kw, _ = _single_gaussian(s=0.3)
+    two = {k: (torch.cat([v, v]) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    two["colors_precomp"] = torch.tensor([[1.0, 0, 0], [0, 0, 1.0]], dtype=torch.float64)
+    two["means3D"] = torch.tensor([[0, 0, 3.0], [0, 0, 5.0]], dtype=torch.float64)
+    near_red, _, _ = OR.rasterize(st, **two)
+    two["means3D"] = torch.tensor([[0, 0, 5.0], [0, 0, 3.0]], dtype=torch.float64)
+    near_blue, _, _ = OR.rasterize(st, **two)
+    c = 32
+    assert near_red[0, c, c] > near_red[2, c, c] and near_blue[2, c, c] > near_blue[0, c, c]
+
+
+def test_oracle_autograd_matches_finite_differences():
+    cam, inp, dirs = util.make_case(24, 32, 32, 30.0, seed=4, scale_mult=60.0)
+    bg = torch.tensor([0.3, 0.2, 0.1])
+    g = torch.Generator().manual_seed(0)
+    wgt = None
+
+    def f(leaf_override=None):
+        (out, _, _), leaf = util.oracle_forward(cam, inp, dirs, bg, dtype=torch.float64, requires_grad=True)
+        return out, leaf
+
+    out, leaf = f()
+    wgt = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    (out * wgt).sum().backward()
+    eps = 1e-6
+    for key in ["means3D", "opac", "scales", "rots", "normals"]:
+        base = inp[key].double()
+        idx = (3, 1) if base.dim() == 2 and base.shape[1] > 1 else (3, 0)
+        vals = []
+        for sgn in (+1, -1):
+            p = dict(inp)
+            t = base.clone(); t[idx] += sgn * eps
+            p[key] = t
+            (o, _, _), _ = util.oracle_forward(cam, p, dirs, bg, dtype=torch.float64)
+            vals.append(float((o * wgt).sum()))
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        an = float(leaf[key].grad[idx])
+        assert abs(fd - an) <= 1e-4 * max(abs(fd), abs(an)) + 1e-7, (key, fd, an)
+
+
+# ---- the C-ABI library ------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from vcr_gaus_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(G), "..", "include", "vcr_raster.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vcr_[a-z0-9_]+)\s*\(", hdr)) - {"vcr_alloc_fn"}
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/vcr_raster.h but not exported"
+    assert set(_lib.SYMBOLS) == declared
+    assert _lib.load().vcr_abi_version() == 1
+
+
+def test_rasterizer_refuses_cpu_tensors():
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    cam, inp, dirs = util.make_case(8, 16, 16, 10.0)
+    s = util.settings_for(cam, torch.zeros(3), GaussianRasterizationSettings)
+    with pytest.raises(RuntimeError):
+        GaussianRasterizer(s)(means3D=inp["means3D"], means2D=torch.zeros(8, 3), shs=inp["shs"], opacities=inp["opac"],
+                              scales=inp["scales"], rotations=inp["rots"])

@@ -53,7 +53,27 @@ SYMBOLS = {
     "vcr_last_error": (C.c_char_p, []),
     "vcr_rasterize_forward": (C.c_int, [C.POINTER(VcrRasterArgs), C.POINTER(VcrForwardOut), ALLOC_FN, C.c_void_p, C.c_void_p]),
     "vcr_rasterize_backward": (C.c_int, [C.POINTER(VcrRasterArgs), C.POINTER(VcrBackwardIO), ALLOC_FN, C.c_void_p, C.c_void_p]),
+    "vcr_activate_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 12),
+    "vcr_activate_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 13),
+    "vcr_adam_step": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_void_p), C.POINTER(C.c_int64), c_float_p, C.c_float, C.c_float,
+                                C.c_float, C.c_int, C.c_float, C.c_void_p]),
+    "vcr_densify_stats": (C.c_int, [C.c_int] + [C.c_void_p] * 6),
+    "vcr_depth_to_normal_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 3),
+    "vcr_depth_to_normal_backward": (C.c_int, [C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 5),
+    "vcr_normalize_chw_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 3),
+    "vcr_normalize_chw_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 4),
+    "vcr_normal_loss_forward": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    "vcr_normal_loss_backward": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vcr_l1_ssim_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "vcr_l1_ssim_backward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 7),
+    "vcr_profile_enable": (None, [C.c_int]),
+    "vcr_profile_num_stages": (C.c_int, []),
+    "vcr_profile_read": (C.c_int, [c_float_p, c_int_p, C.c_int]),
 }
+STAGES = ["preprocess", "depth_sort_scan", "binning", "composite_fwd", "composite_bwd", "preprocess_bwd"]
 
 _lib = None
 
@@ -79,5 +99,30 @@ def load():
     return lib
 
 
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("vcr_raster: " + last_error())
+
+
+def stream_of(t):
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
 def last_error():
     return load().vcr_last_error().decode()
+
+
+def profile_enable(on=True):
+    load().vcr_profile_enable(1 if on else 0)
+
+
+def profile_read():
+    """-> {stage: (total_ms, launches)} accumulated since the previous read (stream must be synchronised)."""
+    lib = load()
+    n = lib.vcr_profile_num_stages()
+    ms = (C.c_float * n)()
+    cnt = (C.c_int32 * n)()
+    if lib.vcr_profile_read(ms, cnt, n) != 0:
+        raise RuntimeError("vcr_raster: " + last_error())
+    return {STAGES[i]: (float(ms[i]), int(cnt[i])) for i in range(n)}

@@ -27,7 +27,9 @@ class Camera:
         self.projection_matrix = getProjectionMatrix(self.znear, self.zfar, FoVx, FoVy).t().contiguous().to(self.device)
         self.full_proj_transform = (self.world_view_transform @ self.projection_matrix).contiguous()
         self.camera_center = torch.inverse(self.world_view_transform.cpu())[3, :3].contiguous().to(self.device)
-        self.intr = getIntrinsic(FoVx, FoVy, self.image_height, self.image_width).to(self.device)
+        intr = getIntrinsic(FoVx, FoVy, self.image_height, self.image_width)
+        self.intr_scalars = (float(intr[0, 0]), float(intr[1, 1]), float(intr[0, 2]), float(intr[1, 2]))
+        self.intr = intr.to(self.device)
         # camera rotation world->camera as a device tensor, built once (the reference re-uploads
         # `R.T` on every render, `gaussian_renderer/__init__.py:100`)
         self.R_w2c = torch.tensor(self.R.T, dtype=torch.float32).contiguous().to(self.device)

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -14,6 +15,32 @@ void vcr_set_error(const char* fmt, ...) {
 }
 
 namespace {
+
+// ---- optional per-stage HIP-event timing (bench.py / profiling only) --------------------------
+enum { ST_PREPROCESS = 0, ST_DEPTHSORT, ST_BINNING, ST_COMPOSITE_FWD, ST_COMPOSITE_BWD, ST_PREPROCESS_BWD, ST_COUNT };
+struct StageEvt { hipEvent_t a, b; int stage; };
+bool g_prof = false;
+std::vector<StageEvt> g_used;
+std::vector<hipEvent_t> g_free;
+
+hipEvent_t get_event() {
+    if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct StageTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t st;
+    int stage;
+    StageTimer(int stage_, hipStream_t st_) : st(st_), stage(stage_) {
+        if (g_prof) { a = get_event(); b = get_event(); (void)hipEventRecord(a, st); }
+    }
+    ~StageTimer() {
+        if (a) { (void)hipEventRecord(b, st); g_used.push_back({a, b, stage}); }
+    }
+};
 
 struct Readback { uint32_t R; uint32_t V; };
 
@@ -104,9 +131,15 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         uint32_t* vis_counter = (uint32_t*)(s1 + 5 * nb);
         void* temp1 = s1 + 5 * nb + 256;
         VCR_HIP_CHECK(hipMemsetAsync(vis_counter, 0, sizeof(uint32_t), st));
-        if (vcr_launch_preprocess(a, g, out->radii, depth_key, ids, st)) return 1;
+        {
+            StageTimer tm(ST_PREPROCESS, st);
+            if (vcr_launch_preprocess(a, g, out->radii, depth_key, ids, st)) return 1;
+        }
         hipLaunchKernelGGL(count_visible_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, g.tiles, vis_counter);
-        if (vcr_depth_sort_and_scan(N, depth_key, ids, key_sorted, ids_sorted, g.tiles, offsets, temp1, tmp1, st)) return 1;
+        {
+            StageTimer tm(ST_DEPTHSORT, st);
+            if (vcr_depth_sort_and_scan(N, depth_key, ids, key_sorted, ids_sorted, g.tiles, offsets, temp1, tmp1, st)) return 1;
+        }
         Readback* rb = pinned_readback();
         if (!rb) { vcr_set_error("hipHostMalloc for the readback word failed"); return 1; }
         VCR_HIP_CHECK(hipMemcpyAsync(&rb->R, offsets + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -123,11 +156,17 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         const size_t rbts = vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1));
         char* s2 = (char*)alloc(user, VCR_BUF_SCRATCH, 3 * rbts + tmp2);
         if (!s2) { vcr_set_error("allocator returned NULL"); return 1; }
-        if (vcr_duplicate_and_sort(a, g, out->radii, ids_sorted, offsets, R, tbits, (uint32_t*)s2, (uint32_t*)(s2 + rbts),
-                                   (uint32_t*)(s2 + 2 * rbts), b.point_list, b.ranges, T, s2 + 3 * rbts, tmp2, st))
-            return 1;
+        {
+            StageTimer tm(ST_BINNING, st);
+            if (vcr_duplicate_and_sort(a, g, out->radii, ids_sorted, offsets, R, tbits, (uint32_t*)s2, (uint32_t*)(s2 + rbts),
+                                       (uint32_t*)(s2 + 2 * rbts), b.point_list, b.ranges, T, s2 + 3 * rbts, tmp2, st))
+                return 1;
+        }
         out->num_rendered = R;
-        if (vcr_launch_composite_forward(a, g, b, im, *out, st)) return 1;
+        {
+            StageTimer tm(ST_COMPOSITE_FWD, st);
+            if (vcr_launch_composite_forward(a, g, b, im, *out, st)) return 1;
+        }
     } else {
         void* bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(0, T));
         if (!bin_p) { vcr_set_error("allocator returned NULL"); return 1; }
@@ -167,11 +206,32 @@ extern "C" int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* 
     GradRec* sgrad = (GradRec*)s;
     float* sgrad_sem = (float*)(s + gb);
     VCR_HIP_CHECK(hipMemsetAsync(s, 0, gb + sb, st));
-    if (io->num_rendered > 0)
+    if (io->num_rendered > 0) {
+        StageTimer tm(ST_COMPOSITE_BWD, st);
         if (vcr_launch_composite_backward(a, g, b, im, io->dL_dout, sgrad, sgrad_sem, st)) return 1;
+    }
     VcrBackwardIO io2 = *io;
     if (!a.normals_precomp) io2.dL_dnormals = nullptr;
     if (a.S == 0) io2.dL_dsemantics = nullptr;
     if (a.colors_precomp == nullptr) io2.dL_dcolors = nullptr;
+    StageTimer tm(ST_PREPROCESS_BWD, st);
     return vcr_launch_preprocess_backward(a, g, io->radii, sgrad, sgrad_sem, io2, st);
+}
+
+extern "C" void vcr_profile_enable(int on) { g_prof = on != 0; }
+
+extern "C" int vcr_profile_num_stages(void) { return ST_COUNT; }
+
+// Adds the elapsed milliseconds / launch counts recorded since the last call into ms[0..n) / launches[0..n)
+// (stage order: preprocess, depth sort+scan, duplicate+tile sort+ranges, composite fwd, composite bwd,
+// preprocess bwd).  The caller must have synchronised the stream(s) first.
+extern "C" int vcr_profile_read(float* ms, int32_t* launches, int n) {
+    for (auto& e : g_used) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) { vcr_set_error("hipEventElapsedTime failed (not synchronised?)"); return 1; }
+        if (e.stage < n) { ms[e.stage] += t; launches[e.stage] += 1; }
+        g_free.push_back(e.a); g_free.push_back(e.b);
+    }
+    g_used.clear();
+    return 0;
 }

@@ -1,0 +1,403 @@
+// Image-space kernels of the D-Normal training step (all HBM-streaming, one pass each):
+//   depth -> normal (tools/normal_utils.py:24-41, tools/graphics_utils.py:111-131) and its adjoint,
+//   rendered-normal normalisation (gaussian_renderer/__init__.py:133-134),
+//   confidence-weighted normal loss (tools/loss_utils.py:122-143, trainer.py:261-293),
+//   fused L1 + SSIM (tools/loss_utils.py:36,49-92) with saved partials for a single-pass backward.
+#include "vcr_common.h"
+
+namespace {
+
+// ---------------- block reduction helper ------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float x) {
+    x = dpp_add<0x128>(x); x = dpp_add<0x124>(x); x = dpp_add<0x122>(x); x = dpp_add<0x121>(x);
+    x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+    return x;
+}
+// one double atomic per wave: deterministic enough (fp64 accumulation) and cheap
+__device__ __forceinline__ void wave_accumulate(double* dst, float v) {
+    const float s = wave_sum(v);
+    if ((threadIdx.x & 63) == 0 && s != 0.f) atomicAdd(dst, (double)s);
+}
+
+// ---------------- depth -> normal ----------------------------------------------------------------
+struct Intr { float fx, fy, cx, cy; };
+
+__device__ __forceinline__ void backproject(const float* __restrict__ depth, int W, int x, int y, Intr k, float X[3]) {
+    const float z = depth[y * W + x];
+    X[0] = ((float)x + 0.5f - k.cx) * z / k.fx;
+    X[1] = ((float)y + 0.5f - k.cy) * z / k.fy;
+    X[2] = z;
+}
+
+// torch.gradient, spacing 1: central inside, one-sided at the borders.
+__device__ __forceinline__ void grad_cols(const float* depth, int W, int H, int x, int y, Intr k, float d[3]) {
+    float a[3], b[3];
+    const int x0 = x > 0 ? x - 1 : x, x1 = x < W - 1 ? x + 1 : x;
+    backproject(depth, W, x0, y, k, a);
+    backproject(depth, W, x1, y, k, b);
+    const float sc = (x0 == x - 1 && x1 == x + 1) ? 0.5f : 1.f;
+    d[0] = (b[0] - a[0]) * sc; d[1] = (b[1] - a[1]) * sc; d[2] = (b[2] - a[2]) * sc;
+}
+__device__ __forceinline__ void grad_rows(const float* depth, int W, int H, int x, int y, Intr k, float d[3]) {
+    float a[3], b[3];
+    const int y0 = y > 0 ? y - 1 : y, y1 = y < H - 1 ? y + 1 : y;
+    backproject(depth, W, x, y0, k, a);
+    backproject(depth, W, x, y1, k, b);
+    const float sc = (y0 == y - 1 && y1 == y + 1) ? 0.5f : 1.f;
+    d[0] = (b[0] - a[0]) * sc; d[1] = (b[1] - a[1]) * sc; d[2] = (b[2] - a[2]) * sc;
+}
+
+__global__ void __launch_bounds__(256) depth_normal_fwd_kernel(int H, int W, Intr k, const float* __restrict__ depth,
+                                                               float* __restrict__ normal) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    float dx[3], dy[3];
+    grad_cols(depth, W, H, x, y, k, dx);
+    grad_rows(depth, W, H, x, y, k, dy);
+    const float c0 = dx[1] * dy[2] - dx[2] * dy[1], c1 = dx[2] * dy[0] - dx[0] * dy[2], c2 = dx[0] * dy[1] - dx[1] * dy[0];
+    const float inv = 1.f / fmaxf(sqrtf(c0 * c0 + c1 * c1 + c2 * c2), 1e-12f);
+    float* o = normal + 3 * ((size_t)y * W + x);
+    o[0] = c0 * inv; o[1] = c1 * inv; o[2] = c2 * inv;
+}
+
+// pass 1: dL/dn -> dL/d(dx), dL/d(dy) per pixel ([P,6] scratch)
+__global__ void __launch_bounds__(256) depth_normal_bwd1_kernel(int H, int W, Intr k, const float* __restrict__ depth,
+                                                                const float* __restrict__ dnormal,
+                                                                float* __restrict__ dgrad) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    float dx[3], dy[3];
+    grad_cols(depth, W, H, x, y, k, dx);
+    grad_rows(depth, W, H, x, y, k, dy);
+    const float c[3] = {dx[1] * dy[2] - dx[2] * dy[1], dx[2] * dy[0] - dx[0] * dy[2], dx[0] * dy[1] - dx[1] * dy[0]};
+    const float len = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    const float* g = dnormal + 3 * ((size_t)y * W + x);
+    float dc[3];
+    if (len > 1e-12f) {
+        const float inv = 1.f / len;
+        const float n[3] = {c[0] * inv, c[1] * inv, c[2] * inv};
+        const float dot = n[0] * g[0] + n[1] * g[1] + n[2] * g[2];
+        dc[0] = (g[0] - n[0] * dot) * inv; dc[1] = (g[1] - n[1] * dot) * inv; dc[2] = (g[2] - n[2] * dot) * inv;
+    } else {
+        dc[0] = g[0] * 1e12f; dc[1] = g[1] * 1e12f; dc[2] = g[2] * 1e12f;
+    }
+    // c = dx x dy  ->  d(dx) = dy x dc,  d(dy) = dc x dx
+    float* o = dgrad + 6 * ((size_t)y * W + x);
+    o[0] = dy[1] * dc[2] - dy[2] * dc[1]; o[1] = dy[2] * dc[0] - dy[0] * dc[2]; o[2] = dy[0] * dc[1] - dy[1] * dc[0];
+    o[3] = dc[1] * dx[2] - dc[2] * dx[1]; o[4] = dc[2] * dx[0] - dc[0] * dx[2]; o[5] = dc[0] * dx[1] - dc[1] * dx[0];
+}
+
+// coefficient of f[i] inside torch.gradient evaluated at index q (q in {i-1, i, i+1}), length n
+__device__ __forceinline__ float grad_coef(int q, int i, int n) {
+    if (q < 0 || q >= n) return 0.f;
+    if (q == 0) return i == 1 ? 1.f : (i == 0 ? -1.f : 0.f);
+    if (q == n - 1) return i == n - 1 ? 1.f : (i == n - 2 ? -1.f : 0.f);
+    return i == q + 1 ? 0.5f : (i == q - 1 ? -0.5f : 0.f);
+}
+
+// pass 2: gather the stencil adjoint and fold through X = z * k(u,v)
+__global__ void __launch_bounds__(256) depth_normal_bwd2_kernel(int H, int W, Intr k, const float* __restrict__ dgrad,
+                                                                float* __restrict__ ddepth) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    float dX[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = -1; o <= 1; ++o) {
+        const float cc = grad_coef(x + o, x, W);
+        if (cc != 0.f) {
+            const float* g = dgrad + 6 * ((size_t)y * W + (x + o));
+            dX[0] += cc * g[0]; dX[1] += cc * g[1]; dX[2] += cc * g[2];
+        }
+        const float cr = grad_coef(y + o, y, H);
+        if (cr != 0.f) {
+            const float* g = dgrad + 6 * ((size_t)(y + o) * W + x) + 3;
+            dX[0] += cr * g[0]; dX[1] += cr * g[1]; dX[2] += cr * g[2];
+        }
+    }
+    ddepth[(size_t)y * W + x] = dX[0] * ((float)x + 0.5f - k.cx) / k.fx + dX[1] * ((float)y + 0.5f - k.cy) / k.fy + dX[2];
+}
+
+// ---------------- planar [3,H,W] -> normalised [H,W,3] ---------------------------------------------
+__global__ void __launch_bounds__(256) normalize_chw_fwd_kernel(int P, const float* __restrict__ in,
+                                                                float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float a = in[i], b = in[P + i], c = in[2 * (size_t)P + i];
+    const float inv = 1.f / fmaxf(sqrtf(a * a + b * b + c * c), 1e-12f);
+    out[3 * (size_t)i] = a * inv; out[3 * (size_t)i + 1] = b * inv; out[3 * (size_t)i + 2] = c * inv;
+}
+__global__ void __launch_bounds__(256) normalize_chw_bwd_kernel(int P, const float* __restrict__ in,
+                                                                const float* __restrict__ dout, float* __restrict__ din) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float a = in[i], b = in[P + i], c = in[2 * (size_t)P + i];
+    const float len = sqrtf(a * a + b * b + c * c);
+    const float g0 = dout[3 * (size_t)i], g1 = dout[3 * (size_t)i + 1], g2 = dout[3 * (size_t)i + 2];
+    float d0, d1, d2;
+    if (len > 1e-12f) {
+        const float inv = 1.f / len;
+        const float n0 = a * inv, n1 = b * inv, n2 = c * inv, dot = n0 * g0 + n1 * g1 + n2 * g2;
+        d0 = (g0 - n0 * dot) * inv; d1 = (g1 - n1 * dot) * inv; d2 = (g2 - n2 * dot) * inv;
+    } else { d0 = g0 * 1e12f; d1 = g1 * 1e12f; d2 = g2 * 1e12f; }
+    din[i] = d0; din[P + i] = d1; din[2 * (size_t)P + i] = d2;
+}
+
+// ---------------- weighted / masked normal loss ----------------------------------------------------
+// sums[0] = sum w*|p-g|_1, sums[1] = sum w*(1 - p.g), sums[2] = #selected pixels
+__global__ void __launch_bounds__(256) normal_loss_fwd_kernel(int P, const float* __restrict__ pred,
+                                                              const float* __restrict__ gt, const float* __restrict__ wsrc,
+                                                              float exp_t, const uint8_t* __restrict__ mask,
+                                                              double* __restrict__ sums) {
+    float s0 = 0.f, s1 = 0.f, cnt = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) {
+        if (mask && !mask[i]) continue;
+        const float p0 = pred[3 * (size_t)i], p1 = pred[3 * (size_t)i + 1], p2 = pred[3 * (size_t)i + 2];
+        const float g0 = gt[3 * (size_t)i], g1 = gt[3 * (size_t)i + 1], g2 = gt[3 * (size_t)i + 2];
+        float w = 1.f;
+        if (wsrc && exp_t > 0.f) {
+            const float c = wsrc[3 * (size_t)i] * g0 + wsrc[3 * (size_t)i + 1] * g1 + wsrc[3 * (size_t)i + 2] * g2;
+            w = __expf((c - 1.f) / exp_t);
+        }
+        s0 += w * (fabsf(p0 - g0) + fabsf(p1 - g1) + fabsf(p2 - g2));
+        s1 += w * (1.f - (p0 * g0 + p1 * g1 + p2 * g2));
+        cnt += 1.f;
+    }
+    wave_accumulate(sums + 0, s0);
+    wave_accumulate(sums + 1, s1);
+    wave_accumulate(sums + 2, cnt);
+}
+
+// dpred = scale * w * (sign(p-g) - g); optionally dgt = scale * w * (-sign(p-g) - p) (consistency loss, both sides live)
+__global__ void __launch_bounds__(256) normal_loss_bwd_kernel(int P, const float* __restrict__ pred,
+                                                              const float* __restrict__ gt, const float* __restrict__ wsrc,
+                                                              float exp_t, const uint8_t* __restrict__ mask,
+                                                              const double* __restrict__ sums, const float* __restrict__ gout,
+                                                              float* __restrict__ dpred, float* __restrict__ dgt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float d[3] = {0.f, 0.f, 0.f}, e[3] = {0.f, 0.f, 0.f};
+    if (!mask || mask[i]) {
+        const float scale = gout[0] / (float)sums[2];
+        const float p[3] = {pred[3 * (size_t)i], pred[3 * (size_t)i + 1], pred[3 * (size_t)i + 2]};
+        const float g[3] = {gt[3 * (size_t)i], gt[3 * (size_t)i + 1], gt[3 * (size_t)i + 2]};
+        float w = 1.f;
+        if (wsrc && exp_t > 0.f) {
+            const float c = wsrc[3 * (size_t)i] * g[0] + wsrc[3 * (size_t)i + 1] * g[1] + wsrc[3 * (size_t)i + 2] * g[2];
+            w = __expf((c - 1.f) / exp_t);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float df = p[k] - g[k];
+            const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+            d[k] = scale * w * (sg - g[k]);
+            e[k] = scale * w * (-sg - p[k]);
+        }
+    }
+    dpred[3 * (size_t)i] = d[0]; dpred[3 * (size_t)i + 1] = d[1]; dpred[3 * (size_t)i + 2] = d[2];
+    if (dgt) { dgt[3 * (size_t)i] = e[0]; dgt[3 * (size_t)i + 1] = e[1]; dgt[3 * (size_t)i + 2] = e[2]; }
+}
+
+// ---------------- fused L1 + SSIM ------------------------------------------------------------------
+#define SSIM_R 5
+#define SSIM_TX 32
+#define SSIM_TY 8
+struct GaussWin { float w[11]; };
+
+// One workgroup = 32x8 output pixels of one channel; stages the (32+10)x(8+10) halo of both images in
+// LDS and evaluates the 11x11 window separably (horizontal pass into LDS, vertical pass from LDS).
+// sums[0] += sum |a-b| ; sums[1] += sum ssim_map.  If `part` != null stores d ssim / d{mu1, sigma1^2, sigma12}.
+__global__ void __launch_bounds__(256) l1_ssim_fwd_kernel(int H, int W, GaussWin gw, const float* __restrict__ img1,
+                                                          const float* __restrict__ img2, double* __restrict__ sums,
+                                                          float* __restrict__ part) {
+    __shared__ float s_a[SSIM_TY + 2 * SSIM_R][SSIM_TX + 2 * SSIM_R + 1];
+    __shared__ float s_b[SSIM_TY + 2 * SSIM_R][SSIM_TX + 2 * SSIM_R + 1];
+    __shared__ float s_h[5][SSIM_TY + 2 * SSIM_R][SSIM_TX + 1];
+    const int c = blockIdx.z, x0 = blockIdx.x * SSIM_TX, y0 = blockIdx.y * SSIM_TY;
+    const size_t P = (size_t)H * W;
+    const float* A = img1 + c * P;
+    const float* B = img2 + c * P;
+    const int TW = SSIM_TX + 2 * SSIM_R, TH = SSIM_TY + 2 * SSIM_R;
+    for (int t = threadIdx.x; t < TW * TH; t += 256) {
+        const int ly = t / TW, lx = t % TW, gx = x0 + lx - SSIM_R, gy = y0 + ly - SSIM_R;
+        const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;          // zero padding (F.conv2d padding=5)
+        s_a[ly][lx] = in ? A[(size_t)gy * W + gx] : 0.f;
+        s_b[ly][lx] = in ? B[(size_t)gy * W + gx] : 0.f;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < SSIM_TX * TH; t += 256) {
+        const int ly = t / SSIM_TX, lx = t % SSIM_TX;
+        float m1 = 0.f, m2 = 0.f, q11 = 0.f, q22 = 0.f, q12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float a = s_a[ly][lx + k], b = s_b[ly][lx + k], w = gw.w[k];
+            m1 += w * a; m2 += w * b; q11 += w * a * a; q22 += w * b * b; q12 += w * a * b;
+        }
+        s_h[0][ly][lx] = m1; s_h[1][ly][lx] = m2; s_h[2][ly][lx] = q11; s_h[3][ly][lx] = q22; s_h[4][ly][lx] = q12;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int gx = x0 + lx, gy = y0 + ly;
+    float l1 = 0.f, sv = 0.f;
+    if (gx < W && gy < H) {
+        float m1 = 0.f, m2 = 0.f, q11 = 0.f, q22 = 0.f, q12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float w = gw.w[k];
+            m1 += w * s_h[0][ly + k][lx]; m2 += w * s_h[1][ly + k][lx]; q11 += w * s_h[2][ly + k][lx];
+            q22 += w * s_h[3][ly + k][lx]; q12 += w * s_h[4][ly + k][lx];
+        }
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
+        const float s11 = q11 - m11, s22 = q22 - m22, s12 = q12 - m12;
+        const float An = 2.f * m12 + C1, Bn = 2.f * s12 + C2, Cd = m11 + m22 + C1, Dd = s11 + s22 + C2;
+        const float iCD = 1.f / (Cd * Dd);
+        sv = An * Bn * iCD;
+        l1 = fabsf(s_a[ly + SSIM_R][lx + SSIM_R] - s_b[ly + SSIM_R][lx + SSIM_R]);
+        if (part) {
+            // ssim = A B / (C D) with sigma terms expanded through mu1: total derivative w.r.t. mu1 at fixed
+            // raw moments q11,q12:  s11 = q11 - mu1^2, s12 = q12 - mu1 mu2
+            const float dS_dm1 = (2.f * m2 * Bn + An * (-2.f * m2)) * iCD - sv * (2.f * m1 * Dd + Cd * (-2.f * m1)) / (Cd * Dd);
+            const float dS_dq11 = -sv / Dd;               // through sigma1^2 in D
+            const float dS_dq12 = 2.f * An * iCD;         // through sigma12 in B
+            const size_t o = c * P + (size_t)gy * W + gx;
+            part[o] = dS_dm1; part[3 * P + o] = dS_dq11; part[6 * P + o] = dS_dq12;
+        }
+    }
+    wave_accumulate(sums + 0, l1);
+    wave_accumulate(sums + 1, sv);
+}
+
+// dimg1(p) = gl1 * sign(a-b) + gss * sum_q w(q-p) [ dm1(q) + 2 a(p) dq11(q) + b(p) dq12(q) ]
+__global__ void __launch_bounds__(256) l1_ssim_bwd_kernel(int H, int W, GaussWin gw, const float* __restrict__ img1,
+                                                          const float* __restrict__ img2, const float* __restrict__ part,
+                                                          const float* __restrict__ g_l1, const float* __restrict__ g_ssim,
+                                                          float wl1, float wss, float* __restrict__ dimg1) {
+    __shared__ float s_p[3][SSIM_TY + 2 * SSIM_R][SSIM_TX + 2 * SSIM_R + 1];
+    __shared__ float s_h[3][SSIM_TY + 2 * SSIM_R][SSIM_TX + 1];
+    const int c = blockIdx.z, x0 = blockIdx.x * SSIM_TX, y0 = blockIdx.y * SSIM_TY;
+    const size_t P = (size_t)H * W;
+    const int TW = SSIM_TX + 2 * SSIM_R, TH = SSIM_TY + 2 * SSIM_R;
+    for (int t = threadIdx.x; t < TW * TH; t += 256) {
+        const int ly = t / TW, lx = t % TW, gx = x0 + lx - SSIM_R, gy = y0 + ly - SSIM_R;
+        const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
+        const size_t o = c * P + (size_t)gy * W + gx;
+        s_p[0][ly][lx] = in ? part[o] : 0.f;
+        s_p[1][ly][lx] = in ? part[3 * P + o] : 0.f;
+        s_p[2][ly][lx] = in ? part[6 * P + o] : 0.f;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < SSIM_TX * TH; t += 256) {
+        const int ly = t / SSIM_TX, lx = t % SSIM_TX;
+        float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float w = gw.w[k];
+            h0 += w * s_p[0][ly][lx + k]; h1 += w * s_p[1][ly][lx + k]; h2 += w * s_p[2][ly][lx + k];
+        }
+        s_h[0][ly][lx] = h0; s_h[1][ly][lx] = h1; s_h[2][ly][lx] = h2;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gx >= W || gy >= H) return;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const float w = gw.w[k];
+        v0 += w * s_h[0][ly + k][lx]; v1 += w * s_h[1][ly + k][lx]; v2 += w * s_h[2][ly + k][lx];
+    }
+    const size_t o = c * P + (size_t)gy * W + gx;
+    const float a = img1[o], b = img2[o];
+    const float n = 1.f / (3.f * (float)P);
+    const float df = a - b;
+    const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+    dimg1[o] = wl1 * g_l1[0] * n * sg + wss * g_ssim[0] * n * (v0 + 2.f * a * v1 + b * v2);
+}
+
+}  // namespace
+
+static Intr make_intr(const float* k4) { return Intr{k4[0], k4[1], k4[2], k4[3]}; }
+
+extern "C" int vcr_depth_to_normal_forward(int H, int W, float fx, float fy, float cx, float cy, const float* depth,
+                                           float* normal, void* stream) {
+    const float k4[4] = {fx, fy, cx, cy};
+    hipLaunchKernelGGL(depth_normal_fwd_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, (hipStream_t)stream, H, W,
+                       make_intr(k4), depth, normal);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_depth_to_normal_backward(int H, int W, float fx, float fy, float cx, float cy, const float* depth,
+                                            const float* dnormal, float* scratch6, float* ddepth, void* stream) {
+    const float k4[4] = {fx, fy, cx, cy};
+    const dim3 grid((W + 63) / 64, (H + 3) / 4);
+    hipLaunchKernelGGL(depth_normal_bwd1_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, make_intr(k4), depth, dnormal,
+                       scratch6);
+    hipLaunchKernelGGL(depth_normal_bwd2_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, make_intr(k4), scratch6,
+                       ddepth);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_normalize_chw_forward(int P, const float* in_chw, float* out_hwc, void* stream) {
+    hipLaunchKernelGGL(normalize_chw_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, in_chw, out_hwc);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_normalize_chw_backward(int P, const float* in_chw, const float* dout_hwc, float* din_chw, void* stream) {
+    hipLaunchKernelGGL(normalize_chw_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, in_chw, dout_hwc,
+                       din_chw);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_normal_loss_forward(int P, const float* pred, const float* gt, const float* wsrc, float exp_t,
+                                       const uint8_t* mask, double* sums3, void* stream) {
+    VCR_HIP_CHECK(hipMemsetAsync(sums3, 0, 3 * sizeof(double), (hipStream_t)stream));
+    const int blocks = min((P + 255) / 256, 2048);
+    hipLaunchKernelGGL(normal_loss_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, pred, gt, wsrc, exp_t, mask,
+                       sums3);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_normal_loss_backward(int P, const float* pred, const float* gt, const float* wsrc, float exp_t,
+                                        const uint8_t* mask, const double* sums3, const float* gout, float* dpred, float* dgt,
+                                        void* stream) {
+    hipLaunchKernelGGL(normal_loss_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, pred, gt, wsrc,
+                       exp_t, mask, sums3, gout, dpred, dgt);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static GaussWin make_window() {
+    GaussWin g;
+    double s = 0.0, v[11];
+    for (int i = 0; i < 11; ++i) { v[i] = exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); s += v[i]; }
+    for (int i = 0; i < 11; ++i) g.w[i] = (float)(v[i] / s);
+    return g;
+}
+
+extern "C" int vcr_l1_ssim_forward(int H, int W, const float* img1, const float* img2, double* sums2, float* partials9,
+                                   void* stream) {
+    VCR_HIP_CHECK(hipMemsetAsync(sums2, 0, 2 * sizeof(double), (hipStream_t)stream));
+    const dim3 grid((W + SSIM_TX - 1) / SSIM_TX, (H + SSIM_TY - 1) / SSIM_TY, 3);
+    hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, make_window(), img1, img2, sums2,
+                       partials9);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_l1_ssim_backward(int H, int W, const float* img1, const float* img2, const float* partials9,
+                                    const float* g_l1, const float* g_ssim, float* dimg1, void* stream) {
+    const dim3 grid((W + SSIM_TX - 1) / SSIM_TX, (H + SSIM_TY - 1) / SSIM_TY, 3);
+    hipLaunchKernelGGL(l1_ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, make_window(), img1, img2, partials9,
+                       g_l1, g_ssim, 1.f, 1.f, dimg1);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,192 @@
+// Per-Gaussian parameter kernels around the rasterizer call (HBM-streaming, one lane per Gaussian):
+//   fused activations + shortest-axis normal + camera orientation
+//     (scene/gaussian_model.py:125-192, tools/general_utils.py:98-119, gaussian_renderer/__init__.py:95-101),
+//   fused multi-tensor Adam (scene/gaussian_model.py:232-262: torch.optim.Adam(lr=0, eps=1e-15), per-group lr),
+//   densification statistics (scene/gaussian_model.py:669-671, trainer.py:345).
+#include "vcr_common.h"
+
+namespace {
+
+__device__ __forceinline__ void quat_R(float r, float x, float y, float z, float R[9]) {
+    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z); R[2] = 2.f * (x * z + r * y);
+    R[3] = 2.f * (x * y + r * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
+    R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// aux: bits0-1 = shortest axis, bit2 = flipped
+__global__ void __launch_bounds__(256) activate_fwd_kernel(int N, const float* __restrict__ scaling_raw,
+                                                           const float* __restrict__ rotation_raw,
+                                                           const float* __restrict__ opacity_raw,
+                                                           const float* __restrict__ xyz, const float* __restrict__ campos,
+                                                           const float* __restrict__ Rw2c, float* __restrict__ scales,
+                                                           float* __restrict__ rots, float* __restrict__ opac,
+                                                           float* __restrict__ normals, uint8_t* __restrict__ aux) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const size_t i3 = 3 * (size_t)i;
+    const float l0 = scaling_raw[i3], l1 = scaling_raw[i3 + 1], l2 = scaling_raw[i3 + 2];
+    const float s0 = expf(l0), s1 = expf(l1), s2 = expf(l2);
+    scales[i3] = s0; scales[i3 + 1] = s1; scales[i3 + 2] = s2;
+    const float4 qr = reinterpret_cast<const float4*>(rotation_raw)[i];
+    const float inv = 1.f / fmaxf(sqrtf(qr.x * qr.x + qr.y * qr.y + qr.z * qr.z + qr.w * qr.w), 1e-12f);
+    const float4 q = make_float4(qr.x * inv, qr.y * inv, qr.z * inv, qr.w * inv);
+    reinterpret_cast<float4*>(rots)[i] = q;
+    opac[i] = 1.f / (1.f + expf(-opacity_raw[i]));
+    if (!normals) return;
+    int axis = 0;                              // torch.argmin: first minimum
+    float sm = s0;
+    if (s1 < sm) { sm = s1; axis = 1; }
+    if (s2 < sm) { sm = s2; axis = 2; }
+    float R[9];
+    quat_R(q.x, q.y, q.z, q.w, R);
+    float n0 = R[axis], n1 = R[3 + axis], n2 = R[6 + axis];
+    const float vx = xyz[i3] - campos[0], vy = xyz[i3 + 1] - campos[1], vz = xyz[i3 + 2] - campos[2];
+    const bool keep = (vx * n0 + vy * n1 + vz * n2) > 0.f;
+    if (!keep) { n0 = -n0; n1 = -n1; n2 = -n2; }
+    normals[i3] = Rw2c[0] * n0 + Rw2c[1] * n1 + Rw2c[2] * n2;
+    normals[i3 + 1] = Rw2c[3] * n0 + Rw2c[4] * n1 + Rw2c[5] * n2;
+    normals[i3 + 2] = Rw2c[6] * n0 + Rw2c[7] * n1 + Rw2c[8] * n2;
+    aux[i] = (uint8_t)(axis | (keep ? 0 : 4));
+}
+
+__global__ void __launch_bounds__(256) activate_bwd_kernel(int N, const float* __restrict__ scaling_raw,
+                                                           const float* __restrict__ rotation_raw,
+                                                           const float* __restrict__ opacity_raw,
+                                                           const float* __restrict__ Rw2c, const uint8_t* __restrict__ aux,
+                                                           const float* __restrict__ d_scales, const float* __restrict__ d_rots,
+                                                           const float* __restrict__ d_opac, const float* __restrict__ d_normals,
+                                                           float* __restrict__ d_scaling_raw, float* __restrict__ d_rotation_raw,
+                                                           float* __restrict__ d_opacity_raw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const size_t i3 = 3 * (size_t)i;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d_scaling_raw[i3 + k] = d_scales ? d_scales[i3 + k] * expf(scaling_raw[i3 + k]) : 0.f;
+    const float o = 1.f / (1.f + expf(-opacity_raw[i]));
+    d_opacity_raw[i] = d_opac ? d_opac[i] * o * (1.f - o) : 0.f;
+    const float4 qr = reinterpret_cast<const float4*>(rotation_raw)[i];
+    const float inv = 1.f / fmaxf(sqrtf(qr.x * qr.x + qr.y * qr.y + qr.z * qr.z + qr.w * qr.w), 1e-12f);
+    const float r = qr.x * inv, x = qr.y * inv, y = qr.z * inv, z = qr.w * inv;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};                 // gradient w.r.t. the unit quaternion
+    if (d_rots) { const float4 d = reinterpret_cast<const float4*>(d_rots)[i]; g[0] = d.x; g[1] = d.y; g[2] = d.z; g[3] = d.w; }
+    if (d_normals) {
+        const int axis = aux[i] & 3;
+        const float sgn = (aux[i] & 4) ? -1.f : 1.f;
+        const float c0 = d_normals[i3], c1 = d_normals[i3 + 1], c2 = d_normals[i3 + 2];
+        // n_cam = Rw2c * (sgn * R[:,axis])
+        const float w0 = sgn * (Rw2c[0] * c0 + Rw2c[3] * c1 + Rw2c[6] * c2);
+        const float w1 = sgn * (Rw2c[1] * c0 + Rw2c[4] * c1 + Rw2c[7] * c2);
+        const float w2 = sgn * (Rw2c[2] * c0 + Rw2c[5] * c1 + Rw2c[8] * c2);
+        float dR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        dR[axis] = w0; dR[3 + axis] = w1; dR[6 + axis] = w2;
+        float h[4];
+        h[0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+        h[1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
+        h[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
+        h[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+        // build_rotation re-normalises its (already unit) input: project onto the tangent space
+        const float hd = h[0] * r + h[1] * x + h[2] * y + h[3] * z;
+        g[0] += h[0] - r * hd; g[1] += h[1] - x * hd; g[2] += h[2] - y * hd; g[3] += h[3] - z * hd;
+    }
+    // q = raw/|raw|
+    const float gd = g[0] * r + g[1] * x + g[2] * y + g[3] * z;
+    reinterpret_cast<float4*>(d_rotation_raw)[i] =
+        make_float4((g[0] - r * gd) * inv, (g[1] - x * gd) * inv, (g[2] - y * gd) * inv, (g[3] - z * gd) * inv);
+}
+
+// ---- fused multi-tensor Adam ---------------------------------------------------------------------
+#define VCR_ADAM_MAX 8
+struct AdamPack {
+    float* p[VCR_ADAM_MAX]; const float* g[VCR_ADAM_MAX]; float* m[VCR_ADAM_MAX]; float* v[VCR_ADAM_MAX];
+    long long start[VCR_ADAM_MAX + 1];       // prefix of element counts
+    float lr[VCR_ADAM_MAX];
+    int n;
+};
+
+__global__ void __launch_bounds__(256) adam_kernel(AdamPack pk, float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                   float gscale) {
+    const long long total = pk.start[pk.n];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int t = 0;
+#pragma unroll
+        for (int k = 1; k < VCR_ADAM_MAX; ++k) if (k < pk.n && i >= pk.start[k]) t = k;
+        const long long j = i - pk.start[t];
+        const float g = pk.g[t][j] * gscale;
+        const float m = b1 * pk.m[t][j] + (1.f - b1) * g;
+        const float v = b2 * pk.v[t][j] + (1.f - b2) * g * g;
+        pk.m[t][j] = m; pk.v[t][j] = v;
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        pk.p[t][j] -= (pk.lr[t] / bc1) * (m / denom);
+    }
+}
+
+// xyz_gradient_accum[vis] += ||grad[:, :2]||, denom[vis] += 1, max_radii2D[vis] = max(., radii)
+__global__ void __launch_bounds__(256) densify_stats_kernel(int N, const float* __restrict__ grad2d,
+                                                            const int32_t* __restrict__ radii, float* __restrict__ accum,
+                                                            float* __restrict__ denom, float* __restrict__ max_radii) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    const float gx = grad2d[3 * (size_t)i], gy = grad2d[3 * (size_t)i + 1];
+    accum[i] += sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.f;
+    max_radii[i] = fmaxf(max_radii[i], (float)r);
+}
+
+}  // namespace
+
+extern "C" int vcr_activate_forward(int N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                                    const float* xyz, const float* campos, const float* R_w2c, float* scales, float* rots,
+                                    float* opac, float* normals_cam, uint8_t* aux, void* stream) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(activate_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling_raw,
+                       rotation_raw, opacity_raw, xyz, campos, R_w2c, scales, rots, opac, normals_cam, aux);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_activate_backward(int N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                                     const float* R_w2c, const uint8_t* aux, const float* d_scales, const float* d_rots,
+                                     const float* d_opac, const float* d_normals, float* d_scaling_raw, float* d_rotation_raw,
+                                     float* d_opacity_raw, void* stream) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(activate_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling_raw,
+                       rotation_raw, opacity_raw, R_w2c, aux, d_scales, d_rots, d_opac, d_normals, d_scaling_raw,
+                       d_rotation_raw, d_opacity_raw);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_adam_step(int ntensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                             float* const* exp_avg_sq, const int64_t* numel, const float* lr, float beta1, float beta2,
+                             float eps, int step, float grad_scale, void* stream) {
+    if (ntensors <= 0) return 0;
+    if (ntensors > VCR_ADAM_MAX) { vcr_set_error("vcr_adam_step: at most %d tensors per call", VCR_ADAM_MAX); return 1; }
+    AdamPack pk;
+    pk.n = ntensors;
+    pk.start[0] = 0;
+    for (int k = 0; k < ntensors; ++k) {
+        pk.p[k] = params[k]; pk.g[k] = grads[k]; pk.m[k] = exp_avg[k]; pk.v[k] = exp_avg_sq[k];
+        pk.lr[k] = lr[k];
+        pk.start[k + 1] = pk.start[k] + numel[k];
+    }
+    for (int k = ntensors; k < VCR_ADAM_MAX; ++k) { pk.p[k] = nullptr; pk.g[k] = nullptr; pk.m[k] = nullptr; pk.v[k] = nullptr; pk.lr[k] = 0.f; pk.start[k + 1] = pk.start[ntensors]; }
+    const long long total = pk.start[ntensors];
+    if (total == 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pk, beta1, beta2, eps, (float)bc1,
+                       (float)sqrt(bc2), grad_scale);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_densify_stats(int N, const float* grad2d, const int32_t* radii, float* accum, float* denom,
+                                 float* max_radii, void* stream) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(densify_stats_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, grad2d, radii, accum,
+                       denom, max_radii);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}

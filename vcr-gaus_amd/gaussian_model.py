@@ -1,0 +1,404 @@
+"""GaussianModel: same operator surface as the reference's `scene/gaussian_model.py`
+(getters, Adam parameter groups, densify / prune surgery, densification statistics), with the
+per-step arithmetic routed to HIP kernels:
+
+  * activations + shortest-axis normal + camera orientation: one fused kernel each way
+    (`fused_activate`, replaces `scene/gaussian_model.py:125-192` + `gaussian_renderer/__init__.py:95-101`)
+  * Adam over all parameter groups: one launch (`FusedAdam`, replaces `torch.optim.Adam` at `:258`)
+  * densification statistics: one kernel (`add_densification_stats`, `:669-671` + `trainer.py:345`)
+
+Densify / prune (every 100 iterations) stays as tensor surgery on the device, with the
+reference's deterministic split rule (`scene/gaussian_model.py:579-628`).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .general_utils import build_rotation, get_expon_lr_func, inverse_sigmoid
+
+GROUPS = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "obj_dc"]
+
+
+class _FusedActivate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scaling, rotation, opacity, xyz, campos, R_w2c, want_normal):
+        lib = _lib.load()
+        N = xyz.shape[0]
+        dev = xyz.device
+        sr, rr, orr = scaling.detach().contiguous(), rotation.detach().contiguous(), opacity.detach().contiguous()
+        scales = torch.empty(N, 3, device=dev)
+        rots = torch.empty(N, 4, device=dev)
+        opac = torch.empty(N, 1, device=dev)
+        nrm = torch.empty(N, 3, device=dev) if want_normal else None
+        aux = torch.empty(N, dtype=torch.uint8, device=dev)
+        cp = campos.detach().contiguous().float()
+        Rw = R_w2c.detach().contiguous().float()
+        _lib.check(lib.vcr_activate_forward(N, sr.data_ptr(), rr.data_ptr(), orr.data_ptr(), xyz.detach().contiguous().data_ptr(),
+                                            cp.data_ptr(), Rw.data_ptr(), scales.data_ptr(), rots.data_ptr(), opac.data_ptr(),
+                                            nrm.data_ptr() if want_normal else None, aux.data_ptr(), _lib.stream_of(xyz)))
+        ctx.save_for_backward(sr, rr, orr, Rw, aux)
+        ctx.want_normal = want_normal
+        if want_normal:
+            return scales, rots, opac, nrm
+        return scales, rots, opac
+
+    @staticmethod
+    def backward(ctx, d_scales, d_rots, d_opac, d_nrm=None):
+        lib = _lib.load()
+        sr, rr, orr, Rw, aux = ctx.saved_tensors
+        N = sr.shape[0]
+
+        def p(t):
+            return None if t is None else t.contiguous().float().data_ptr()
+
+        keep = [None if t is None else t.contiguous().float() for t in (d_scales, d_rots, d_opac, d_nrm)]
+        ds, dr, do = torch.empty_like(sr), torch.empty_like(rr), torch.empty_like(orr)
+        _lib.check(lib.vcr_activate_backward(N, sr.data_ptr(), rr.data_ptr(), orr.data_ptr(), Rw.data_ptr(), aux.data_ptr(),
+                                             *[None if t is None else t.data_ptr() for t in keep],
+                                             ds.data_ptr(), dr.data_ptr(), do.data_ptr(), _lib.stream_of(sr)))
+        return ds, dr, do, None, None, None, None
+
+
+def fused_activate(pc, camera_center, R_w2c, want_normal=True):
+    """-> (scales[N,3], rotations[N,4], opacity[N,1], normals_cam[N,3]) from the raw parameters."""
+    return _FusedActivate.apply(pc._scaling, pc._rotation, pc._opacity, pc._xyz, camera_center, R_w2c, want_normal)
+
+
+class FusedAdam:
+    """`torch.optim.Adam(lr=0.0, eps=1e-15)` semantics with per-group learning rates
+    (`scene/gaussian_model.py:247-258`), executed as ONE HIP launch over all groups.
+    Keeps `param_groups` / `state` / `step()` / `zero_grad()` / `state_dict()` like the torch class."""
+
+    def __init__(self, groups, eps=1e-15, betas=(0.9, 0.999)):
+        self.param_groups = groups
+        self.eps, self.betas = eps, betas
+        self.state = {}          # name -> dict(step, exp_avg, exp_avg_sq)
+        self.grad_scale = 1.0
+
+    def _state(self, g):
+        st = self.state.get(g["name"])
+        if st is None:
+            p = g["params"][0]
+            st = dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+            self.state[g["name"]] = st
+        return st
+
+    @torch.no_grad()
+    def step(self):
+        lib = _lib.load()
+        live = [g for g in self.param_groups if g["params"][0].grad is not None and g["params"][0].numel() > 0]
+        if not live:
+            return
+        by_step = {}
+        for g in live:
+            st = self._state(g)
+            st["step"] += 1
+            by_step.setdefault(st["step"], []).append(g)
+        for step, gs in by_step.items():
+            n = len(gs)
+            P, G, M, V = ((C.c_void_p * n)() for _ in range(4))
+            numel = (C.c_int64 * n)()
+            lr = (C.c_float * n)()
+            keep = []
+            for k, g in enumerate(gs):
+                p = g["params"][0]
+                st = self.state[g["name"]]
+                grad = p.grad.contiguous()
+                keep.append(grad)
+                P[k], G[k], M[k], V[k] = p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                numel[k], lr[k] = p.numel(), g["lr"]
+            _lib.check(lib.vcr_adam_step(n, P, G, M, V, numel, lr, self.betas[0], self.betas[1], self.eps, step,
+                                         float(self.grad_scale), _lib.stream_of(gs[0]["params"][0])))
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if set_to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
+
+    def state_dict(self):
+        return dict(state={k: dict(v) for k, v in self.state.items()},
+                    param_groups=[dict(name=g["name"], lr=g["lr"]) for g in self.param_groups])
+
+    def load_state_dict(self, sd):
+        self.state = {k: dict(v) for k, v in sd["state"].items()}
+        lrs = {g["name"]: g["lr"] for g in sd["param_groups"]}
+        for g in self.param_groups:
+            g["lr"] = lrs.get(g["name"], g["lr"])
+
+
+class GaussianModel:
+    def __init__(self, cfg):
+        self.active_sh_degree = 0
+        self.max_sh_degree = cfg.sh_degree
+        self._xyz = self._features_dc = self._features_rest = torch.empty(0)
+        self._scaling = self._rotation = self._opacity = self._objects_dc = torch.empty(0)
+        self.max_radii2D = self.xyz_gradient_accum = self.denom = torch.empty(0)
+        self.optimizer = None
+        self.percent_dense = 0
+        self.large_percent_dense = None
+        self.spatial_lr_scale = 0
+        self.max_mem = getattr(cfg, "max_mem", 22)
+        self.enable_semantic = bool(getattr(cfg, "enable_semantic", False))
+        self.ch_sem_feat = getattr(cfg, "ch_sem_feat", 0)
+        self.num_cls = getattr(cfg, "num_cls", 0)
+        self.classifier = None
+        self.extent = 1.0
+        self.trans = torch.zeros(3)
+        self.scale = torch.ones(3)
+
+    # ---- construction --------------------------------------------------------------------------
+    def create_from_params(self, raw, spatial_lr_scale, device="cuda"):
+        """Initialise from a dict in the reference's storage layout (synthetic.make_gaussians);
+        stands in for `create_from_pcd` (`scene/gaussian_model.py:199-229`), whose simple-knn
+        dependency is outside the hot path."""
+        self.spatial_lr_scale = spatial_lr_scale
+        mk = lambda t: torch.nn.Parameter(t.detach().float().to(device).contiguous().requires_grad_(True))
+        self._xyz, self._features_dc, self._features_rest = mk(raw["xyz"]), mk(raw["f_dc"]), mk(raw["f_rest"])
+        self._scaling, self._rotation, self._opacity = mk(raw["scaling"]), mk(raw["rotation"]), mk(raw["opacity"])
+        if "obj_dc" in raw:
+            self.enable_semantic = True
+            self._objects_dc = mk(raw["obj_dc"])
+            self.ch_sem_feat = raw["obj_dc"].shape[-1]
+            self.num_cls = self.num_cls or 2
+            self.classifier = torch.nn.Conv2d(self.ch_sem_feat, self.num_cls, kernel_size=1).to(device)
+        self.max_radii2D = torch.zeros(self._xyz.shape[0], device=device)
+        self.trans = self.trans.to(device)
+        self.scale = self.scale.to(device)
+
+    # ---- getters (scene/gaussian_model.py:125-195) -----------------------------------------------
+    @property
+    def device(self):
+        return self._xyz.device
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self._rotation)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._opacity)
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    @property
+    def get_objects(self):
+        return self._objects_dc
+
+    def get_normal(self, is_all=True):
+        """World-space shortest-axis normal (`scene/gaussian_model.py:168-192`); off the hot path —
+        `render()` uses `fused_activate`, which also orients and rotates it."""
+        rots = build_rotation(self.get_rotation)
+        axis = torch.argmin(self.get_scaling, dim=-1)
+        return rots.gather(2, axis[:, None, None].expand(-1, 3, -1)).squeeze(-1)
+
+    def get_covariance(self, scaling_modifier=1):
+        L = build_rotation(self._rotation) * (scaling_modifier * self.get_scaling)[:, None, :]
+        S = L @ L.transpose(1, 2)
+        return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1)
+
+    def get_inside_gaus_normalized(self):
+        """`tools/math_utils.py:50-74` with a translation-vector `trans`."""
+        pts = (self._xyz - self.trans) / self.scale
+        with torch.no_grad():
+            inside = torch.all(torch.abs(pts) < 1, dim=-1)
+        return inside, pts
+
+    def oneupSHdegree(self):
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    # ---- optimiser (scene/gaussian_model.py:232-270) -----------------------------------------------
+    def _param_table(self):
+        t = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+             "scaling": "_scaling", "rotation": "_rotation"}
+        if self.enable_semantic:
+            t["obj_dc"] = "_objects_dc"
+        return t
+
+    def training_setup(self, training_args):
+        self.percent_dense = training_args.percent_dense
+        dl = getattr(training_args, "densify_large", None)
+        self.large_percent_dense = dl.percent_dense if (dl is not None and getattr(dl, "percent_dense", 0) > 0) else None
+        N, dev = self._xyz.shape[0], self.device
+        self.xyz_gradient_accum = torch.zeros((N, 1), device=dev)
+        self.denom = torch.zeros((N, 1), device=dev)
+        lrs = {"xyz": training_args.position_lr_init * self.spatial_lr_scale, "f_dc": training_args.feature_lr,
+               "f_rest": training_args.feature_lr / 20.0, "opacity": training_args.opacity_lr,
+               "scaling": training_args.scaling_lr, "rotation": training_args.rotation_lr,
+               "obj_dc": training_args.feature_lr}
+        groups = [{"params": [getattr(self, attr)], "lr": lrs[name], "name": name}
+                  for name, attr in self._param_table().items()]
+        self.optimizer = FusedAdam(groups, eps=1e-15)
+        self.xyz_scheduler_args = get_expon_lr_func(
+            lr_init=training_args.position_lr_init * self.spatial_lr_scale,
+            lr_final=training_args.position_lr_final * self.spatial_lr_scale,
+            lr_delay_mult=training_args.position_lr_delay_mult, max_steps=training_args.position_lr_max_steps)
+
+    def update_learning_rate(self, iteration):
+        for g in self.optimizer.param_groups:
+            if g["name"] == "xyz":
+                g["lr"] = float(self.xyz_scheduler_args(iteration))
+                return g["lr"]
+
+    # ---- densification statistics --------------------------------------------------------------------
+    @torch.no_grad()
+    def add_densification_stats(self, viewspace_point_tensor, update_filter=None, radii=None):
+        """`scene/gaussian_model.py:669-671` (+ the max_radii2D update of `trainer.py:345` when `radii`
+        is given): one HIP kernel instead of three masked index ops."""
+        g = viewspace_point_tensor.grad if viewspace_point_tensor.grad is not None else viewspace_point_tensor
+        if radii is None:
+            self.xyz_gradient_accum[update_filter] += torch.norm(g[update_filter, :2], dim=-1, keepdim=True)
+            self.denom[update_filter] += 1
+            return
+        lib = _lib.load()
+        g = g.contiguous()
+        _lib.check(lib.vcr_densify_stats(g.shape[0], g.data_ptr(), radii.data_ptr(), self.xyz_gradient_accum.data_ptr(),
+                                         self.denom.data_ptr(), self.max_radii2D.data_ptr(), _lib.stream_of(g)))
+
+    # ---- optimiser-state surgery (scene/gaussian_model.py:425-531) -----------------------------------
+    def _set_params(self, new):
+        for name, attr in self._param_table().items():
+            setattr(self, attr, new[name])
+
+    def _rebind(self, fn_param, fn_state):
+        out = {}
+        for g in self.optimizer.param_groups:
+            p = g["params"][0]
+            newp = torch.nn.Parameter(fn_param(g["name"], p.detach()).contiguous().requires_grad_(True))
+            st = self.optimizer.state.get(g["name"])
+            if st is not None:
+                st["exp_avg"] = fn_state(g["name"], st["exp_avg"]).contiguous()
+                st["exp_avg_sq"] = fn_state(g["name"], st["exp_avg_sq"]).contiguous()
+            g["params"][0] = newp
+            out[g["name"]] = newp
+        self._set_params(out)
+
+    @torch.no_grad()
+    def prune_points(self, mask):
+        keep = ~mask
+        self._rebind(lambda n, p: p[keep], lambda n, s: s[keep])
+        self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
+        self.denom = self.denom[keep]
+        self.max_radii2D = self.max_radii2D[keep]
+
+    @torch.no_grad()
+    def densification_postfix(self, new, reset=True):
+        self._rebind(lambda n, p: torch.cat((p, new[n]), 0), lambda n, s: torch.cat((s, torch.zeros_like(new[n])), 0))
+        N, dev = self._xyz.shape[0], self.device
+        if reset:
+            self.xyz_gradient_accum = torch.zeros((N, 1), device=dev)
+            self.denom = torch.zeros((N, 1), device=dev)
+            self.max_radii2D = torch.zeros(N, device=dev)
+        else:
+            k = N - self.max_radii2D.shape[0]
+            self.xyz_gradient_accum = torch.cat((self.xyz_gradient_accum, torch.zeros((k, 1), device=dev)))
+            self.denom = torch.cat((self.denom, torch.zeros((k, 1), device=dev)))
+            self.max_radii2D = torch.cat((self.max_radii2D, torch.zeros(k, device=dev)))
+
+    def _gather(self, mask, times=1):
+        out = {}
+        for name, attr in self._param_table().items():
+            v = getattr(self, attr).detach()[mask]
+            out[name] = torch.cat([v] * times, 0) if times > 1 else v
+        return out
+
+    @torch.no_grad()
+    def densify_and_clone(self, grads, grad_threshold, scene_extent):
+        sel = torch.norm(grads, dim=-1) >= grad_threshold
+        sel &= self.get_scaling.max(dim=1).values <= self.percent_dense * scene_extent
+        self.densification_postfix(self._gather(sel))
+
+    @torch.no_grad()
+    def densify_and_split_along_maxscaling(self, grads, grad_threshold, scene_extent, visi=None, N=2, n_std=2):
+        """Deterministic two-way split along the longest axis (`scene/gaussian_model.py:579-628`):
+        children at mu +- (n_std/3) s_max e_max, longest scale divided by 0.8 N."""
+        n0 = self._xyz.shape[0]
+        padded = torch.zeros(n0, device=self.device)
+        padded[:grads.shape[0]] = grads.squeeze()
+        smax = self.get_scaling.max(dim=1).values
+        sel = (padded >= grad_threshold) & (smax > self.percent_dense * scene_extent)
+        mem_gb = torch.cuda.memory_allocated(self.device) / 1024 ** 3 if self.device.type == "cuda" else 0.0
+        if self.large_percent_dense is not None and mem_gb < self.max_mem:
+            big = (smax > self.large_percent_dense * scene_extent) & self.get_inside_gaus_normalized()[0]
+            if visi is not None:
+                pv = torch.zeros(n0, device=self.device, dtype=torch.bool)
+                pv[:visi.shape[0]] = visi
+                big &= pv
+            sel |= big
+        scaling = self.get_scaling[sel]
+        rots = build_rotation(self._rotation.detach()[sel])
+        axis = torch.argmax(scaling, dim=-1)
+        ar = torch.arange(scaling.shape[0], device=self.device)
+        max_s = scaling[ar, axis]
+        dirs = rots.gather(2, axis[:, None, None].expand(-1, 3, -1)).squeeze(-1)
+        off = dirs * (n_std * max_s / 3.0)[:, None]
+        new = self._gather(sel, times=N)
+        base = self._xyz.detach()[sel]
+        new["xyz"] = torch.cat((base + off, base - off), 0)
+        ns = scaling.clone()
+        ns[ar, axis] = max_s / (0.8 * N)
+        new["scaling"] = torch.log(ns).repeat(N, 1)
+        self.densification_postfix(new)
+        prune = torch.cat((sel, torch.zeros(N * int(sel.sum()), device=self.device, dtype=torch.bool)))
+        self.prune_points(prune)
+
+    @torch.no_grad()
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, visi=None):
+        """`scene/gaussian_model.py:643-659`."""
+        grads = self.xyz_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        self.densify_and_clone(grads, max_grad, extent)
+        self.densify_and_split_along_maxscaling(grads, max_grad, extent, visi=visi)
+        prune = (self.get_opacity < min_opacity).squeeze()
+        if max_screen_size:
+            prune |= self.max_radii2D > max_screen_size
+            prune |= self.get_scaling.max(dim=1).values > 0.1 * extent
+        self.prune_points(prune)
+
+    @torch.no_grad()
+    def reset_opacity(self):
+        """`scene/gaussian_model.py:361-364`: opacity <- min(opacity, 0.01), Adam moments zeroed."""
+        new = inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * 0.01))
+        for g in self.optimizer.param_groups:
+            if g["name"] == "opacity":
+                st = self.optimizer.state.get("opacity")
+                if st is not None:
+                    st["exp_avg"] = torch.zeros_like(new)
+                    st["exp_avg_sq"] = torch.zeros_like(new)
+                g["params"][0] = torch.nn.Parameter(new.contiguous().requires_grad_(True))
+                self._opacity = g["params"][0]
+
+    @torch.no_grad()
+    def prune_gaussians(self, percent, import_score):
+        """`scene/gaussian_model.py:661-667`."""
+        s, _ = torch.sort(import_score, dim=0)
+        thr = s[int(percent * (s.shape[0] - 1))]
+        self.prune_points((import_score <= thr).squeeze())
+
+    # ---- checkpoint (scene/gaussian_model.py:88-123) ---------------------------------------------------
+    def capture(self):
+        return (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
+                self._opacity, self._objects_dc, self.max_radii2D, self.xyz_gradient_accum, self.denom,
+                self.optimizer.state_dict(), self.spatial_lr_scale)
+
+    def restore(self, model_args, training_args):
+        (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
+         self._opacity, self._objects_dc, self.max_radii2D, acc, den, opt, self.spatial_lr_scale) = model_args
+        self.training_setup(training_args)
+        self.xyz_gradient_accum, self.denom = acc, den
+        self.optimizer.load_state_dict(opt)

@@ -1,0 +1,107 @@
+"""`render()` and the forward-only raster modes: same signature, dictionary keys and shapes as the
+reference's `gaussian_renderer/__init__.py` (`render :22-164`, `count_render :250-355`,
+`visi_acc_render :467-571`), with every tensor op on the path executed by a HIP kernel:
+fused activation/normal kernel -> rasterizer -> normal normalisation -> depth-to-normal."""
+import math
+
+import torch
+
+from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+from .gaussian_model import fused_activate
+from .normal_utils import compute_normals, normalize_rendered_normal
+
+
+def _settings(cam, pc, bg_color, scaling_modifier, debug, f_count):
+    return GaussianRasterizationSettings(
+        image_height=int(cam.image_height), image_width=int(cam.image_width),
+        tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=cam.camera_center, prefiltered=False, debug=debug, f_count=f_count)
+
+
+def _cam_rotation(cam, device):
+    R = getattr(cam, "R_w2c", None)
+    if R is None:   # reference cameras only carry the numpy c2w rotation (`scene/cameras.py:28`)
+        R = torch.tensor(cam.R.T, dtype=torch.float32)
+    return R.to(device)
+
+
+def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_color=None, return_normal=True,
+           is_all=True, dirs=None, mask_depth_thr=0.8):
+    """Background tensor (bg_color) must be on the GPU.  Returns the reference's dict:
+    render[3,H,W] depth[1,H,W] normal[H,W,3] est_normal[H,W,3] alpha[1,H,W] viewspace_points[N,3]
+    viewspace_points_densify[N,3] visibility_filter[N] mask[H,W] radii[N] (+render_sem)."""
+    dev = pc.get_xyz.device
+    screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True) + 0
+    screenspace_points_densify = torch.zeros_like(pc.get_xyz, requires_grad=True) + 0
+    screenspace_points.retain_grad()
+    screenspace_points_densify.retain_grad()
+
+    rs = _settings(viewpoint_camera, pc, bg_color, scaling_modifier, cfg.pipline.debug, 0)
+    rasterizer = GaussianRasterizer(raster_settings=rs)
+
+    act = fused_activate(pc, viewpoint_camera.camera_center, _cam_rotation(viewpoint_camera, dev), return_normal)
+    scales, rotations, opacity = act[:3]
+    normals_precomp = act[3] if return_normal else None
+    cov3D_precomp = None
+    if cfg.pipline.compute_cov3D_python:
+        cov3D_precomp, scales, rotations = pc.get_covariance(scaling_modifier), None, None
+
+    shs, colors_precomp = (pc.get_features, None) if override_color is None else (None, override_color)
+    sem_feats = pc.get_objects.squeeze(1) if cfg.optim.loss_weight.semantic > 0 else None
+
+    rendered_out, radii = rasterizer(
+        means3D=pc.get_xyz, means2D=screenspace_points, means2D_densify=screenspace_points_densify, shs=shs,
+        colors_precomp=colors_precomp, normals_precomp=normals_precomp, semantics_precomp=sem_feats,
+        opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, dirs=dirs, inside=None)
+
+    rendered_image, rendered_depth, rendered_normal, rendered_alpha = rendered_out[:8].split([3, 1, 3, 1], dim=0)
+    with torch.no_grad():
+        mask = viewpoint_camera.mask.bool() if hasattr(viewpoint_camera, "mask") else None
+        if cfg.optim.mask_depth_thr > 0:
+            m1 = (rendered_depth < (pc.extent * cfg.optim.mask_depth_thr)).squeeze(0)
+            mask = m1 if mask is None else (mask & m1)
+        if mask is None:
+            mask = torch.ones(rendered_depth.shape[1:], dtype=torch.bool, device=dev)
+
+    normal = normalize_rendered_normal(rendered_normal)
+    est_normal = compute_normals(rendered_depth, viewpoint_camera.intr,
+                                 getattr(viewpoint_camera, "intr_scalars", None))
+    out = {"render": rendered_image, "depth": rendered_depth, "normal": normal, "est_normal": est_normal,
+           "alpha": rendered_alpha, "viewspace_points": screenspace_points,
+           "viewspace_points_densify": screenspace_points_densify, "visibility_filter": radii > 0, "mask": mask,
+           "radii": radii}
+    if cfg.optim.loss_weight.semantic > 0:
+        sem = rendered_out[8:8 + cfg.model.ch_sem_feat]
+        out["render_sem"] = pc.classifier(sem[None])[0].permute(1, 2, 0)
+    return out
+
+
+def _forward_only(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, f_count):
+    rs = _settings(viewpoint_camera, pc, bg_color, scaling_modifier, pipe.debug, f_count)
+    rasterizer = GaussianRasterizer(raster_settings=rs)
+    dev = pc.get_xyz.device
+    with torch.no_grad():
+        scales, rotations, opacity = fused_activate(pc, viewpoint_camera.camera_center,
+                                                    _cam_rotation(viewpoint_camera, dev), False)
+    shs, colors = (pc.get_features, None) if override_color is None else (None, override_color)
+    screenspace_points = torch.zeros_like(pc.get_xyz)
+    res = rasterizer(means3D=pc.get_xyz, means2D=screenspace_points, means2D_densify=None, shs=shs,
+                     colors_precomp=colors, normals_precomp=None, semantics_precomp=None, opacities=opacity,
+                     scales=scales, rotations=rotations, cov3D_precomp=None)
+    return res, screenspace_points
+
+
+def count_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+    """f_count=1 (`gaussian_renderer/__init__.py:250-355`): per-Gaussian hit count and sum of alpha*T."""
+    (count, score, image, radii), sp = _forward_only(viewpoint_camera, pc, pipe, bg_color, scaling_modifier,
+                                                     override_color, 1)
+    return {"render": image, "viewspace_points": sp, "visibility_filter": radii > 0, "radii": radii,
+            "gaussians_count": count, "important_score": score}
+
+
+def visi_acc_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+    """f_count=3 (`gaussian_renderer/__init__.py:467-571`): per-Gaussian visibility count only."""
+    (count, radii), sp = _forward_only(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, 3)
+    return {"viewspace_points": sp, "visibility_filter": radii > 0, "radii": radii, "countlist": count}

@@ -1,0 +1,124 @@
+"""Training losses, HIP-backed.  Function names follow the reference's `tools/loss_utils.py`."""
+import torch
+
+from . import _lib
+
+
+class _L1SSIM(torch.autograd.Function):
+    """One pass over both images: returns (mean |a-b|, mean ssim_map)."""
+
+    @staticmethod
+    def forward(ctx, img1, img2):
+        lib = _lib.load()
+        a = img1.detach().contiguous().float()
+        b = img2.detach().contiguous().float()
+        C, H, W = a.shape
+        assert C == 3, "l1_ssim expects [3,H,W] images"
+        sums = torch.empty(2, dtype=torch.float64, device=a.device)
+        need = img1.requires_grad
+        part = torch.empty(9, H, W, dtype=torch.float32, device=a.device) if need else None
+        _lib.check(lib.vcr_l1_ssim_forward(H, W, a.data_ptr(), b.data_ptr(), sums.data_ptr(),
+                                           part.data_ptr() if need else None, _lib.stream_of(a)))
+        ctx.save_for_backward(a, b, part)
+        res = (sums / (3.0 * H * W)).float()
+        return res[0], res[1]
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ssim):
+        lib = _lib.load()
+        a, b, part = ctx.saved_tensors
+        _, H, W = a.shape
+        d = torch.empty_like(a)
+        gl = g_l1.contiguous().float().reshape(1)
+        gs = g_ssim.contiguous().float().reshape(1)
+        _lib.check(lib.vcr_l1_ssim_backward(H, W, a.data_ptr(), b.data_ptr(), part.data_ptr(), gl.data_ptr(),
+                                            gs.data_ptr(), d.data_ptr(), _lib.stream_of(a)))
+        return d, None
+
+
+def l1_ssim(network_output, gt):
+    """Fused (l1_loss, ssim) pair (`tools/loss_utils.py:36,61-92`)."""
+    return _L1SSIM.apply(network_output, gt)
+
+
+def l1_loss(network_output, gt):
+    """`tools/loss_utils.py:36-37` for [3,H,W] images (shares the fused kernel)."""
+    if network_output.dim() == 3 and network_output.shape[0] == 3:
+        return _L1SSIM.apply(network_output, gt)[0]
+    return torch.abs(network_output - gt).mean()     # small per-Gaussian vectors (l1_scale)
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """`tools/loss_utils.py:61-92` (11x11, sigma 1.5, zero padding, C1=.01^2, C2=.03^2, global mean)."""
+    assert window_size == 11 and size_average
+    return _L1SSIM.apply(img1, img2)[1]
+
+
+class _NormalLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, wsrc, exp_t, mask, gt_grad):
+        lib = _lib.load()
+        p = pred.detach().contiguous().float().view(-1, 3)
+        g = gt.detach().contiguous().float().view(-1, 3)
+        w = None if wsrc is None else wsrc.detach().contiguous().float().view(-1, 3)
+        m = None if mask is None else mask.detach().contiguous().view(-1).to(torch.uint8)
+        P = p.shape[0]
+        sums = torch.empty(3, dtype=torch.float64, device=p.device)
+        _lib.check(lib.vcr_normal_loss_forward(P, p.data_ptr(), g.data_ptr(), None if w is None else w.data_ptr(),
+                                               float(exp_t), None if m is None else m.data_ptr(), sums.data_ptr(),
+                                               _lib.stream_of(p)))
+        ctx.save_for_backward(p, g, w, m, sums)
+        ctx.exp_t, ctx.shape, ctx.gt_grad = float(exp_t), pred.shape, bool(gt_grad)
+        cnt = sums[2]
+        return torch.where(cnt > 0, (sums[0] + sums[1]) / cnt.clamp_min(1.0), torch.zeros_like(cnt)).float()
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        p, g, w, m, sums = ctx.saved_tensors
+        go = gout.contiguous().float().reshape(1)
+        dp = torch.empty_like(p)
+        dg = torch.empty_like(p) if ctx.gt_grad else None
+        _lib.check(lib.vcr_normal_loss_backward(p.shape[0], p.data_ptr(), g.data_ptr(), None if w is None else w.data_ptr(),
+                                                ctx.exp_t, None if m is None else m.data_ptr(), sums.data_ptr(),
+                                                go.data_ptr(), dp.data_ptr(), None if dg is None else dg.data_ptr(),
+                                                _lib.stream_of(p)))
+        return dp.view(ctx.shape), (dg.view(ctx.shape) if dg is not None else None), None, None, None, None
+
+
+def normal_loss(normal_pred, normal_gt, weight_src=None, exp_t=0.0, mask=None):
+    """Fused form of the reference's D-Normal chain (`trainer.py:266-280`):
+        w = cos_weight(weight_src.detach(), gt, exp_t);  monosdf_normal_loss(pred[mask], gt[mask], w[mask])
+    i.e. mean_mask(w |p-g|_1) + mean_mask(w (1 - p.g)) with w = exp((<weight_src,g> - 1)/exp_t)
+    (`tools/loss_utils.py:122-143`).  Gradients flow to `normal_pred` and, when it requires grad
+    (normal-consistency loss, `trainer.py:289-293`), to `normal_gt`."""
+    return _NormalLoss.apply(normal_pred, normal_gt, weight_src, exp_t, mask, normal_gt.requires_grad)
+
+
+def monosdf_normal_loss(normal_pred, normal_gt, weight=None):
+    """`tools/loss_utils.py:122-132`.  Unweighted calls run on the fused HIP kernel; an explicit
+    per-pixel weight tensor (only produced by `cos_weight`, which `normal_loss` fuses) falls back to
+    the two-line torch expression for API compatibility."""
+    if weight is None:
+        return normal_loss(normal_pred, normal_gt)
+    l1 = (weight * torch.abs(normal_pred - normal_gt).sum(dim=-1)).mean()
+    cos = (weight * (1.0 - torch.sum(normal_pred * normal_gt, dim=-1))).mean()
+    return l1 + cos
+
+
+def cos_weight(render_normal, gt_normal, exp_t=1.0):
+    """`tools/loss_utils.py:135-143` (kept for API compatibility; `normal_loss` computes it in-kernel)."""
+    cos = torch.sum(render_normal * gt_normal, dim=-1)
+    cos = torch.exp((cos - 1) / exp_t) if exp_t > 0 else torch.ones_like(cos)
+    return cos.detach()
+
+
+def entropy_loss(opacity):
+    """`tools/loss_utils.py:30-33` (weight 0 in every shipped config)."""
+    return (-opacity * torch.log(opacity + 1e-6) - (1 - opacity) * torch.log(1 - opacity + 1e-6)).mean()
+
+
+def psnr(img1, img2):
+    """`tools/image_utils.py:17-19`."""
+    mse = ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))

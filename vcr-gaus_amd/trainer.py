@@ -1,0 +1,244 @@
+"""Training step of the reference (`trainer.py:233-392`) on the HIP hot path, plus view-parallel
+data parallelism (new capability: the reference trains on one GPU).
+
+Per iteration (same order as `Trainer.train_step`, `trainer.py:323-392`):
+  camera pick -> render() -> loss dictionary (`_compute_loss`, :233-308) -> weighted sum (:310-321)
+  -> backward -> [DP: sum all-reduce of the per-Gaussian gradients over RCCL] -> densification
+  statistics / densify_and_prune / opacity reset on the reference's schedule -> Adam step.
+
+Data parallelism: one process per GPU; every rank holds a full replica (parameters, Adam moments,
+densification statistics), renders ITS OWN camera of the step's batch of `world` cameras, and the
+gradients are summed across ranks and scaled by 1/world inside the fused Adam kernel.  All schedule
+decisions depend only on all-reduced quantities, so replicas stay in lock-step without broadcasts.
+"""
+import random
+
+import torch
+import torch.distributed as dist
+
+from .gaussian_model import GaussianModel
+from .gaussian_renderer import count_render, render, visi_acc_render
+from .loss_utils import l1_ssim, normal_loss
+from .normal_utils import get_edge_aware_distortion_map
+
+
+class Trainer:
+    def __init__(self, cfg, model, cameras, extent, device, world=1, rank=0, dirs=None, seed=0):
+        self.cfg, self.model, self.cameras = cfg, model, cameras
+        self.device, self.world, self.rank = device, world, rank
+        self.extent = extent
+        self.model.extent = extent
+        self.dirs = dirs
+        self.weights = {k: v for k, v in cfg.optim.loss_weight.items() if v}
+        self.losses = {}
+        self.current_iteration = 0
+        self.background = torch.tensor([1.0, 1.0, 1.0] if cfg.model.white_background else [0.0, 0.0, 0.0], device=device)
+        self.rng = random.Random(seed)            # identical on every rank
+        self.gen = torch.Generator(device="cpu").manual_seed(seed)
+        self.view_order = []
+        self.visi_list = None
+        self.last_stats = {}
+
+    # ---- camera batch: `world` cameras per step, rank r takes the r-th (`trainer.py:326-328`) -------
+    def _next_cameras(self):
+        picked = []
+        for _ in range(self.world):
+            if not self.view_order:
+                self.view_order = list(range(len(self.cameras)))
+            picked.append(self.view_order.pop(self.rng.randint(0, len(self.view_order) - 1)))
+        return picked
+
+    # ---- losses (`trainer.py:233-321`) -------------------------------------------------------------------
+    def _compute_loss(self, data, cam):
+        cfg, it, L = self.cfg, self.current_iteration, {}
+        gt_image = cam.original_image
+        l1, ssim_v = l1_ssim(data["render"], gt_image)
+        L["l1"], L["ssim"] = l1, 1.0 - ssim_v
+        if "l1_scale" in self.weights:
+            inside, _ = self.model.get_inside_gaus_normalized()
+            smin = torch.exp(self.model._scaling.min(-1)[0])
+            L["l1_scale"] = (smin * inside).sum() / inside.sum().clamp_min(1)
+        gt_normal = getattr(cam, "normal", None)
+        if "mono_normal" in self.weights and it > cfg.optim.normal_from_iter:
+            L["mono_normal"] = normal_loss(data["normal"], gt_normal)
+        if "depth_normal" in self.weights and it > cfg.optim.dnormal_from_iter:
+            L["depth_normal"] = normal_loss(data["est_normal"], gt_normal, weight_src=data["normal"].detach(),
+                                            exp_t=cfg.optim.exp_t, mask=data["mask"])
+        if "consistent_normal" in self.weights and it > cfg.optim.consistent_normal_from_iter:
+            L["consistent_normal"] = normal_loss(data["est_normal"], data["normal"])
+        if "distortion" in self.weights and it > cfg.optim.close_depth_from_iter and "distortion" in data:
+            L["distortion"] = get_edge_aware_distortion_map(gt_image, data["distortion"]).mean()
+        if "semantic" in self.weights and "render_sem" in data:
+            logits = data["render_sem"].reshape(-1, self.model.num_cls)
+            L["semantic"] = torch.nn.functional.cross_entropy(logits, cam.mask.view(-1).long()) / \
+                torch.log(torch.tensor(float(self.model.num_cls)))
+        self.losses = L
+        total = None
+        for k, w in self.weights.items():
+            if k in L:
+                total = L[k] * w if total is None else total + L[k] * w
+        L["total"] = total
+        return total
+
+    # ---- gradient exchange ------------------------------------------------------------------------------------
+    def _allreduce_grads(self):
+        """Sum the per-Gaussian gradients of all ranks (RCCL over xGMI).  One collective per parameter
+        tensor, all in flight together; the 1/world scale is folded into the Adam kernel."""
+        if self.world == 1:
+            self.model.optimizer.grad_scale = 1.0
+            return
+        works = []
+        for g in self.model.optimizer.param_groups:
+            p = g["params"][0]
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
+        self.model.optimizer.grad_scale = 1.0 / self.world
+
+    def _densify_stats(self, data):
+        m = self.model
+        vp = data["viewspace_points_densify"]
+        if self.world == 1:
+            m.add_densification_stats(vp, data["visibility_filter"], radii=data["radii"])
+            return
+        N = m._xyz.shape[0]
+        acc, den, mr = torch.zeros(N, 1, device=self.device), torch.zeros(N, 1, device=self.device), torch.zeros(N, device=self.device)
+        keep = (m.xyz_gradient_accum, m.denom, m.max_radii2D)
+        m.xyz_gradient_accum, m.denom, m.max_radii2D = acc, den, mr
+        m.add_densification_stats(vp, data["visibility_filter"], radii=data["radii"])
+        m.xyz_gradient_accum, m.denom, m.max_radii2D = keep
+        pair = torch.cat([acc, den], 1)
+        w1 = dist.all_reduce(pair, op=dist.ReduceOp.SUM, async_op=True)
+        w2 = dist.all_reduce(mr, op=dist.ReduceOp.MAX, async_op=True)
+        w1.wait(); w2.wait()
+        m.xyz_gradient_accum += pair[:, :1]
+        m.denom += pair[:, 1:]
+        torch.maximum(m.max_radii2D, mr, out=m.max_radii2D)
+
+    # ---- visibility / importance passes (`tools/prune.py:6-69`, `trainer.py:688-702`), camera-sharded ------------
+    @torch.no_grad()
+    def visibility_mask(self, cams):
+        count = None
+        for cam in cams[self.rank::self.world]:
+            c = visi_acc_render(cam, self.model, self.cfg.pipline, self.background)["countlist"]
+            count = c if count is None else count + c
+        if count is None:
+            count = torch.zeros(self.model._xyz.shape[0], dtype=torch.int32, device=self.device)
+        if self.world > 1:
+            dist.all_reduce(count, op=dist.ReduceOp.SUM)
+        return (count > 0) & self.model.get_inside_gaus_normalized()[0]
+
+    @torch.no_grad()
+    def importance_scores(self, cams):
+        cnt, imp = None, None
+        for cam in cams[self.rank::self.world]:
+            pkg = count_render(cam, self.model, self.cfg.pipline, self.background)
+            cnt = pkg["gaussians_count"] if cnt is None else cnt + pkg["gaussians_count"]
+            imp = pkg["important_score"] if imp is None else imp + pkg["important_score"]
+        if self.world > 1:
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            dist.all_reduce(imp, op=dist.ReduceOp.SUM)
+        return cnt, imp
+
+    def v_imp_score(self, imp, v_pow):
+        """`tools/prune.py:6-22`."""
+        vol = torch.prod(self.model.get_scaling, dim=1)
+        kth = torch.sort(vol, descending=True)[0][int(len(vol) * 0.9)]
+        return torch.pow(vol / kth, v_pow) * imp
+
+    # ---- one iteration ------------------------------------------------------------------------------------------
+    def train_step(self):
+        cfg, m = self.cfg, self.model
+        self.current_iteration += 1
+        it = self.current_iteration
+        m.update_learning_rate(it)
+        if it % 1000 == 0:
+            m.oneupSHdegree()
+        cam = self.cameras[self._next_cameras()[self.rank]]
+        bg = torch.rand(3, generator=self.gen).to(self.device) if cfg.optim.random_background else self.background
+        data = render(cam, m, cfg, bg, dirs=self.dirs)
+        loss = self._compute_loss(data, cam)
+        loss.backward()
+        with torch.no_grad():
+            self._allreduce_grads()
+            if it < cfg.optim.densify_until_iter:
+                self._densify_stats(data)
+                if it > cfg.optim.densify_from_iter and it % cfg.optim.densification_interval == 0:
+                    size_threshold = 20 if it > cfg.optim.opacity_reset_interval else None
+                    visi = None
+                    dl = cfg.optim.densify_large
+                    if dl.percent_dense and dl.sample_cams.num > 0:
+                        n = min(dl.sample_cams.num, len(self.cameras))
+                        visi = self.visibility_mask(self.rng.sample(self.cameras, n))
+                    m.densify_and_prune(cfg.optim.densify_grad_threshold, 0.005, self.extent, size_threshold, visi)
+                if it % cfg.optim.opacity_reset_interval == 0 or (cfg.model.white_background and it == cfg.optim.densify_from_iter):
+                    m.reset_opacity()
+            if it in cfg.optim.prune.iterations:
+                _, imp = self.importance_scores(self.cameras)
+                i = cfg.optim.prune.iterations.index(it)
+                m.prune_gaussians((cfg.optim.prune.decay ** i) * cfg.optim.prune.percent,
+                                  self.v_imp_score(imp, cfg.optim.prune.v_pow))
+            m.optimizer.step()
+            m.optimizer.zero_grad(set_to_none=True)
+        return data
+
+
+def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_jitter=0.02, seed=0, **overrides):
+    """Model + GT (renders of a perturbed copy of the scene, so every loss is non-trivial) + Trainer."""
+    from . import synthetic
+    from .config import make_config
+    from .graphics_utils import get_all_px_dir
+    cfg = make_config(preset, **overrides)
+    sem = "obj_dc" in raw
+    cfg.model.enable_semantic = sem
+    if sem:
+        cfg.model.ch_sem_feat = raw["obj_dc"].shape[-1]
+        cfg.model.num_cls = 2
+    model = GaussianModel(cfg.model)
+    model.create_from_params(raw, spatial_lr_scale=synthetic.cameras_extent(cams), device=device)
+    model.active_sh_degree = cfg.model.sh_degree
+    model.training_setup(cfg.optim)
+    extent = synthetic.cameras_extent(cams)
+    dirs = get_all_px_dir(cams[0].intr, cams[0].image_height, cams[0].image_width) \
+        if cfg.model.depth_type == "intersection" else None
+    tr = Trainer(cfg, model, cams, extent, device, world=world, rank=rank, dirs=dirs, seed=seed)
+    # ground truth from a jittered copy
+    g = torch.Generator().manual_seed(seed + 1)
+    raw2 = {k: v.clone() for k, v in raw.items()}
+    raw2["xyz"] = raw2["xyz"] + gt_jitter * 0.1 * torch.randn(raw["xyz"].shape, generator=g)
+    raw2["f_dc"] = raw2["f_dc"] + gt_jitter * 5 * torch.randn(raw["f_dc"].shape, generator=g)
+    gt_model = GaussianModel(cfg.model)
+    gt_model.create_from_params(raw2, spatial_lr_scale=1.0, device=device)
+    gt_model.active_sh_degree = cfg.model.sh_degree
+    gt_model.extent = extent
+    bg = torch.zeros(3, device=device)
+    with torch.no_grad():
+        for cam in cams:
+            pkg = render(cam, gt_model, cfg, bg, dirs=dirs)
+            cam.original_image = pkg["render"].clamp(0, 1).contiguous()
+            cam.normal = pkg["est_normal"].contiguous()
+            if sem:
+                cam.mask = (pkg["depth"][0] > 0).long()
+    del gt_model
+    return tr
+
+
+class BenchTrainer:
+    """bench.py's step: exactly `Trainer.train_step` on a synthetic workload."""
+
+    def __init__(self, raw, cams, device, world=1, rank=0, preset="tnt"):
+        self.tr = make_synthetic_trainer(raw, cams, device, world=world, rank=rank, preset=preset,
+                                         optim={"densify_from_iter": 10 ** 9, "prune": {"iterations": []}})
+        self.last_R = self.last_V = 0
+
+    def step(self, i):
+        from . import rasterizer
+        self.tr.train_step()
+        self.last_R, self.last_V = rasterizer.last_stats.get("R", 0), rasterizer.last_stats.get("V", 0)
+
+    def describe(self):
+        w = self.tr.weights
+        return "render fwd (activate, raster, normals) + losses[" + ",".join(sorted(w)) + "] + bwd + " + \
+            ("RCCL grad all-reduce + " if self.tr.world > 1 else "") + "fused Adam (densify/prune off in the timed window)"
