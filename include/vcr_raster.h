@@ -139,8 +139,10 @@ int vcr_depth_to_normal_backward(int H, int W, float fx, float fy, float cx, flo
 int vcr_normalize_chw_forward(int P, const float* in_chw, float* out_hwc, void* stream);
 int vcr_normalize_chw_backward(int P, const float* in_chw, const float* dout_hwc, float* din_chw, void* stream);
 /* monosdf_normal_loss with the cos_weight confidence and boolean mask fused in
- * (tools/loss_utils.py:122-143, trainer.py:261-293).  sums3 (device, fp64) = {sum w|p-g|_1, sum w(1-p.g), count};
- * loss = (sums[0]+sums[1])/sums[2].  wsrc NULL or exp_t<=0 -> w=1.  dgt may be NULL. */
+ * (tools/loss_utils.py:122-143, trainer.py:261-293).  sums3 (device, fp64, vcr_sums_elems(3) doubles: results
+ * first, reduction slots behind) = {sum w|p-g|_1, sum w(1-p.g), count}; loss = (sums[0]+sums[1])/sums[2].
+ * wsrc NULL or exp_t<=0 -> w=1.  dgt may be NULL. */
+int vcr_sums_elems(int k);
 int vcr_normal_loss_forward(int P, const float* pred, const float* gt, const float* wsrc, float exp_t,
                             const uint8_t* mask, double* sums3, void* stream);
 int vcr_normal_loss_backward(int P, const float* pred, const float* gt, const float* wsrc, float exp_t,

@@ -129,13 +129,14 @@ def test_render_keys_and_training_reduces_loss(device):
     raw["scaling"] = raw["scaling"] + 1.0
     cams = synthetic.make_cameras(4, 160, 120, 140.0, device=device)
     tr = make_synthetic_trainer(raw, cams, device, preset="dtu", gt_jitter=0.05,
-                                optim={"densify_from_iter": 5, "densification_interval": 10, "densify_until_iter": 1000})
-    first, n0 = None, tr.model._xyz.shape[0]
-    for i in range(40):
+                                optim={"densify_from_iter": 40, "densification_interval": 10, "densify_until_iter": 1000})
+    n0 = tr.model._xyz.shape[0]
+    hist = []
+    for i in range(60):
         data = tr.train_step()
-        tot = float(tr.losses["total"])
-        assert np.isfinite(tot)
-        first = tot if first is None else first
+        hist.append(float(tr.losses["total"]))
+        assert np.isfinite(hist[-1])
+    first, tot = sum(hist[:4]) / 4, sum(hist[36:40]) / 4      # before the first densification (iteration 50)
     for k in ["render", "depth", "normal", "est_normal", "alpha", "viewspace_points", "viewspace_points_densify",
               "visibility_filter", "mask", "radii"]:
         assert k in data

@@ -67,6 +67,7 @@ SYMBOLS = {
                                           C.c_void_p, C.c_void_p]),
     "vcr_normal_loss_backward": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vcr_sums_elems": (C.c_int, [C.c_int]),
     "vcr_l1_ssim_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5),
     "vcr_l1_ssim_backward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 7),
     "vcr_profile_enable": (None, [C.c_int]),

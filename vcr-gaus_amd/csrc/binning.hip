@@ -93,6 +93,9 @@ size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits) {
     auto it = rocprim::make_transform_iterator(d, GatherTiles{d});
     (void)rocprim::inclusive_scan(nullptr, b1, it, d, (size_t)N, rocprim::plus<uint32_t>(), (hipStream_t)0);
     if (R > 0) (void)rocprim::radix_sort_pairs(nullptr, b2, d, d, d, d, (size_t)R, 0, tile_bits, (hipStream_t)0);
+    size_t b3 = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, b3, d, d, d, d, (size_t)(1 << tile_bits), 0, 32, (hipStream_t)0);
+    if (b3 > b2) b2 = b3;
     size_t m = b0 > b1 ? b0 : b1;
     return vcr_align(m > b2 ? m : b2);
 }
@@ -110,10 +113,10 @@ int vcr_depth_sort_and_scan(int N, const uint32_t* depth_key, const uint32_t* id
 
 int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const uint32_t* ids_sorted,
                            const uint32_t* offsets, int64_t R, int tile_bits, uint32_t* keys_a, uint32_t* vals_a,
-                           uint32_t* keys_b, uint32_t* point_list, uint2* ranges, int num_tiles, void* temp,
-                           size_t temp_bytes, hipStream_t st) {
+                           uint32_t* keys_b, uint32_t* point_list, uint2* ranges, uint32_t* tile_order, int num_tiles,
+                           void* temp, size_t temp_bytes, hipStream_t st) {
     VCR_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, st));
-    if (R <= 0) return 0;
+    if (R <= 0) return vcr_launch_tile_len(num_tiles, ranges, keys_a, tile_order, st);   // identity order
     const int blocks = (a.N + 255) / 256;
     hipLaunchKernelGGL(duplicate_kernel, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, offsets, g.rec, radii,
                        g.tiles, keys_a, vals_a);
@@ -123,5 +126,10 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
     const int64_t rb = (R + 255) / 256;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)rb), dim3(256), 0, st, R, keys_b, ranges);
     VCR_HIP_CHECK(hipGetLastError());
+    // longest-first tile order; keys_a / vals_a are free again and hold >= 2*T words each (caller guarantees)
+    uint32_t* lk = keys_a; uint32_t* lv = vals_a; uint32_t* lk2 = keys_a + num_tiles;
+    if (vcr_launch_tile_len(num_tiles, ranges, lk, lv, st)) return 1;
+    tb = temp_bytes;
+    VCR_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, lk, lk2, lv, tile_order, (size_t)num_tiles, 0, 32, st));
     return 0;
 }

@@ -9,6 +9,7 @@
 // depth-ordered Gaussian list is staged through LDS in 256-record batches (one 64-byte GeomRec gather per
 // lane); the per-pixel loop then reads each record as an LDS broadcast.
 #include "vcr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -310,12 +311,308 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(VcrRasterArgs a, con
     }
 }
 
+// ================= v2: one wave = one 8x8 quad, no LDS, no barriers =====================================
+// Each lane first acts as a CULLER for one Gaussian of the tile list (exact minimum of the conic form over
+// the quad's pixel rectangle against the alpha >= 1/255 threshold), a 64-bit ballot compacts the survivors,
+// and the wave then walks the set bits in depth order; the survivor's record is broadcast from its owner
+// lane with v_readlane (SGPR operands for the per-pixel VALU work).  The next 64 records are gathered from
+// HBM/L2 while the current survivors are shaded.
+
+__device__ __forceinline__ float bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ float edge_min(float a2, float c2, float b, float xe, float ic, float y0, float y1) {
+    // min over y in [y0,y1] of 0.5*(a2*xe^2... ) with a2=A, c2=C: Q = 0.5*A*xe^2 + B*xe*y + 0.5*C*y^2
+    const float ys = fminf(y1, fmaxf(y0, -b * xe * ic));
+    return 0.5f * a2 * xe * xe + b * xe * ys + 0.5f * c2 * ys * ys;
+}
+
+// Can this Gaussian reach alpha >= 1/255 at any pixel centre of the quad [X0,X0+7]x[Y0,Y0+7]?  Conservative.
+__device__ __forceinline__ bool quad_touch(const float4 q0, const float4 q1, float X0, float Y0) {
+    const float A = q1.x, B = q1.y, C = q1.z;
+    const float tau = __logf(255.f * q0.w);
+    if (!(tau >= 0.f)) return false;                      // opacity below 1/255 never contributes
+    if (!(A > 0.f) || !(C > 0.f)) return true;            // degenerate conic: leave it to the per-pixel test
+    const float x0 = X0 - q0.x, x1 = X0 + 7.f - q0.x, y0 = Y0 - q0.y, y1 = Y0 + 7.f - q0.y;
+    if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return true;
+    const float ia = 1.f / A, ic = 1.f / C;
+    float qm = edge_min(A, C, B, x0, ic, y0, y1);
+    qm = fminf(qm, edge_min(A, C, B, x1, ic, y0, y1));
+    qm = fminf(qm, edge_min(C, A, B, y0, ia, x0, x1));
+    qm = fminf(qm, edge_min(C, A, B, y1, ia, x0, x1));
+    const float mx = fmaxf(x0 * x0, x1 * x1), my = fmaxf(y0 * y0, y1 * y1);
+    return qm <= tau + 0.05f + 2e-6f * (A * mx + C * my);
+}
+
+// Two-stage software pipeline over 64-entry chunks of the tile list: the id of chunk k+2 is loaded while
+// the 64-byte records of chunk k+1 are gathered and chunk k is shaded.  Plain registers only (no structs), and
+// out-of-range lanes read record 0 (never used) so that no select-of-pointers / scratch is generated.
+#define VCR_LOAD_ID(POS, END, ID, VALID) \
+    do { const uint32_t _p = (POS); VALID = _p < (END); ID = VALID ? point_list[_p] : 0u; } while (0)
+#define VCR_GATHER_REC(ID, Q0, Q1, Q2, Q3)                                          \
+    do {                                                                            \
+        const float4* _src = reinterpret_cast<const float4*>(rec + (ID));           \
+        Q0 = _src[0]; Q1 = _src[1]; Q2 = _src[2]; Q3 = _src[3];                      \
+    } while (0)
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+template <int S, bool ISECT, int FC>
+__global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
+                                                               const float* __restrict__ semv,
+                                                               const uint32_t* __restrict__ point_list,
+                                                               const uint2* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ tile_order,
+                                                               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                               float* __restrict__ out, int32_t* __restrict__ count,
+                                                               float* __restrict__ score) {
+    const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    const PixelMap pm = pixel_of_thread(tile, gx, a.W, a.H);
+    const uint2 range = ranges[tile];
+    const int P = a.H * a.W;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8), Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8);
+    const float fx = (float)pm.x, fy = (float)pm.y;
+    float rx = 0.f, ry = 0.f, rz = 1.f;
+    if (ISECT && pm.inside) { rx = a.dirs[pm.pix]; ry = a.dirs[P + pm.pix]; rz = a.dirs[2 * P + pm.pix]; }
+
+    float T = 1.f;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, A = 0.f;
+    float SM[S > 0 ? S : 1];
+#pragma unroll
+    for (int k = 0; k < S; ++k) SM[k] = 0.f;
+    uint32_t last = 0;
+    bool done = !pm.inside;
+
+    uint32_t pos = range.x;
+    uint32_t id, nid; float4 q0, q1, q2, q3; bool valid, nvalid;
+    VCR_LOAD_ID(pos + lane, range.y, id, valid);
+    VCR_GATHER_REC(id, q0, q1, q2, q3);
+    VCR_LOAD_ID(pos + 64 + lane, range.y, nid, nvalid);
+    while (pos < range.y) {
+        uint32_t nnid; float4 nq0, nq1, nq2, nq3; bool nnvalid;
+        const uint32_t npos = pos + 64;
+        VCR_GATHER_REC(nid, nq0, nq1, nq2, nq3);                     // records of the next chunk
+        VCR_LOAD_ID(npos + 64 + lane, range.y, nnid, nnvalid);       // ids of the chunk after that
+        const bool keep = valid && quad_touch(q0, q1, X0, Y0);
+        unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const float gxp = bcast(q0.x, b), gyp = bcast(q0.y, b), op = bcast(q0.w, b);
+            const float ca = bcast(q1.x, b), cb = bcast(q1.y, b), cc = bcast(q1.z, b);
+            const float dx = gxp - fx, dy = gyp - fy;
+            const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+            const float alpha = fminf(VCR_ALPHA_MAX, op * __expf(power));
+            bool hit = !done && power <= 0.f && alpha >= VCR_ALPHA_MIN;
+            const float test_T = T * (1.f - alpha);
+            if (hit && test_T < VCR_T_EPS) { done = true; hit = false; }
+            const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+            if (hm == 0) {
+                if (__builtin_amdgcn_ballot_w64(!done) == 0) { m = 0; pos = range.y; }
+                continue;
+            }
+            const float w = hit ? alpha * T : 0.f;
+            if (FC != 0) {
+                const float ws = wave_sum(w);
+                if (lane == 0) {
+                    const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, b);
+                    atomicAdd(count + gid, (int)__popcll(hm));
+                    if (FC != 3) atomicAdd(score + gid, ws);
+                }
+            }
+            const float cr = bcast(q2.x, b), cg = bcast(q2.y, b), cbl = bcast(q2.z, b);
+            float dep = bcast(q0.z, b);
+            const float nx = bcast(q3.x, b), ny = bcast(q3.y, b), nz = bcast(q3.z, b);
+            if (ISECT) {
+                const float pl = bcast(q1.w, b);
+                const float den = nx * rx + ny * ry + nz * rz;
+                if (den > VCR_PLANE_EPS) dep = pl * fast_rcp(den) * rz;
+            }
+            C0 += w * cr; C1 += w * cg; C2 += w * cbl;
+            D += w * dep;
+            N0 += w * nx; N1 += w * ny; N2 += w * nz;
+            A += w;
+            if (S > 0) {
+                const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, b);
+#pragma unroll
+                for (int k = 0; k < S; ++k) SM[k] += w * semv[(size_t)gid * S + k];
+            }
+            if (hit) { T = test_T; last = pos - range.x + (uint32_t)b + 1u; }
+        }
+        if (pos >= range.y) break;
+        pos = npos; id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; valid = nvalid; nid = nnid; nvalid = nnvalid;
+    }
+    if (pm.inside) {
+        final_T[pm.pix] = T;
+        n_contrib[pm.pix] = last;
+        if (FC != 3) {
+            out[0 * (size_t)P + pm.pix] = C0 + T * a.bg[0];
+            out[1 * (size_t)P + pm.pix] = C1 + T * a.bg[1];
+            out[2 * (size_t)P + pm.pix] = C2 + T * a.bg[2];
+        }
+        if (FC == 0) {
+            out[3 * (size_t)P + pm.pix] = D;
+            out[4 * (size_t)P + pm.pix] = N0;
+            out[5 * (size_t)P + pm.pix] = N1;
+            out[6 * (size_t)P + pm.pix] = N2;
+            out[7 * (size_t)P + pm.pix] = A;
+#pragma unroll
+            for (int k = 0; k < S; ++k) out[(8 + k) * (size_t)P + pm.pix] = SM[k];
+        }
+    }
+}
+
+template <int S, bool ISECT>
+__global__ void __launch_bounds__(256) composite_bwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
+                                                               const float* __restrict__ semv,
+                                                               const uint32_t* __restrict__ point_list,
+                                                               const uint2* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ tile_order,
+                                                               const float* __restrict__ final_T,
+                                                               const uint32_t* __restrict__ n_contrib,
+                                                               const float* __restrict__ dL_dout, GradRec* __restrict__ sgrad,
+                                                               float* __restrict__ sgrad_sem) {
+    const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    const PixelMap pm = pixel_of_thread(tile, gx, a.W, a.H);
+    const uint2 range = ranges[tile];
+    const int P = a.H * a.W;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8), Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8);
+    const float fx = (float)pm.x, fy = (float)pm.y;
+    float rx = 0.f, ry = 0.f, rz = 1.f;
+    if (ISECT && pm.inside) { rx = a.dirs[pm.pix]; ry = a.dirs[P + pm.pix]; rz = a.dirs[2 * P + pm.pix]; }
+
+    float g[8 + (S > 0 ? S : 0)];
+#pragma unroll
+    for (int c = 0; c < 8 + S; ++c) g[c] = pm.inside ? dL_dout[c * (size_t)P + pm.pix] : 0.f;
+    const float Tf = pm.inside ? final_T[pm.pix] : 1.f;
+    const uint32_t lastc = pm.inside ? n_contrib[pm.pix] : 0u;
+    const float bgdot = Tf * (a.bg[0] * g[0] + a.bg[1] * g[1] + a.bg[2] * g[2]);
+    // deepest contributor of this quad (1-based index in the tile list)
+    uint32_t maxc = lastc;
+    for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, o));
+    if (maxc == 0) return;                                 // wave-uniform
+    float T = Tf, Asuf = 0.f;
+
+    int chunk = (int)((maxc - 1) / 64);                    // chunks of 64 list entries, walked back to front
+    uint32_t id, nid; float4 q0, q1, q2, q3; bool valid, nvalid;
+    const uint32_t lim = range.x + maxc;
+    VCR_LOAD_ID(range.x + (uint32_t)chunk * 64u + lane, lim, id, valid);
+    VCR_GATHER_REC(id, q0, q1, q2, q3);
+    VCR_LOAD_ID(chunk > 0 ? range.x + (uint32_t)(chunk - 1) * 64u + lane : lim, lim, nid, nvalid);
+    for (; chunk >= 0; --chunk) {
+        uint32_t nnid; float4 nq0, nq1, nq2, nq3; bool nnvalid;
+        VCR_GATHER_REC(nid, nq0, nq1, nq2, nq3);
+        VCR_LOAD_ID(chunk > 1 ? range.x + (uint32_t)(chunk - 2) * 64u + lane : lim, lim, nnid, nnvalid);
+        const bool keep = valid && quad_touch(q0, q1, X0, Y0);
+        unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        while (m) {
+            const int b = 63 - __builtin_clzll(m);
+            m &= ~(1ull << b);
+            const uint32_t idx1 = (uint32_t)chunk * 64u + (uint32_t)b + 1u;
+            const float gxp = bcast(q0.x, b), gyp = bcast(q0.y, b), op = bcast(q0.w, b);
+            const float ca = bcast(q1.x, b), cb = bcast(q1.y, b), cc = bcast(q1.z, b);
+            const float dx = gxp - fx, dy = gyp - fy;
+            const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+            const float G = __expf(power);
+            const float araw = op * G;
+            const float alpha = fminf(VCR_ALPHA_MAX, araw);
+            const bool hit = idx1 <= lastc && power <= 0.f && alpha >= VCR_ALPHA_MIN;
+            if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
+            const float cr = bcast(q2.x, b), cg = bcast(q2.y, b), cbl = bcast(q2.z, b);
+            const float zc = bcast(q0.z, b), pl = bcast(q1.w, b);
+            const float nx = bcast(q3.x, b), ny = bcast(q3.y, b), nz = bcast(q3.z, b);
+            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, b);
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = 0.f;
+            float vs[S > 0 ? S : 1];
+#pragma unroll
+            for (int k = 0; k < S; ++k) vs[k] = 0.f;
+            if (hit) {
+                const float inv1ma = fast_rcp(1.f - alpha);
+                T *= inv1ma;
+                const float w = alpha * T;
+                float dep = zc, den = 1.f, iden = 1.f;
+                bool isect = false;
+                if (ISECT) {
+                    den = nx * rx + ny * ry + nz * rz;
+                    isect = den > VCR_PLANE_EPS;
+                    iden = fast_rcp(den);
+                    if (isect) dep = pl * iden * rz;
+                }
+                float fg = cr * g[0] + cg * g[1] + cbl * g[2] + dep * g[3] + nx * g[4] + ny * g[5] + nz * g[6] + g[7];
+#pragma unroll
+                for (int k = 0; k < S; ++k) fg += semv[(size_t)gid * S + k] * g[8 + k];
+                const float dL_dalpha = T * fg - (Asuf + bgdot) * inv1ma;
+                Asuf += w * fg;
+                const float dL_dpow = araw * dL_dalpha;
+                const float gdx = -(ca * dx + cb * dy) * dL_dpow;
+                const float gdy = -(cc * dy + cb * dx) * dL_dpow;
+                v[0] = gdx; v[1] = gdy; v[2] = fabsf(gdx); v[3] = fabsf(gdy);
+                v[4] = -0.5f * dx * dx * dL_dpow; v[5] = -dx * dy * dL_dpow; v[6] = -0.5f * dy * dy * dL_dpow;
+                v[7] = G * dL_dalpha;
+                v[8] = w * g[0]; v[9] = w * g[1]; v[10] = w * g[2];
+                const float wd = w * g[3];
+                v[13] = w * g[4]; v[14] = w * g[5]; v[15] = w * g[6];
+                if (ISECT && isect) {
+                    const float k1 = wd * rz * iden;
+                    v[12] = k1;
+                    const float k2 = -k1 * pl * iden;
+                    v[13] += k2 * rx; v[14] += k2 * ry; v[15] += k2 * rz;
+                } else {
+                    v[11] = wd;
+                }
+#pragma unroll
+                for (int k = 0; k < S; ++k) vs[k] = w * g[8 + k];
+            }
+            float r4[4];
+            wave_reduce16(v, r4);
+            if ((lane & 15) < 4) {
+                const int sub = lane & 15;
+                const float val = sub == 0 ? r4[0] : (sub == 1 ? r4[1] : (sub == 2 ? r4[2] : r4[3]));
+                const int k = 8 * (lane >> 5) + 4 * ((lane >> 4) & 1) + sub;
+                if (val != 0.f) atomicAdd(reinterpret_cast<float*>(sgrad + gid) + k, val);
+            }
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                const float t = wave_sum(vs[k]);
+                if (lane == 0 && t != 0.f) atomicAdd(sgrad_sem + (size_t)gid * S + k, t);
+            }
+        }
+        id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; valid = nvalid; nid = nnid; nvalid = nnvalid;
+    }
+}
+
+// per-tile list length as a sort key (descending via bit inversion) for longest-first block scheduling
+__global__ void tile_len_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ keys,
+                                uint32_t* __restrict__ vals) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    keys[t] = ~(ranges[t].y - ranges[t].x);
+    vals[t] = (uint32_t)t;
+}
+
+bool use_v1() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VCR_COMPOSITE_V1"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 template <int S, bool ISECT>
 int launch_fwd_fc(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o, int tiles,
                   hipStream_t st) {
 #define VCR_FWD(FC)                                                                                               \
-    hipLaunchKernelGGL((composite_fwd_kernel<S, ISECT, FC>), dim3(tiles), dim3(256), 0, st, a, g.rec, g.sem,       \
-                       b.point_list, b.ranges, im.final_T, im.n_contrib, o.out, o.count, o.score)
+    if (use_v1())                                                                                                 \
+        hipLaunchKernelGGL((composite_fwd_kernel<S, ISECT, FC>), dim3(tiles), dim3(256), 0, st, a, g.rec, g.sem,   \
+                           b.point_list, b.ranges, im.final_T, im.n_contrib, o.out, o.count, o.score);            \
+    else                                                                                                          \
+        hipLaunchKernelGGL((composite_fwd_v2_kernel<S, ISECT, FC>), dim3(tiles), dim3(256), 0, st, a, g.rec, g.sem, \
+                           b.point_list, b.ranges, b.tile_order, im.final_T, im.n_contrib, o.out, o.count, o.score)
     switch (a.f_count) {
         case 0: VCR_FWD(0); break;
         case 1: case 2: VCR_FWD(1); break;
@@ -342,8 +639,12 @@ template <bool ISECT>
 int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, const float* dL_dout, GradRec* sgrad,
                  float* sgrad_sem, int tiles, hipStream_t st) {
 #define VCR_BWD(SS)                                                                                              \
-    hipLaunchKernelGGL((composite_bwd_kernel<SS, ISECT>), dim3(tiles), dim3(256), 0, st, a, g.rec, g.sem,         \
-                       b.point_list, b.ranges, im.final_T, im.n_contrib, dL_dout, sgrad, sgrad_sem)
+    if (use_v1())                                                                                                \
+        hipLaunchKernelGGL((composite_bwd_kernel<SS, ISECT>), dim3(tiles), dim3(256), 0, st, a, g.rec, g.sem,     \
+                           b.point_list, b.ranges, im.final_T, im.n_contrib, dL_dout, sgrad, sgrad_sem);         \
+    else                                                                                                         \
+        hipLaunchKernelGGL((composite_bwd_v2_kernel<SS, ISECT>), dim3(tiles), dim3(256), 0, st, a, g.rec, g.sem,  \
+                           b.point_list, b.ranges, b.tile_order, im.final_T, im.n_contrib, dL_dout, sgrad, sgrad_sem)
     switch (a.S) {
         case 0: VCR_BWD(0); break;
         case 1: VCR_BWD(1); break;
@@ -371,4 +672,10 @@ int vcr_launch_composite_backward(const VcrRasterArgs& a, GeomState g, BinState 
     const bool isect = a.dirs != nullptr && a.normals_precomp != nullptr;
     return isect ? launch_bwd_s<true>(a, g, b, im, dL_dout, sgrad, sgrad_sem, tiles, st)
                  : launch_bwd_s<false>(a, g, b, im, dL_dout, sgrad, sgrad_sem, tiles, st);
+}
+
+int vcr_launch_tile_len(int T, const uint2* ranges, uint32_t* keys, uint32_t* vals, hipStream_t st) {
+    hipLaunchKernelGGL(tile_len_kernel, dim3((T + 255) / 256), dim3(256), 0, st, T, ranges, keys, vals);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
 }

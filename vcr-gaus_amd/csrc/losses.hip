@@ -17,10 +17,33 @@ __device__ __forceinline__ float wave_sum(float x) {
     x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
     return x;
 }
-// one double atomic per wave: deterministic enough (fp64 accumulation) and cheap
-__device__ __forceinline__ void wave_accumulate(double* dst, float v) {
-    const float s = wave_sum(v);
-    if ((threadIdx.x & 63) == 0 && s != 0.f) atomicAdd(dst, (double)s);
+// Block-level sum, then ONE fp64 atomic per block into one of VCR_NSLOT slots (spread over L2 channels so the
+// atomics do not serialise on a single address); finalize_sums_kernel folds the slots in a fixed order.
+#define VCR_NSLOT 256
+template <int K>
+__device__ __forceinline__ void block_accumulate(double* __restrict__ slots, const float (&v)[K]) {
+    __shared__ float s_part[K][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float s = wave_sum(v[k]);
+        if (lane == 0) s_part[k][wv] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        const float t = s_part[threadIdx.x][0] + s_part[threadIdx.x][1] + s_part[threadIdx.x][2] + s_part[threadIdx.x][3];
+        const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (t != 0.f) atomicAdd(slots + (size_t)(b % VCR_NSLOT) * K + threadIdx.x, (double)t);
+    }
+}
+
+// sums layout: [K results][VCR_NSLOT x K slots]
+__global__ void finalize_sums_kernel(int K, double* __restrict__ sums) {
+    const int k = threadIdx.x;
+    if (k >= K) return;
+    double t = 0.0;
+    for (int s = 0; s < VCR_NSLOT; ++s) t += sums[K + (size_t)s * K + k];
+    sums[k] = t;
 }
 
 // ---------------- depth -> normal ----------------------------------------------------------------
@@ -166,9 +189,8 @@ __global__ void __launch_bounds__(256) normal_loss_fwd_kernel(int P, const float
         s1 += w * (1.f - (p0 * g0 + p1 * g1 + p2 * g2));
         cnt += 1.f;
     }
-    wave_accumulate(sums + 0, s0);
-    wave_accumulate(sums + 1, s1);
-    wave_accumulate(sums + 2, cnt);
+    const float v[3] = {s0, s1, cnt};
+    block_accumulate<3>(sums + 3, v);
 }
 
 // dpred = scale * w * (sign(p-g) - g); optionally dgt = scale * w * (-sign(p-g) - p) (consistency loss, both sides live)
@@ -267,8 +289,8 @@ __global__ void __launch_bounds__(256) l1_ssim_fwd_kernel(int H, int W, GaussWin
             part[o] = dS_dm1; part[3 * P + o] = dS_dq11; part[6 * P + o] = dS_dq12;
         }
     }
-    wave_accumulate(sums + 0, l1);
-    wave_accumulate(sums + 1, sv);
+    const float v[2] = {l1, sv};
+    block_accumulate<2>(sums + 2, v);
 }
 
 // dimg1(p) = gl1 * sign(a-b) + gss * sum_q w(q-p) [ dm1(q) + 2 a(p) dq11(q) + b(p) dq12(q) ]
@@ -358,10 +380,11 @@ extern "C" int vcr_normalize_chw_backward(int P, const float* in_chw, const floa
 
 extern "C" int vcr_normal_loss_forward(int P, const float* pred, const float* gt, const float* wsrc, float exp_t,
                                        const uint8_t* mask, double* sums3, void* stream) {
-    VCR_HIP_CHECK(hipMemsetAsync(sums3, 0, 3 * sizeof(double), (hipStream_t)stream));
+    VCR_HIP_CHECK(hipMemsetAsync(sums3, 0, 3 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
     const int blocks = min((P + 255) / 256, 2048);
     hipLaunchKernelGGL(normal_loss_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, pred, gt, wsrc, exp_t, mask,
                        sums3);
+    hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, 3, sums3);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -385,10 +408,11 @@ static GaussWin make_window() {
 
 extern "C" int vcr_l1_ssim_forward(int H, int W, const float* img1, const float* img2, double* sums2, float* partials9,
                                    void* stream) {
-    VCR_HIP_CHECK(hipMemsetAsync(sums2, 0, 2 * sizeof(double), (hipStream_t)stream));
+    VCR_HIP_CHECK(hipMemsetAsync(sums2, 0, 2 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
     const dim3 grid((W + SSIM_TX - 1) / SSIM_TX, (H + SSIM_TY - 1) / SSIM_TY, 3);
     hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, make_window(), img1, img2, sums2,
                        partials9);
+    hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, 2, sums2);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -401,3 +425,5 @@ extern "C" int vcr_l1_ssim_backward(int H, int W, const float* img1, const float
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+extern "C" int vcr_sums_elems(int k) { return k * (1 + VCR_NSLOT); }

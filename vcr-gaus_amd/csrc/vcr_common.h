@@ -61,14 +61,17 @@ struct GeomState {
 struct BinState {
     uint32_t* point_list;  // [R] Gaussian ids, (tile, depth, id)-ordered
     uint2* ranges;         // [T] per-tile [begin,end)
+    uint32_t* tile_order;  // [T] tile ids, longest list first (block scheduling order)
     static size_t bytes(int64_t R, int T) {
-        return vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1)) + vcr_align(sizeof(uint2) * (size_t)T);
+        return vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1)) + vcr_align(sizeof(uint2) * (size_t)T) +
+               vcr_align(sizeof(uint32_t) * (size_t)T);
     }
     static BinState view(void* p, int64_t R, int T) {
         BinState b;
         char* c = (char*)p;
         b.point_list = (uint32_t*)c;  c += vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1));
-        b.ranges = (uint2*)c;
+        b.ranges = (uint2*)c;         c += vcr_align(sizeof(uint2) * (size_t)T);
+        b.tile_order = (uint32_t*)c;
         return b;
     }
 };
@@ -124,8 +127,9 @@ int vcr_depth_sort_and_scan(int N, const uint32_t* depth_key, const uint32_t* id
                             size_t temp_bytes, hipStream_t st);
 int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const uint32_t* ids_sorted,
                            const uint32_t* offsets, int64_t R, int tile_bits, uint32_t* keys_a, uint32_t* vals_a,
-                           uint32_t* keys_b, uint32_t* point_list, uint2* ranges, int num_tiles, void* temp,
-                           size_t temp_bytes, hipStream_t st);
+                           uint32_t* keys_b, uint32_t* point_list, uint2* ranges, uint32_t* tile_order, int num_tiles,
+                           void* temp, size_t temp_bytes, hipStream_t st);
+int vcr_launch_tile_len(int T, const uint2* ranges, uint32_t* keys, uint32_t* vals, hipStream_t st);
 int vcr_launch_composite_forward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o,
                                  hipStream_t st);
 int vcr_launch_composite_backward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,

@@ -35,8 +35,9 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
     dev = pc.get_xyz.device
     screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True) + 0
     screenspace_points_densify = torch.zeros_like(pc.get_xyz, requires_grad=True) + 0
-    screenspace_points.retain_grad()
-    screenspace_points_densify.retain_grad()
+    if screenspace_points.requires_grad:           # not under no_grad (the reference guards with try/except)
+        screenspace_points.retain_grad()
+        screenspace_points_densify.retain_grad()
 
     rs = _settings(viewpoint_camera, pc, bg_color, scaling_modifier, cfg.pipline.debug, 0)
     rasterizer = GaussianRasterizer(raster_settings=rs)

@@ -14,13 +14,13 @@ class _L1SSIM(torch.autograd.Function):
         b = img2.detach().contiguous().float()
         C, H, W = a.shape
         assert C == 3, "l1_ssim expects [3,H,W] images"
-        sums = torch.empty(2, dtype=torch.float64, device=a.device)
+        sums = torch.empty(lib.vcr_sums_elems(2), dtype=torch.float64, device=a.device)
         need = img1.requires_grad
         part = torch.empty(9, H, W, dtype=torch.float32, device=a.device) if need else None
         _lib.check(lib.vcr_l1_ssim_forward(H, W, a.data_ptr(), b.data_ptr(), sums.data_ptr(),
                                            part.data_ptr() if need else None, _lib.stream_of(a)))
         ctx.save_for_backward(a, b, part)
-        res = (sums / (3.0 * H * W)).float()
+        res = (sums[:2] / (3.0 * H * W)).float()
         return res[0], res[1]
 
     @staticmethod
@@ -63,7 +63,7 @@ class _NormalLoss(torch.autograd.Function):
         w = None if wsrc is None else wsrc.detach().contiguous().float().view(-1, 3)
         m = None if mask is None else mask.detach().contiguous().view(-1).to(torch.uint8)
         P = p.shape[0]
-        sums = torch.empty(3, dtype=torch.float64, device=p.device)
+        sums = torch.empty(lib.vcr_sums_elems(3), dtype=torch.float64, device=p.device)
         _lib.check(lib.vcr_normal_loss_forward(P, p.data_ptr(), g.data_ptr(), None if w is None else w.data_ptr(),
                                                float(exp_t), None if m is None else m.data_ptr(), sums.data_ptr(),
                                                _lib.stream_of(p)))
