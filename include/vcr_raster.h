@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 1
+#define VCR_ABI_VERSION 2
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -47,7 +47,9 @@ typedef struct VcrRasterArgs {
     const float* projmatrix;    /* [4,4] full_proj_transform */
     const float* campos;        /* [3]  */
     const float* means3D;       /* [N,3] */
-    const float* shs;           /* [N,K,3] or NULL */
+    const float* shs;           /* [N,K,3] or NULL; with shs_rest: the DC coefficient only, [N,1,3] */
+    const float* shs_rest;      /* NULL, or [N,K-1,3]: the reference's split storage (_features_dc/_features_rest,
+                                   scene/gaussian_model.py:139-142) passed without the torch.cat of get_features */
     const float* colors_precomp;/* [N,3] or NULL (exactly one of shs/colors_precomp) */
     const float* normals_precomp;   /* [N,3] camera-space unit normals or NULL */
     const float* semantics_precomp; /* [N,S] or NULL */
@@ -85,7 +87,8 @@ typedef struct VcrBackwardIO {
     float* dL_dmeans3D;      /* [N,3] */
     float* dL_dmeans2D;      /* [N,3] (x,y in NDC units, z = 0) */
     float* dL_dmeans2D_densify; /* [N,3] sum over pixels of |per-pixel dL/dxy| (NDC units), or NULL */
-    float* dL_dshs;          /* [N,K,3] or NULL */
+    float* dL_dshs;          /* [N,K,3] (or [N,1,3] with dL_dshs_rest) or NULL */
+    float* dL_dshs_rest;     /* [N,K-1,3] when shs_rest was given, else NULL */
     float* dL_dcolors;       /* [N,3] or NULL */
     float* dL_dnormals;      /* [N,3] or NULL */
     float* dL_dsemantics;    /* [N,S] or NULL */

@@ -87,3 +87,25 @@ def test_empty_and_all_culled(device):
     assert int(radii.abs().sum()) == 0
     assert torch.allclose(out[:3].cpu(), bg[:, None, None].expand(3, 32, 48))
     assert float(out[3:].abs().max()) == 0.0
+
+
+def test_split_sh_storage_equals_combined(device):
+    """shs=_features_dc, shs_rest=_features_rest (no torch.cat) gives bit-identical renders and the same grads."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    cam, inp, dirs = util.make_case(3001, 96, 64, 80.0, seed=13, scale_mult=6.0)     # N not a multiple of 256
+    bg = torch.tensor([0.1, 0.2, 0.3], device=device)
+    s = util.settings_for(cam, bg, GaussianRasterizationSettings, device=device)
+    base = {k: (None if v is None else v.float().to(device)) for k, v in inp.items()}
+    outs, grads = [], []
+    for split in (False, True):
+        shs = base["shs"].clone().requires_grad_(True)
+        dc, rest = shs[:, :1].contiguous(), shs[:, 1:].contiguous()
+        kw = dict(shs=dc, shs_rest=rest) if split else dict(shs=shs)
+        xyz = base["means3D"].clone().requires_grad_(True)
+        out, _ = GaussianRasterizer(s)(means3D=xyz, means2D=torch.zeros_like(xyz), opacities=base["opac"],
+                                       scales=base["scales"], rotations=base["rots"], normals_precomp=base["normals"],
+                                       dirs=dirs.to(device), **kw)
+        out.square().sum().backward()
+        outs.append(out.detach()); grads.append((shs.grad.clone(), xyz.grad.clone()))
+    assert torch.equal(outs[0], outs[1])
+    assert util.rel_err(grads[1][0], grads[0][0]) < 1e-5 and util.rel_err(grads[1][1], grads[0][1]) < 1e-4

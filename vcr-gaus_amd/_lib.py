@@ -22,7 +22,7 @@ class VcrRasterArgs(C.Structure):
         ("sh_degree", C.c_int32), ("f_count", C.c_int32), ("num_dist", C.c_int32), ("debug", C.c_int32),
         ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
         ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
-        ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("means3D", C.c_void_p), ("shs", C.c_void_p), ("shs_rest", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("normals_precomp", C.c_void_p), ("semantics_precomp", C.c_void_p), ("opacities", C.c_void_p),
         ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("dirs", C.c_void_p),
     ]
@@ -41,7 +41,7 @@ class VcrBackwardIO(C.Structure):
         ("dL_dout", C.c_void_p), ("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p),
         ("radii", C.c_void_p), ("num_rendered", C.c_int64),
         ("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dmeans2D_densify", C.c_void_p),
-        ("dL_dshs", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_dnormals", C.c_void_p),
+        ("dL_dshs", C.c_void_p), ("dL_dshs_rest", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_dnormals", C.c_void_p),
         ("dL_dsemantics", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
         ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
     ]
@@ -94,7 +94,7 @@ def load():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.vcr_abi_version() != 1:
+    if lib.vcr_abi_version() != 2:
         raise ImportError("libvcr_raster.so ABI version mismatch")
     _lib = lib
     return lib

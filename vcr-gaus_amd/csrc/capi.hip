@@ -79,6 +79,7 @@ int validate(const VcrRasterArgs* a) {
     if (a->shs && (a->sh_degree < 0 || a->sh_degree > 3 || (a->sh_degree + 1) * (a->sh_degree + 1) > a->K)) {
         vcr_set_error("sh_degree=%d incompatible with K=%d", a->sh_degree, a->K); return 1;
     }
+    if (a->shs_rest && (!a->shs || a->K != 16)) { vcr_set_error("shs_rest needs shs (DC) and K=16"); return 1; }
     if (a->S > 0 && !a->semantics_precomp) { vcr_set_error("S>0 but semantics_precomp is NULL"); return 1; }
     if (!a->bg || !a->viewmatrix || !a->projmatrix || !a->campos || !a->means3D || !a->opacities) {
         vcr_set_error("required pointer is NULL"); return 1;
@@ -202,6 +203,7 @@ extern "C" int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* 
     if (!io->dL_dout || !io->geom || !io->binning || !io->image || !io->radii || !io->dL_dmeans3D || !io->dL_dmeans2D ||
         !io->dL_dopacities) { vcr_set_error("backward: required pointer is NULL"); return 1; }
     if (a.shs && !io->dL_dshs) { vcr_set_error("backward: dL_dshs is NULL"); return 1; }
+    if (a.shs_rest && !io->dL_dshs_rest) { vcr_set_error("backward: dL_dshs_rest is NULL"); return 1; }
     if (a.scales && (!io->dL_dscales || !io->dL_drotations)) { vcr_set_error("backward: dL_dscales/rotations NULL"); return 1; }
     if (a.cov3D_precomp && !io->dL_dcov3D) { vcr_set_error("backward: dL_dcov3D is NULL"); return 1; }
     const int gx = (a.W + VCR_TILE - 1) / VCR_TILE, gy = (a.H + VCR_TILE - 1) / VCR_TILE;

@@ -131,10 +131,73 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
+
+// ---- cooperative SH staging ------------------------------------------------------------------------------
+// A lane-per-Gaussian read of 48 consecutive floats is a 192-byte-stride access: every load instruction of
+// a wave touches 64 different lines and the 32 KiB L1 thrashes.  Instead the 256 Gaussians of a block are
+// streamed with fully coalesced 16-byte loads into LDS (row stride 49 dwords -> conflict-free per-lane rows)
+// and each lane then reads its own row.  Works for the combined [N,16,3] layout and for the reference's split
+// storage (_features_dc [N,1,3] + _features_rest [N,15,3]) so no torch.cat is needed.
+#define SH_ROW 49
+#define SH_K 16
+
+__device__ __forceinline__ void coop_copy_in(const float* __restrict__ src, int total, int per, int off, float* s) {
+    // src: `total` contiguous floats = rows of `per` floats; row g goes to s[g*SH_ROW + off ...]
+    const int n4 = (reinterpret_cast<uintptr_t>(src) & 15) ? 0 : (total >> 2);      // unaligned views: scalar path
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    for (int e4 = threadIdx.x; e4 < n4; e4 += 256) {
+        const float4 v = s4[e4];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = e4 * 4 + j, g = e / per;
+            s[g * SH_ROW + off + (e - g * per)] = vv[j];
+        }
+    }
+    for (int e = (n4 << 2) + threadIdx.x; e < total; e += 256) {
+        const int g = e / per;
+        s[g * SH_ROW + off + (e - g * per)] = src[e];
+    }
+}
+
+__device__ __forceinline__ void coop_copy_out(float* __restrict__ dst, int total, int per, int off, const float* s) {
+    const int n4 = (reinterpret_cast<uintptr_t>(dst) & 15) ? 0 : (total >> 2);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int e4 = threadIdx.x; e4 < n4; e4 += 256) {
+        float vv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = e4 * 4 + j, g = e / per;
+            vv[j] = s[g * SH_ROW + off + (e - g * per)];
+        }
+        d4[e4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
+    for (int e = (n4 << 2) + threadIdx.x; e < total; e += 256) {
+        const int g = e / per;
+        dst[e] = s[g * SH_ROW + off + (e - g * per)];
+    }
+}
+
+__device__ __forceinline__ void stage_sh_in(const VcrRasterArgs& a, int base, int cnt, float* s) {
+    if (a.shs_rest) {
+        coop_copy_in(a.shs + (size_t)base * 3, cnt * 3, 3, 0, s);
+        coop_copy_in(a.shs_rest + (size_t)base * 45, cnt * 45, 45, 3, s);
+    } else {
+        coop_copy_in(a.shs + (size_t)base * 48, cnt * 48, 48, 0, s);
+    }
+}
+
+template <bool STAGE>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, GeomState g, int32_t* __restrict__ radii,
                                                              uint32_t* __restrict__ depth_key,
                                                              uint32_t* __restrict__ ids) {
+    extern __shared__ __attribute__((aligned(16))) float s_sh[];
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (STAGE) {
+        const int base = blockIdx.x * 256;
+        stage_sh_in(a, base, min(256, a.N - base), s_sh);
+        __syncthreads();
+    }
     if (i >= a.N) return;
     ids[i] = i;
     radii[i] = 0;
@@ -190,7 +253,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
         dx *= il; dy *= il; dz *= il;
         float b[16];
         sh_basis<false>(a.sh_degree, dx, dy, dz, b, nullptr, nullptr, nullptr);
-        const float* sh = a.shs + (size_t)i * a.K * 3;
+        const float* sh = STAGE ? (s_sh + threadIdx.x * SH_ROW) : (a.shs + (size_t)i * a.K * 3);
         const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
         float c0 = 0.5f, c1 = 0.5f, c2 = 0.5f;
 #pragma unroll
@@ -224,13 +287,21 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
     depth_key[i] = __float_as_uint(pr.t[2]);
 }
 
+template <bool STAGE>
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, GeomState g, const int32_t* __restrict__ radii,
                                                              const GradRec* __restrict__ sgrad,
                                                              const float* __restrict__ sgrad_sem, VcrBackwardIO io) {
+    extern __shared__ __attribute__((aligned(16))) float s_sh[];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.N) return;
-    const size_t i3 = 3 * (size_t)i;
-    const bool vis = radii[i] > 0;
+    const int blk_base = blockIdx.x * 256, blk_cnt = min(256, a.N - blk_base);
+    if (STAGE) {
+        stage_sh_in(a, blk_base, blk_cnt, s_sh);
+        __syncthreads();
+    }
+    const bool live = i < a.N;
+    const size_t i3 = 3 * (size_t)(live ? i : 0);
+    const bool vis = live && radii[i] > 0;
+    if (!STAGE && !live) return;
     const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
 
     float dp[3] = {0.f, 0.f, 0.f};                 // dL/dmeans3D
@@ -327,8 +398,9 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
             dx *= il; dy *= il; dz *= il;
             float b[16], bx[16], by[16], bz[16];
             sh_basis<true>(a.sh_degree, dx, dy, dz, b, bx, by, bz);
-            const float* sh = a.shs + (size_t)i * a.K * 3;
-            float* dsh = io.dL_dshs + (size_t)i * a.K * 3;
+            float* shrow = STAGE ? (s_sh + threadIdx.x * SH_ROW) : nullptr;     // own row: read, then overwritten
+            const float* sh = STAGE ? shrow : (a.shs + (size_t)i * a.K * 3);
+            float* dsh = STAGE ? shrow : (io.dL_dshs + (size_t)i * a.K * 3);
             float ddx = 0.f, ddy = 0.f, ddz = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -366,9 +438,19 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
             dq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
             dsc[0] *= a.scale_modifier; dsc[1] *= a.scale_modifier; dsc[2] *= a.scale_modifier;
         }
-    } else if (io.dL_dshs) {
-        float* dsh = io.dL_dshs + (size_t)i * a.K * 3;
+    } else if (io.dL_dshs && (STAGE || live)) {
+        float* dsh = STAGE ? (s_sh + threadIdx.x * SH_ROW) : (io.dL_dshs + (size_t)i * a.K * 3);
         for (int k = 0; k < a.K * 3; ++k) dsh[k] = 0.f;
+    }
+    if (STAGE) {                               // coalesced write-back of the block's SH gradients
+        __syncthreads();
+        if (io.dL_dshs_rest) {
+            coop_copy_out(io.dL_dshs + (size_t)blk_base * 3, blk_cnt * 3, 3, 0, s_sh);
+            coop_copy_out(io.dL_dshs_rest + (size_t)blk_base * 45, blk_cnt * 45, 45, 3, s_sh);
+        } else {
+            coop_copy_out(io.dL_dshs + (size_t)blk_base * 48, blk_cnt * 48, 48, 0, s_sh);
+        }
+        if (!live) return;
     }
 
     io.dL_dmeans3D[i3] = dp[0]; io.dL_dmeans3D[i3 + 1] = dp[1]; io.dL_dmeans3D[i3 + 2] = dp[2];
@@ -398,7 +480,11 @@ int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, u
                           hipStream_t st) {
     if (a.N == 0) return 0;
     const int blocks = (a.N + 255) / 256;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, st, a, g, radii, depth_key, ids);
+    if (a.shs && a.K == SH_K)
+        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(blocks), dim3(256), 256 * SH_ROW * sizeof(float), st, a, g, radii,
+                           depth_key, ids);
+    else
+        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(blocks), dim3(256), 0, st, a, g, radii, depth_key, ids);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -407,7 +493,11 @@ int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const in
                                    const float* sgrad_sem, VcrBackwardIO& io, hipStream_t st) {
     if (a.N == 0) return 0;
     const int blocks = (a.N + 255) / 256;
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(blocks), dim3(256), 0, st, a, g, radii, sgrad, sgrad_sem, io);
+    if (a.shs && a.K == SH_K)
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(256), 256 * SH_ROW * sizeof(float), st, a, g, radii,
+                           sgrad, sgrad_sem, io);
+    else
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(blocks), dim3(256), 0, st, a, g, radii, sgrad, sgrad_sem, io);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }

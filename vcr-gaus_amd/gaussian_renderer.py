@@ -49,13 +49,16 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
     if cfg.pipline.compute_cov3D_python:
         cov3D_precomp, scales, rotations = pc.get_covariance(scaling_modifier), None, None
 
-    shs, colors_precomp = (pc.get_features, None) if override_color is None else (None, override_color)
+    # SH coefficients go to the kernel in the model's split storage (no torch.cat of get_features)
+    shs, shs_rest, colors_precomp = (pc._features_dc, pc._features_rest, None) if override_color is None \
+        else (None, None, override_color)
     sem_feats = pc.get_objects.squeeze(1) if cfg.optim.loss_weight.semantic > 0 else None
 
     rendered_out, radii = rasterizer(
         means3D=pc.get_xyz, means2D=screenspace_points, means2D_densify=screenspace_points_densify, shs=shs,
         colors_precomp=colors_precomp, normals_precomp=normals_precomp, semantics_precomp=sem_feats,
-        opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, dirs=dirs, inside=None)
+        opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, dirs=dirs, inside=None,
+        shs_rest=shs_rest)
 
     rendered_image, rendered_depth, rendered_normal, rendered_alpha = rendered_out[:8].split([3, 1, 3, 1], dim=0)
     with torch.no_grad():
@@ -86,11 +89,12 @@ def _forward_only(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, overri
     with torch.no_grad():
         scales, rotations, opacity = fused_activate(pc, viewpoint_camera.camera_center,
                                                     _cam_rotation(viewpoint_camera, dev), False)
-    shs, colors = (pc.get_features, None) if override_color is None else (None, override_color)
+    shs, shs_rest, colors = (pc._features_dc, pc._features_rest, None) if override_color is None \
+        else (None, None, override_color)
     screenspace_points = torch.zeros_like(pc.get_xyz)
     res = rasterizer(means3D=pc.get_xyz, means2D=screenspace_points, means2D_densify=None, shs=shs,
                      colors_precomp=colors, normals_precomp=None, semantics_precomp=None, opacities=opacity,
-                     scales=scales, rotations=rotations, cov3D_precomp=None)
+                     scales=scales, rotations=rotations, cov3D_precomp=None, shs_rest=shs_rest)
     return res, screenspace_points
 
 

@@ -66,25 +66,25 @@ last_stats = {}   # R / V of the most recent forward (for benchmarks; not part o
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, means2D_densify, sh, colors_precomp, normals_precomp,
-                semantics_precomp, opacities, scales, rotations, cov3Ds_precomp, dirs, rs):
+                semantics_precomp, opacities, scales, rotations, cov3Ds_precomp, dirs, rs, sh_rest=None):
         lib = _lib.load()
         dev = means3D.device
         if dev.type != "cuda":
             raise RuntimeError("vcr_raster: tensors must live on a HIP device (no CPU path exists)")
         N = means3D.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
-        t = dict(means3D=_f32(means3D), shs=_f32(sh), colors=_f32(colors_precomp), normals=_f32(normals_precomp),
+        t = dict(means3D=_f32(means3D), shs=_f32(sh), shs_rest=_f32(sh_rest), colors=_f32(colors_precomp), normals=_f32(normals_precomp),
                  sem=_f32(semantics_precomp), opac=_f32(opacities), scales=_f32(scales), rots=_f32(rotations),
                  cov=_f32(cov3Ds_precomp), dirs=_f32(dirs), bg=_f32(rs.bg).to(dev), view=_f32(rs.viewmatrix).to(dev),
                  proj=_f32(rs.projmatrix).to(dev), campos=_f32(rs.campos).to(dev))
         S = 0 if t["sem"] is None else int(t["sem"].shape[1])
-        K = 0 if t["shs"] is None else int(t["shs"].shape[1])
+        K = 0 if t["shs"] is None else int(t["shs"].shape[1]) + (0 if t["shs_rest"] is None else int(t["shs_rest"].shape[1]))
         a = _lib.VcrRasterArgs(N=N, H=H, W=W, S=S, K=K, sh_degree=int(rs.sh_degree), f_count=int(rs.f_count),
                                num_dist=0, debug=int(bool(rs.debug)), tanfovx=float(rs.tanfovx),
                                tanfovy=float(rs.tanfovy), scale_modifier=float(rs.scale_modifier),
                                bg=_ptr(t["bg"]), viewmatrix=_ptr(t["view"]), projmatrix=_ptr(t["proj"]),
                                campos=_ptr(t["campos"]), means3D=_ptr(t["means3D"]), shs=_ptr(t["shs"]),
-                               colors_precomp=_ptr(t["colors"]), normals_precomp=_ptr(t["normals"]),
+                               shs_rest=_ptr(t["shs_rest"]), colors_precomp=_ptr(t["colors"]), normals_precomp=_ptr(t["normals"]),
                                semantics_precomp=_ptr(t["sem"]), opacities=_ptr(t["opac"]), scales=_ptr(t["scales"]),
                                rotations=_ptr(t["rots"]), cov3D_precomp=_ptr(t["cov"]), dirs=_ptr(t["dirs"]))
         fc = int(rs.f_count)
@@ -119,12 +119,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         N = t["means3D"].shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
         S = 0 if t["sem"] is None else int(t["sem"].shape[1])
-        K = 0 if t["shs"] is None else int(t["shs"].shape[1])
+        K = 0 if t["shs"] is None else int(t["shs"].shape[1]) + (0 if t["shs_rest"] is None else int(t["shs_rest"].shape[1]))
         a = _lib.VcrRasterArgs(N=N, H=H, W=W, S=S, K=K, sh_degree=int(rs.sh_degree), f_count=0, num_dist=0,
                                debug=int(bool(rs.debug)), tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy),
                                scale_modifier=float(rs.scale_modifier), bg=_ptr(t["bg"]), viewmatrix=_ptr(t["view"]),
                                projmatrix=_ptr(t["proj"]), campos=_ptr(t["campos"]), means3D=_ptr(t["means3D"]),
-                               shs=_ptr(t["shs"]), colors_precomp=_ptr(t["colors"]), normals_precomp=_ptr(t["normals"]),
+                               shs=_ptr(t["shs"]), shs_rest=_ptr(t["shs_rest"]), colors_precomp=_ptr(t["colors"]), normals_precomp=_ptr(t["normals"]),
                                semantics_precomp=_ptr(t["sem"]), opacities=_ptr(t["opac"]), scales=_ptr(t["scales"]),
                                rotations=_ptr(t["rots"]), cov3D_precomp=_ptr(t["cov"]), dirs=_ptr(t["dirs"]))
         g = grad_out.contiguous().float()
@@ -134,7 +134,8 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         d_means3D, d_means2D, d_opac = new(N, 3), new(N, 3), new(N, 1)
         d_dens = new(N, 3) if ctx.has else None
-        d_shs = new(N, K, 3) if t["shs"] is not None else None
+        d_shs = new(*t["shs"].shape) if t["shs"] is not None else None
+        d_shr = new(*t["shs_rest"].shape) if t["shs_rest"] is not None else None
         d_col = new(N, 3) if t["colors"] is not None else None
         d_nrm = new(N, 3) if t["normals"] is not None else None
         d_sem = new(N, S) if t["sem"] is not None else None
@@ -145,14 +146,14 @@ class _RasterizeGaussians(torch.autograd.Function):
                                 binning=_ptr(ctx.state[_lib.BUF_BINNING]), image=_ptr(ctx.state[_lib.BUF_IMAGE]),
                                 radii=_ptr(radii), num_rendered=ctx.num_rendered, dL_dmeans3D=_ptr(d_means3D),
                                 dL_dmeans2D=_ptr(d_means2D), dL_dmeans2D_densify=_ptr(d_dens), dL_dshs=_ptr(d_shs),
-                                dL_dcolors=_ptr(d_col), dL_dnormals=_ptr(d_nrm), dL_dsemantics=_ptr(d_sem),
+                                dL_dshs_rest=_ptr(d_shr), dL_dcolors=_ptr(d_col), dL_dnormals=_ptr(d_nrm), dL_dsemantics=_ptr(d_sem),
                                 dL_dopacities=_ptr(d_opac), dL_dscales=_ptr(d_sc), dL_drotations=_ptr(d_rot),
                                 dL_dcov3D=_ptr(d_cov))
         al = _Allocator(dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _check(lib.vcr_rasterize_backward(a, io, al.cb, None, stream))
-        return (d_means3D, d_means2D, d_dens, d_shs, d_col, d_nrm, d_sem, d_opac, d_sc, d_rot, d_cov, None, None)
+        return (d_means3D, d_means2D, d_dens, d_shs, d_col, d_nrm, d_sem, d_opac, d_sc, d_rot, d_cov, None, None, d_shr)
 
 
 class GaussianRasterizer(nn.Module):
@@ -162,7 +163,9 @@ class GaussianRasterizer(nn.Module):
 
     def forward(self, means3D, means2D, opacities, means2D_densify=None, shs=None, colors_precomp=None,
                 normals_precomp=None, semantics_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
-                dirs=None, inside=None):
+                dirs=None, inside=None, shs_rest=None):
+        """`shs_rest` (extension): pass the reference's split SH storage as shs=_features_dc [N,1,3],
+        shs_rest=_features_rest [N,15,3] and skip the torch.cat of `get_features`."""
         rs = self.raster_settings
         if (shs is None) == (colors_precomp is None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
@@ -170,4 +173,4 @@ class GaussianRasterizer(nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         return _RasterizeGaussians.apply(means3D, means2D, means2D_densify, shs, colors_precomp, normals_precomp,
-                                         semantics_precomp, opacities, scales, rotations, cov3D_precomp, dirs, rs)
+                                         semantics_precomp, opacities, scales, rotations, cov3D_precomp, dirs, rs, shs_rest)
