@@ -106,9 +106,9 @@ def test_fused_activation_and_camera_normals(device):
 def test_fused_adam_matches_torch(device):
     from vcr_gaus_amd.gaussian_model import FusedAdam
     g = torch.Generator().manual_seed(3)
-    shapes = [(1000, 3), (1000, 1, 3), (1000, 15, 3), (1000, 1), (1000, 4)]
+    shapes = [(1001, 3), (1001, 1, 3), (1001, 15, 3), (1001, 1), (1001, 4)]
     lrs = [1.6e-4, 2.5e-3, 1.25e-4, 0.05, 1e-3]
-    ps = [torch.randn(s, generator=g) for s in shapes]
+    ps = [torch.randn(s, generator=g) for s in shapes]  # 1001: exercises the scalar tails
     tp = [torch.nn.Parameter(p.clone().to(device)) for p in ps]
     hp = [torch.nn.Parameter(p.clone().to(device)) for p in ps]
     topt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(tp, lrs)], lr=0.0, eps=1e-15)

@@ -98,11 +98,14 @@ __global__ void __launch_bounds__(256) activate_bwd_kernel(int N, const float* _
 #define VCR_ADAM_MAX 8
 struct AdamPack {
     float* p[VCR_ADAM_MAX]; const float* g[VCR_ADAM_MAX]; float* m[VCR_ADAM_MAX]; float* v[VCR_ADAM_MAX];
-    long long start[VCR_ADAM_MAX + 1];       // prefix of element counts
+    long long start[VCR_ADAM_MAX + 1];       // prefix of float4-group counts
     float lr[VCR_ADAM_MAX];
+    int tail[VCR_ADAM_MAX];                  // numel % 4
     int n;
 };
 
+// Each thread owns 4 consecutive elements (16-byte loads/stores); `start` counts float4 groups per tensor
+// (tensor sizes are padded up to a multiple of 4 by the host wrapper through a scalar tail launch).
 __global__ void __launch_bounds__(256) adam_kernel(AdamPack pk, float b1, float b2, float eps, float bc1, float bc2_sqrt,
                                                    float gscale) {
     const long long total = pk.start[pk.n];
@@ -111,13 +114,37 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamPack pk, float b1, float 
 #pragma unroll
         for (int k = 1; k < VCR_ADAM_MAX; ++k) if (k < pk.n && i >= pk.start[k]) t = k;
         const long long j = i - pk.start[t];
-        const float g = pk.g[t][j] * gscale;
-        const float m = b1 * pk.m[t][j] + (1.f - b1) * g;
-        const float v = b2 * pk.v[t][j] + (1.f - b2) * g * g;
-        pk.m[t][j] = m; pk.v[t][j] = v;
-        const float denom = sqrtf(v) / bc2_sqrt + eps;
-        pk.p[t][j] -= (pk.lr[t] / bc1) * (m / denom);
+        const float4 g4 = reinterpret_cast<const float4*>(pk.g[t])[j];
+        float4 m4 = reinterpret_cast<float4*>(pk.m[t])[j];
+        float4 v4 = reinterpret_cast<float4*>(pk.v[t])[j];
+        float4 p4 = reinterpret_cast<float4*>(pk.p[t])[j];
+        const float step = pk.lr[t] / bc1;
+        const float gg[4] = {g4.x * gscale, g4.y * gscale, g4.z * gscale, g4.w * gscale};
+        float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            mm[c] = b1 * mm[c] + (1.f - b1) * gg[c];
+            vv[c] = b2 * vv[c] + (1.f - b2) * gg[c] * gg[c];
+            pp[c] -= step * (mm[c] / (sqrtf(vv[c]) / bc2_sqrt + eps));
+        }
+        reinterpret_cast<float4*>(pk.m[t])[j] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        reinterpret_cast<float4*>(pk.v[t])[j] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        reinterpret_cast<float4*>(pk.p[t])[j] = make_float4(pp[0], pp[1], pp[2], pp[3]);
     }
+}
+
+// scalar tails (numel % 4 elements per tensor)
+__global__ void adam_tail_kernel(AdamPack pk, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+    const int t = blockIdx.x;
+    const long long n4 = pk.start[t + 1] - pk.start[t];
+    const int tail = (int)pk.tail[t];
+    if ((int)threadIdx.x >= tail) return;
+    const long long j = n4 * 4 + threadIdx.x;
+    const float g = pk.g[t][j] * gscale;
+    const float m = b1 * pk.m[t][j] + (1.f - b1) * g;
+    const float v = b2 * pk.v[t][j] + (1.f - b2) * g * g;
+    pk.m[t][j] = m; pk.v[t][j] = v;
+    pk.p[t][j] -= (pk.lr[t] / bc1) * (m / (sqrtf(v) / bc2_sqrt + eps));
 }
 
 // xyz_gradient_accum[vis] += ||grad[:, :2]||, denom[vis] += 1, max_radii2D[vis] = max(., radii)
@@ -164,20 +191,31 @@ extern "C" int vcr_adam_step(int ntensors, float* const* params, const float* co
     if (ntensors <= 0) return 0;
     if (ntensors > VCR_ADAM_MAX) { vcr_set_error("vcr_adam_step: at most %d tensors per call", VCR_ADAM_MAX); return 1; }
     AdamPack pk;
+    bool any_tail = false;
     pk.n = ntensors;
     pk.start[0] = 0;
     for (int k = 0; k < ntensors; ++k) {
         pk.p[k] = params[k]; pk.g[k] = grads[k]; pk.m[k] = exp_avg[k]; pk.v[k] = exp_avg_sq[k];
         pk.lr[k] = lr[k];
-        pk.start[k + 1] = pk.start[k] + numel[k];
+        pk.start[k + 1] = pk.start[k] + numel[k] / 4;
+        pk.tail[k] = (int)(numel[k] % 4);
+        any_tail |= pk.tail[k] != 0;
+        if ((((uintptr_t)params[k]) | ((uintptr_t)grads[k]) | ((uintptr_t)exp_avg[k]) | ((uintptr_t)exp_avg_sq[k])) & 15) {
+            vcr_set_error("vcr_adam_step: tensor %d is not 16-byte aligned", k);
+            return 1;
+        }
     }
-    for (int k = ntensors; k < VCR_ADAM_MAX; ++k) { pk.p[k] = nullptr; pk.g[k] = nullptr; pk.m[k] = nullptr; pk.v[k] = nullptr; pk.lr[k] = 0.f; pk.start[k + 1] = pk.start[ntensors]; }
+    for (int k = ntensors; k < VCR_ADAM_MAX; ++k) { pk.p[k] = nullptr; pk.g[k] = nullptr; pk.m[k] = nullptr; pk.v[k] = nullptr; pk.lr[k] = 0.f; pk.tail[k] = 0; pk.start[k + 1] = pk.start[ntensors]; }
     const long long total = pk.start[ntensors];
-    if (total == 0) return 0;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pk, beta1, beta2, eps, (float)bc1,
-                       (float)sqrt(bc2), grad_scale);
+    if (total > 0) {
+        const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pk, beta1, beta2, eps, (float)bc1,
+                           (float)sqrt(bc2), grad_scale);
+    }
+    if (any_tail)
+        hipLaunchKernelGGL(adam_tail_kernel, dim3(ntensors), dim3(64), 0, (hipStream_t)stream, pk, beta1, beta2, eps,
+                           (float)bc1, (float)sqrt(bc2), grad_scale);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
