@@ -224,7 +224,7 @@ def bin_and_sort(pre):
     return owner, beg, end, R
 
 
-def composite_tile(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem):
+def composite_tile(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem, num_dist=0):
     """K6 for one 16x16 tile, vectorised over [pixels, list]."""
     dt = pre["px"].dtype
     H, W = s.image_height, s.image_width
@@ -233,7 +233,7 @@ def composite_tile(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem):
     xs, ys = xs.reshape(-1), ys.reshape(-1)
     npix = xs.numel()
     L = idx.numel()
-    C = 8 + num_sem
+    C = 8 + num_sem + num_dist
     if L == 0:
         out = torch.zeros(npix, C, dtype=dt)
         Tfin = torch.ones(npix, dtype=dt)
@@ -280,6 +280,8 @@ def composite_tile(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem):
     outs = [out_rgb, out_d, out_n, out_a]
     if num_sem:
         outs.append(wgt @ pre["sem"][idx].to(dt))
+    if num_dist == 2:                                  # depth moments (gaussian_renderer/__init__.py:155-157)
+        outs += [out_d, (wgt * dep * dep).sum(1, keepdim=True)]
     out = torch.cat(outs, 1)
     return xs, ys, out, Tfin, contrib, wgt
 
@@ -287,7 +289,7 @@ def composite_tile(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem):
 def rasterize(s: Settings, means3D, means2D=None, means2D_densify=None, shs=None,
               colors_precomp=None, normals_precomp=None, semantics_precomp=None, opacities=None,
               scales=None, rotations=None, cov3D_precomp=None, dirs=None, inside=None, tile_stride=1,
-              timings=None):
+              timings=None, num_dist=0):
     """Full forward (tile_stride>1 composites only every k-th tile: bounded CPU-baseline sample).  f_count==0: (out[C,H,W], radii).  f_count==1/2: (count, score, image, radii).
     f_count==3: (count, radii).  C = 8 + S (colour3, depth1, normal3, alpha1, sem S)."""
     dt = means3D.dtype
@@ -303,7 +305,7 @@ def rasterize(s: Settings, means3D, means2D=None, means2D_densify=None, shs=None
     owner, beg, end, R = bin_and_sort(pre)
     _t1 = _time.perf_counter()
     gx, gy = pre["grid"]
-    C = 8 + num_sem
+    C = 8 + num_sem + num_dist
     img = torch.zeros(H, W, C, dtype=dt)
     Tmap = torch.ones(H, W, dtype=dt)
     count = torch.zeros(N, dtype=torch.int32)
@@ -316,7 +318,7 @@ def rasterize(s: Settings, means3D, means2D=None, means2D_densify=None, shs=None
                 continue
             idx = owner[beg[t]:end[t]]
             xs, ys, out, Tfin, contrib, wgt = composite_tile(
-                s, pre, idx, tx * TILE, ty * TILE, means2D_densify, dirs, num_sem)
+                s, pre, idx, tx * TILE, ty * TILE, means2D_densify, dirs, num_sem, num_dist)
             rows.append(ys); cols.append(xs); vals.append(out); tvals.append(Tfin)
             if s.f_count and contrib is not None:
                 count.index_add_(0, idx, contrib.sum(0).to(torch.int32))

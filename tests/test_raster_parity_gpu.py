@@ -109,3 +109,22 @@ def test_split_sh_storage_equals_combined(device):
         outs.append(out.detach()); grads.append((shs.grad.clone(), xyz.grad.clone()))
     assert torch.equal(outs[0], outs[1])
     assert util.rel_err(grads[1][0], grads[0][0]) < 1e-5 and util.rel_err(grads[1][1], grads[0][1]) < 1e-4
+
+
+def test_depth_moment_channels_forward_backward(device):
+    """num_dist=2 (the fork's NUM_DIST trailing channels used by depth_var): sum w d and sum w d^2."""
+    cam, inp, dirs = util.make_case(2500, 96, 64, 80.0, seed=21, scale_mult=6.0)
+    bg = torch.tensor([0.2, 0.1, 0.4])
+    (ref, _, _), rl = util.oracle_forward(cam, inp, dirs, bg, dtype=torch.float64, requires_grad=True, num_dist=2)
+    assert ref.shape[0] == 10
+    g = torch.Generator().manual_seed(5)
+    wgt = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    (ref * wgt).sum().backward()
+    (out, _), hl = util.hip_forward(cam, inp, dirs, bg, device, requires_grad=True, num_dist=2)
+    assert out.shape == ref.shape
+    assert util.frac_bad(out, ref, 1e-4, 2e-4) < 1e-4
+    assert torch.equal(out[8], out[3])
+    (out * wgt.float().to(device)).sum().backward()
+    for k in ["means3D", "normals", "opac", "scales", "rots", "shs"]:
+        e = util.rel_err(hl[k].grad, rl[k].grad)
+        assert e < 5e-4, f"grad {k}: rel err {e}"

@@ -32,7 +32,7 @@ def settings_for(cam, bg, cls, sh_degree=3, f_count=0, device=None):
 
 
 def oracle_forward(cam, inp, dirs, bg, dtype=torch.float64, requires_grad=False, sh_degree=3, f_count=0,
-                   use_normals=True):
+                   use_normals=True, num_dist=0):
     s = settings_for(cam, bg, OR.Settings, sh_degree=sh_degree, f_count=f_count)
     leaf = {}
     for k, v in inp.items():
@@ -45,11 +45,11 @@ def oracle_forward(cam, inp, dirs, bg, dtype=torch.float64, requires_grad=False,
     leaf["m2d"] = torch.zeros(N, 3, dtype=dtype, requires_grad=requires_grad)
     res = OR.rasterize(s, leaf["means3D"], leaf["m2"], leaf["m2d"], leaf["shs"], None,
                        leaf["normals"] if use_normals else None, leaf["sem"], leaf["opac"], leaf["scales"],
-                       leaf["rots"], None, dirs if use_normals else None)
+                       leaf["rots"], None, dirs if use_normals else None, num_dist=num_dist)
     return res, leaf
 
 
-def hip_forward(cam, inp, dirs, bg, device, requires_grad=False, sh_degree=3, f_count=0, use_normals=True):
+def hip_forward(cam, inp, dirs, bg, device, requires_grad=False, sh_degree=3, f_count=0, use_normals=True, num_dist=0):
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     s = settings_for(cam, bg, GaussianRasterizationSettings, sh_degree=sh_degree, f_count=f_count, device=device)
     leaf = {}
@@ -58,7 +58,7 @@ def hip_forward(cam, inp, dirs, bg, device, requires_grad=False, sh_degree=3, f_
     N = inp["means3D"].shape[0]
     leaf["m2"] = torch.zeros(N, 3, device=device, requires_grad=requires_grad)
     leaf["m2d"] = torch.zeros(N, 3, device=device, requires_grad=requires_grad)
-    rast = GaussianRasterizer(raster_settings=s)
+    rast = GaussianRasterizer(raster_settings=s, num_dist=num_dist)
     res = rast(means3D=leaf["means3D"], means2D=leaf["m2"], means2D_densify=leaf["m2d"] if f_count == 0 else None,
                shs=leaf["shs"], colors_precomp=None, normals_precomp=leaf["normals"] if use_normals else None,
                semantics_precomp=leaf["sem"], opacities=leaf["opac"], scales=leaf["scales"], rotations=leaf["rots"],

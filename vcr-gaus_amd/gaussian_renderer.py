@@ -40,7 +40,9 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
         screenspace_points_densify.retain_grad()
 
     rs = _settings(viewpoint_camera, pc, bg_color, scaling_modifier, cfg.pipline.debug, 0)
-    rasterizer = GaussianRasterizer(raster_settings=rs)
+    lw = cfg.optim.loss_weight
+    want_var = getattr(lw, "depth_var", 0) > 0
+    rasterizer = GaussianRasterizer(raster_settings=rs, num_dist=2 if want_var else None)
 
     act = fused_activate(pc, viewpoint_camera.camera_center, _cam_rotation(viewpoint_camera, dev), return_normal)
     scales, rotations, opacity = act[:3]
@@ -79,6 +81,9 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
     if cfg.optim.loss_weight.semantic > 0:
         sem = rendered_out[8:8 + cfg.model.ch_sem_feat]
         out["render_sem"] = pc.classifier(sem[None])[0].permute(1, 2, 0)
+    if want_var:                                    # gaussian_renderer/__init__.py:154-158
+        d1, d2 = rendered_out[-2:-1], rendered_out[-1:]
+        out["depth_var"] = d2 / rendered_alpha - (d1 / rendered_alpha) ** 2
     return out
 
 

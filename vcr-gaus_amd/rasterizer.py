@@ -60,13 +60,14 @@ def _check(rc):
         raise RuntimeError("vcr_raster: " + _lib.last_error())
 
 
+NUM_DIST = 0      # trailing channels, the fork's compile-time `NUM_DIST` (README.md:155): 0, or 2 = sum w d, sum w d^2
 last_stats = {}   # R / V of the most recent forward (for benchmarks; not part of the reference API)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, means2D_densify, sh, colors_precomp, normals_precomp,
-                semantics_precomp, opacities, scales, rotations, cov3Ds_precomp, dirs, rs, sh_rest=None):
+                semantics_precomp, opacities, scales, rotations, cov3Ds_precomp, dirs, rs, sh_rest=None, num_dist=0):
         lib = _lib.load()
         dev = means3D.device
         if dev.type != "cuda":
@@ -80,7 +81,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         S = 0 if t["sem"] is None else int(t["sem"].shape[1])
         K = 0 if t["shs"] is None else int(t["shs"].shape[1]) + (0 if t["shs_rest"] is None else int(t["shs_rest"].shape[1]))
         a = _lib.VcrRasterArgs(N=N, H=H, W=W, S=S, K=K, sh_degree=int(rs.sh_degree), f_count=int(rs.f_count),
-                               num_dist=0, debug=int(bool(rs.debug)), tanfovx=float(rs.tanfovx),
+                               num_dist=int(num_dist), debug=int(bool(rs.debug)), tanfovx=float(rs.tanfovx),
                                tanfovy=float(rs.tanfovy), scale_modifier=float(rs.scale_modifier),
                                bg=_ptr(t["bg"]), viewmatrix=_ptr(t["view"]), projmatrix=_ptr(t["proj"]),
                                campos=_ptr(t["campos"]), means3D=_ptr(t["means3D"]), shs=_ptr(t["shs"]),
@@ -88,7 +89,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                semantics_precomp=_ptr(t["sem"]), opacities=_ptr(t["opac"]), scales=_ptr(t["scales"]),
                                rotations=_ptr(t["rots"]), cov3D_precomp=_ptr(t["cov"]), dirs=_ptr(t["dirs"]))
         fc = int(rs.f_count)
-        C = 8 + S
+        C = 8 + S + int(num_dist)
         out = torch.empty((C if fc == 0 else 3, H, W), dtype=torch.float32, device=dev) if fc != 3 else None
         radii = torch.zeros(N, dtype=torch.int32, device=dev)
         count = torch.zeros(N, dtype=torch.int32, device=dev) if fc != 0 else None
@@ -103,6 +104,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             ctx.rs, ctx.args_t, ctx.state = rs, t, al.bufs
             ctx.num_rendered = int(fo.num_rendered)
             ctx.has = (means2D_densify is not None)
+            ctx.num_dist = int(num_dist)
             ctx.save_for_backward(radii)
             ctx.mark_non_differentiable(radii)
             return out, radii
@@ -120,7 +122,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         H, W = int(rs.image_height), int(rs.image_width)
         S = 0 if t["sem"] is None else int(t["sem"].shape[1])
         K = 0 if t["shs"] is None else int(t["shs"].shape[1]) + (0 if t["shs_rest"] is None else int(t["shs_rest"].shape[1]))
-        a = _lib.VcrRasterArgs(N=N, H=H, W=W, S=S, K=K, sh_degree=int(rs.sh_degree), f_count=0, num_dist=0,
+        a = _lib.VcrRasterArgs(N=N, H=H, W=W, S=S, K=K, sh_degree=int(rs.sh_degree), f_count=0, num_dist=ctx.num_dist,
                                debug=int(bool(rs.debug)), tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy),
                                scale_modifier=float(rs.scale_modifier), bg=_ptr(t["bg"]), viewmatrix=_ptr(t["view"]),
                                projmatrix=_ptr(t["proj"]), campos=_ptr(t["campos"]), means3D=_ptr(t["means3D"]),
@@ -153,13 +155,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _check(lib.vcr_rasterize_backward(a, io, al.cb, None, stream))
-        return (d_means3D, d_means2D, d_dens, d_shs, d_col, d_nrm, d_sem, d_opac, d_sc, d_rot, d_cov, None, None, d_shr)
+        return (d_means3D, d_means2D, d_dens, d_shs, d_col, d_nrm, d_sem, d_opac, d_sc, d_rot, d_cov, None, None, d_shr, None)
 
 
 class GaussianRasterizer(nn.Module):
-    def __init__(self, raster_settings):
+    def __init__(self, raster_settings, num_dist=None):
         super().__init__()
         self.raster_settings = raster_settings
+        self.num_dist = NUM_DIST if num_dist is None else num_dist
 
     def forward(self, means3D, means2D, opacities, means2D_densify=None, shs=None, colors_precomp=None,
                 normals_precomp=None, semantics_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
@@ -173,4 +176,5 @@ class GaussianRasterizer(nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         return _RasterizeGaussians.apply(means3D, means2D, means2D_densify, shs, colors_precomp, normals_precomp,
-                                         semantics_precomp, opacities, scales, rotations, cov3D_precomp, dirs, rs, shs_rest)
+                                         semantics_precomp, opacities, scales, rotations, cov3D_precomp, dirs, rs, shs_rest,
+                                         self.num_dist if rs.f_count == 0 else 0)

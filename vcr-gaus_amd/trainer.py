@@ -68,6 +68,8 @@ class Trainer:
             L["consistent_normal"] = normal_loss(data["est_normal"], data["normal"])
         if "distortion" in self.weights and it > cfg.optim.close_depth_from_iter and "distortion" in data:
             L["distortion"] = get_edge_aware_distortion_map(gt_image, data["distortion"]).mean()
+        if "depth_var" in self.weights and it > cfg.optim.close_depth_from_iter and "depth_var" in data:
+            L["depth_var"] = get_edge_aware_distortion_map(gt_image, data["depth_var"]).mean()
         if "semantic" in self.weights and "render_sem" in data:
             logits = data["render_sem"].reshape(-1, self.model.num_cls)
             L["semantic"] = torch.nn.functional.cross_entropy(logits, cam.mask.view(-1).long()) / \
