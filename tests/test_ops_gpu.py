@@ -161,3 +161,30 @@ def test_visibility_and_importance_passes(device):
     assert bool(((cnt > 0) >= vis).all())      # visible & inside implies counted
     assert float(imp.min()) >= 0.0 and float(imp.max()) > 0.0
     assert tr.v_imp_score(imp, 0.1).shape[0] == 5000
+
+
+def test_scale_regulariser_and_fused_depth_mask(device):
+    from vcr_gaus_amd.loss_utils import normal_loss, scale_regulariser
+    g = torch.Generator().manual_seed(7)
+    N = 4097
+    sc = torch.randn(N, 3, generator=g) - 3
+    xyz = torch.randn(N, 3, generator=g)
+    trans, scale = torch.tensor([0.1, -0.2, 0.05]), torch.tensor([1.2, 0.9, 1.1])
+    sd = sc.double().requires_grad_(True)
+    inside = torch.all(torch.abs((xyz.double() - trans.double()) / scale.double()) < 1, dim=-1)      # tools/math_utils.py:70-74
+    ref = torch.exp(sd)[inside].min(-1)[0].abs().mean()                                               # trainer.py:243-245
+    ref.backward()
+    sh = sc.to(device).requires_grad_(True)
+    l = scale_regulariser(sh, xyz.to(device), trans.to(device), scale.to(device))
+    l.backward()
+    assert abs(float(l) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+    assert torch.allclose(sh.grad.cpu().double(), sd.grad, atol=1e-9, rtol=1e-4)
+    # depth threshold fused into the loss kernel == explicit boolean mask
+    H, W = 37, 53
+    p = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1).to(device)
+    q = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1).to(device)
+    depth = (torch.rand(1, H, W, generator=g) * 4).to(device)
+    base = torch.rand(H, W, generator=g).to(device) > 0.3
+    a = normal_loss(p, q, weight_src=p, exp_t=0.01, mask=base & (depth[0] < 2.5))
+    b = normal_loss(p, q, weight_src=p, exp_t=0.01, mask=base, depth=depth, depth_max=2.5)
+    assert float(a) == float(b)

@@ -38,12 +38,19 @@ __device__ __forceinline__ void block_accumulate(double* __restrict__ slots, con
 }
 
 // sums layout: [K results][VCR_NSLOT x K slots]
-__global__ void finalize_sums_kernel(int K, double* __restrict__ sums) {
+// mode 0: result[k] = sums[k] * scale (means);  mode 1: result[0] = count > 0 ? (sums[0]+sums[1])/sums[2] : 0
+__global__ void finalize_sums_kernel(int K, double* __restrict__ sums, int mode, double scale, float* __restrict__ result) {
+    __shared__ double s_t[8];
     const int k = threadIdx.x;
-    if (k >= K) return;
-    double t = 0.0;
-    for (int s = 0; s < VCR_NSLOT; ++s) t += sums[K + (size_t)s * K + k];
-    sums[k] = t;
+    if (k < K) {
+        double t = 0.0;
+        for (int s = 0; s < VCR_NSLOT; ++s) t += sums[K + (size_t)s * K + k];
+        sums[k] = t;
+        s_t[k] = t;
+        if (mode == 0 && result) result[k] = (float)(t * scale);
+    }
+    __syncthreads();
+    if (mode == 1 && k == 0 && result) result[0] = s_t[2] > 0.0 ? (float)((s_t[0] + s_t[1]) / s_t[2]) : 0.f;
 }
 
 // ---------------- depth -> normal ----------------------------------------------------------------
@@ -174,10 +181,12 @@ __global__ void __launch_bounds__(256) normalize_chw_bwd_kernel(int P, const flo
 __global__ void __launch_bounds__(256) normal_loss_fwd_kernel(int P, const float* __restrict__ pred,
                                                               const float* __restrict__ gt, const float* __restrict__ wsrc,
                                                               float exp_t, const uint8_t* __restrict__ mask,
+                                                              const float* __restrict__ depth, float depth_max,
                                                               double* __restrict__ sums) {
     float s0 = 0.f, s1 = 0.f, cnt = 0.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) {
         if (mask && !mask[i]) continue;
+        if (depth && !(depth[i] < depth_max)) continue;
         const float p0 = pred[3 * (size_t)i], p1 = pred[3 * (size_t)i + 1], p2 = pred[3 * (size_t)i + 2];
         const float g0 = gt[3 * (size_t)i], g1 = gt[3 * (size_t)i + 1], g2 = gt[3 * (size_t)i + 2];
         float w = 1.f;
@@ -197,12 +206,13 @@ __global__ void __launch_bounds__(256) normal_loss_fwd_kernel(int P, const float
 __global__ void __launch_bounds__(256) normal_loss_bwd_kernel(int P, const float* __restrict__ pred,
                                                               const float* __restrict__ gt, const float* __restrict__ wsrc,
                                                               float exp_t, const uint8_t* __restrict__ mask,
+                                                              const float* __restrict__ depth, float depth_max,
                                                               const double* __restrict__ sums, const float* __restrict__ gout,
                                                               float* __restrict__ dpred, float* __restrict__ dgt) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     float d[3] = {0.f, 0.f, 0.f}, e[3] = {0.f, 0.f, 0.f};
-    if (!mask || mask[i]) {
+    if ((!mask || mask[i]) && (!depth || depth[i] < depth_max)) {
         const float scale = gout[0] / (float)sums[2];
         const float p[3] = {pred[3 * (size_t)i], pred[3 * (size_t)i + 1], pred[3 * (size_t)i + 2]};
         const float g[3] = {gt[3 * (size_t)i], gt[3 * (size_t)i + 1], gt[3 * (size_t)i + 2]};
@@ -379,21 +389,22 @@ extern "C" int vcr_normalize_chw_backward(int P, const float* in_chw, const floa
 }
 
 extern "C" int vcr_normal_loss_forward(int P, const float* pred, const float* gt, const float* wsrc, float exp_t,
-                                       const uint8_t* mask, double* sums3, void* stream) {
+                                       const uint8_t* mask, const float* depth, float depth_max, double* sums3,
+                                       float* loss, void* stream) {
     VCR_HIP_CHECK(hipMemsetAsync(sums3, 0, 3 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
     const int blocks = min((P + 255) / 256, 2048);
     hipLaunchKernelGGL(normal_loss_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, pred, gt, wsrc, exp_t, mask,
-                       sums3);
-    hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, 3, sums3);
+                       depth, depth_max, sums3);
+    hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, 3, sums3, 1, 1.0, loss);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 extern "C" int vcr_normal_loss_backward(int P, const float* pred, const float* gt, const float* wsrc, float exp_t,
-                                        const uint8_t* mask, const double* sums3, const float* gout, float* dpred, float* dgt,
-                                        void* stream) {
+                                        const uint8_t* mask, const float* depth, float depth_max, const double* sums3,
+                                        const float* gout, float* dpred, float* dgt, void* stream) {
     hipLaunchKernelGGL(normal_loss_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, pred, gt, wsrc,
-                       exp_t, mask, sums3, gout, dpred, dgt);
+                       exp_t, mask, depth, depth_max, sums3, gout, dpred, dgt);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -406,13 +417,14 @@ static GaussWin make_window() {
     return g;
 }
 
-extern "C" int vcr_l1_ssim_forward(int H, int W, const float* img1, const float* img2, double* sums2, float* partials9,
-                                   void* stream) {
+extern "C" int vcr_l1_ssim_forward(int H, int W, const float* img1, const float* img2, double* sums2, float* means2,
+                                   float* partials9, void* stream) {
     VCR_HIP_CHECK(hipMemsetAsync(sums2, 0, 2 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
     const dim3 grid((W + SSIM_TX - 1) / SSIM_TX, (H + SSIM_TY - 1) / SSIM_TY, 3);
     hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, make_window(), img1, img2, sums2,
                        partials9);
-    hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, 2, sums2);
+    hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, 2, sums2, 0,
+                       1.0 / (3.0 * (double)H * (double)W), means2);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -422,6 +434,64 @@ extern "C" int vcr_l1_ssim_backward(int H, int W, const float* img1, const float
     const dim3 grid((W + SSIM_TX - 1) / SSIM_TX, (H + SSIM_TY - 1) / SSIM_TY, 3);
     hipLaunchKernelGGL(l1_ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, make_window(), img1, img2, partials9,
                        g_l1, g_ssim, 1.f, 1.f, dimg1);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------- l1_scale regulariser (trainer.py:243-245, tools/math_utils.py:50-74) ----------------------------
+// mean over Gaussians inside the normalised bounding box of min_axis(exp(_scaling)).
+namespace {
+__global__ void __launch_bounds__(256) scale_reg_fwd_kernel(int N, const float* __restrict__ scaling_raw,
+                                                            const float* __restrict__ xyz, const float* __restrict__ trans,
+                                                            const float* __restrict__ scale, double* __restrict__ sums) {
+    float s0 = 0.f, cnt = 0.f;
+    const float t0 = trans[0], t1 = trans[1], t2 = trans[2], i0 = 1.f / scale[0], i1 = 1.f / scale[1], i2 = 1.f / scale[2];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        const size_t i3 = 3 * (size_t)i;
+        const bool in = fabsf((xyz[i3] - t0) * i0) < 1.f && fabsf((xyz[i3 + 1] - t1) * i1) < 1.f &&
+                        fabsf((xyz[i3 + 2] - t2) * i2) < 1.f;
+        if (!in) continue;
+        s0 += __expf(fminf(scaling_raw[i3], fminf(scaling_raw[i3 + 1], scaling_raw[i3 + 2])));
+        cnt += 1.f;
+    }
+    const float v[3] = {s0, 0.f, cnt};
+    block_accumulate<3>(sums + 3, v);
+}
+__global__ void __launch_bounds__(256) scale_reg_bwd_kernel(int N, const float* __restrict__ scaling_raw,
+                                                            const float* __restrict__ xyz, const float* __restrict__ trans,
+                                                            const float* __restrict__ scale, const double* __restrict__ sums,
+                                                            const float* __restrict__ gout, float* __restrict__ dscaling) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const size_t i3 = 3 * (size_t)i;
+    float d[3] = {0.f, 0.f, 0.f};
+    const bool in = fabsf((xyz[i3] - trans[0]) / scale[0]) < 1.f && fabsf((xyz[i3 + 1] - trans[1]) / scale[1]) < 1.f &&
+                    fabsf((xyz[i3 + 2] - trans[2]) / scale[2]) < 1.f;
+    if (in) {
+        const float a = scaling_raw[i3], b = scaling_raw[i3 + 1], c = scaling_raw[i3 + 2];
+        const int k = (a <= b && a <= c) ? 0 : (b <= c ? 1 : 2);           // first minimum, like torch.min
+        d[k] = gout[0] / (float)sums[2] * __expf(fminf(a, fminf(b, c)));
+    }
+    dscaling[i3] = d[0]; dscaling[i3 + 1] = d[1]; dscaling[i3 + 2] = d[2];
+}
+}  // namespace
+
+extern "C" int vcr_scale_reg_forward(int N, const float* scaling_raw, const float* xyz, const float* trans, const float* scale,
+                                     double* sums3, float* loss, void* stream) {
+    VCR_HIP_CHECK(hipMemsetAsync(sums3, 0, 3 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
+    if (N > 0)
+        hipLaunchKernelGGL(scale_reg_fwd_kernel, dim3(min((N + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, N,
+                           scaling_raw, xyz, trans, scale, sums3);
+    hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, 3, sums3, 1, 1.0, loss);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_scale_reg_backward(int N, const float* scaling_raw, const float* xyz, const float* trans, const float* scale,
+                                      const double* sums3, const float* gout, float* dscaling, void* stream) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(scale_reg_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling_raw, xyz,
+                       trans, scale, sums3, gout, dscaling);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -28,7 +28,7 @@ def _cam_rotation(cam, device):
 
 
 def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_color=None, return_normal=True,
-           is_all=True, dirs=None, mask_depth_thr=0.8):
+           is_all=True, dirs=None, mask_depth_thr=0.8, lazy_mask=False):
     """Background tensor (bg_color) must be on the GPU.  Returns the reference's dict:
     render[3,H,W] depth[1,H,W] normal[H,W,3] est_normal[H,W,3] alpha[1,H,W] viewspace_points[N,3]
     viewspace_points_densify[N,3] visibility_filter[N] mask[H,W] radii[N] (+render_sem)."""
@@ -63,13 +63,16 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
         shs_rest=shs_rest)
 
     rendered_image, rendered_depth, rendered_normal, rendered_alpha = rendered_out[:8].split([3, 1, 3, 1], dim=0)
-    with torch.no_grad():
-        mask = viewpoint_camera.mask.bool() if hasattr(viewpoint_camera, "mask") else None
-        if cfg.optim.mask_depth_thr > 0:
-            m1 = (rendered_depth < (pc.extent * cfg.optim.mask_depth_thr)).squeeze(0)
-            mask = m1 if mask is None else (mask & m1)
-        if mask is None:
-            mask = torch.ones(rendered_depth.shape[1:], dtype=torch.bool, device=dev)
+    cam_mask = viewpoint_camera.mask.bool() if hasattr(viewpoint_camera, "mask") else None
+    mask = None
+    if not lazy_mask:      # reference behaviour (:125-131); the fused trainer passes depth + threshold to the loss kernel
+        with torch.no_grad():
+            mask = cam_mask
+            if cfg.optim.mask_depth_thr > 0:
+                m1 = (rendered_depth < (pc.extent * cfg.optim.mask_depth_thr)).squeeze(0)
+                mask = m1 if mask is None else (mask & m1)
+            if mask is None:
+                mask = torch.ones(rendered_depth.shape[1:], dtype=torch.bool, device=dev)
 
     normal = normalize_rendered_normal(rendered_normal)
     est_normal = compute_normals(rendered_depth, viewpoint_camera.intr,
@@ -77,7 +80,7 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
     out = {"render": rendered_image, "depth": rendered_depth, "normal": normal, "est_normal": est_normal,
            "alpha": rendered_alpha, "viewspace_points": screenspace_points,
            "viewspace_points_densify": screenspace_points_densify, "visibility_filter": radii > 0, "mask": mask,
-           "radii": radii}
+           "mask_static": cam_mask, "radii": radii}
     if cfg.optim.loss_weight.semantic > 0:
         sem = rendered_out[8:8 + cfg.model.ch_sem_feat]
         out["render_sem"] = pc.classifier(sem[None])[0].permute(1, 2, 0)

@@ -15,12 +15,12 @@ class _L1SSIM(torch.autograd.Function):
         C, H, W = a.shape
         assert C == 3, "l1_ssim expects [3,H,W] images"
         sums = torch.empty(lib.vcr_sums_elems(2), dtype=torch.float64, device=a.device)
+        res = torch.empty(2, dtype=torch.float32, device=a.device)
         need = img1.requires_grad
         part = torch.empty(9, H, W, dtype=torch.float32, device=a.device) if need else None
-        _lib.check(lib.vcr_l1_ssim_forward(H, W, a.data_ptr(), b.data_ptr(), sums.data_ptr(),
+        _lib.check(lib.vcr_l1_ssim_forward(H, W, a.data_ptr(), b.data_ptr(), sums.data_ptr(), res.data_ptr(),
                                            part.data_ptr() if need else None, _lib.stream_of(a)))
         ctx.save_for_backward(a, b, part)
-        res = (sums[:2] / (3.0 * H * W)).float()
         return res[0], res[1]
 
     @staticmethod
@@ -56,43 +56,78 @@ def ssim(img1, img2, window_size=11, size_average=True):
 
 class _NormalLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, gt, wsrc, exp_t, mask, gt_grad):
+    def forward(ctx, pred, gt, wsrc, exp_t, mask, gt_grad, depth, depth_max):
         lib = _lib.load()
         p = pred.detach().contiguous().float().view(-1, 3)
         g = gt.detach().contiguous().float().view(-1, 3)
         w = None if wsrc is None else wsrc.detach().contiguous().float().view(-1, 3)
         m = None if mask is None else mask.detach().contiguous().view(-1).to(torch.uint8)
+        d = None if depth is None else depth.detach().contiguous().float().view(-1)
         P = p.shape[0]
         sums = torch.empty(lib.vcr_sums_elems(3), dtype=torch.float64, device=p.device)
+        loss = torch.empty(1, dtype=torch.float32, device=p.device)
         _lib.check(lib.vcr_normal_loss_forward(P, p.data_ptr(), g.data_ptr(), None if w is None else w.data_ptr(),
-                                               float(exp_t), None if m is None else m.data_ptr(), sums.data_ptr(),
-                                               _lib.stream_of(p)))
-        ctx.save_for_backward(p, g, w, m, sums)
-        ctx.exp_t, ctx.shape, ctx.gt_grad = float(exp_t), pred.shape, bool(gt_grad)
-        cnt = sums[2]
-        return torch.where(cnt > 0, (sums[0] + sums[1]) / cnt.clamp_min(1.0), torch.zeros_like(cnt)).float()
+                                               float(exp_t), None if m is None else m.data_ptr(),
+                                               None if d is None else d.data_ptr(), float(depth_max), sums.data_ptr(),
+                                               loss.data_ptr(), _lib.stream_of(p)))
+        ctx.save_for_backward(p, g, w, m, d, sums)
+        ctx.exp_t, ctx.shape, ctx.gt_grad, ctx.depth_max = float(exp_t), pred.shape, bool(gt_grad), float(depth_max)
+        return loss[0]
 
     @staticmethod
     def backward(ctx, gout):
         lib = _lib.load()
-        p, g, w, m, sums = ctx.saved_tensors
+        p, g, w, m, d, sums = ctx.saved_tensors
         go = gout.contiguous().float().reshape(1)
         dp = torch.empty_like(p)
         dg = torch.empty_like(p) if ctx.gt_grad else None
         _lib.check(lib.vcr_normal_loss_backward(p.shape[0], p.data_ptr(), g.data_ptr(), None if w is None else w.data_ptr(),
-                                                ctx.exp_t, None if m is None else m.data_ptr(), sums.data_ptr(),
+                                                ctx.exp_t, None if m is None else m.data_ptr(),
+                                                None if d is None else d.data_ptr(), ctx.depth_max, sums.data_ptr(),
                                                 go.data_ptr(), dp.data_ptr(), None if dg is None else dg.data_ptr(),
                                                 _lib.stream_of(p)))
-        return dp.view(ctx.shape), (dg.view(ctx.shape) if dg is not None else None), None, None, None, None
+        return dp.view(ctx.shape), (dg.view(ctx.shape) if dg is not None else None), None, None, None, None, None, None
 
 
-def normal_loss(normal_pred, normal_gt, weight_src=None, exp_t=0.0, mask=None):
+def normal_loss(normal_pred, normal_gt, weight_src=None, exp_t=0.0, mask=None, depth=None, depth_max=0.0):
     """Fused form of the reference's D-Normal chain (`trainer.py:266-280`):
         w = cos_weight(weight_src.detach(), gt, exp_t);  monosdf_normal_loss(pred[mask], gt[mask], w[mask])
     i.e. mean_mask(w |p-g|_1) + mean_mask(w (1 - p.g)) with w = exp((<weight_src,g> - 1)/exp_t)
     (`tools/loss_utils.py:122-143`).  Gradients flow to `normal_pred` and, when it requires grad
-    (normal-consistency loss, `trainer.py:289-293`), to `normal_gt`."""
-    return _NormalLoss.apply(normal_pred, normal_gt, weight_src, exp_t, mask, normal_gt.requires_grad)
+    (normal-consistency loss, `trainer.py:289-293`), to `normal_gt`.  `depth`/`depth_max` fuse the
+    `rendered_depth < extent * mask_depth_thr` part of the mask (`gaussian_renderer/__init__.py:128-131`)."""
+    return _NormalLoss.apply(normal_pred, normal_gt, weight_src, exp_t, mask, normal_gt.requires_grad, depth, depth_max)
+
+
+class _ScaleReg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scaling_raw, xyz, trans, scale):
+        lib = _lib.load()
+        s = scaling_raw.detach().contiguous()
+        x = xyz.detach().contiguous()
+        t, sc = trans.detach().contiguous().float(), scale.detach().contiguous().float()
+        sums = torch.empty(lib.vcr_sums_elems(3), dtype=torch.float64, device=s.device)
+        loss = torch.empty(1, dtype=torch.float32, device=s.device)
+        _lib.check(lib.vcr_scale_reg_forward(s.shape[0], s.data_ptr(), x.data_ptr(), t.data_ptr(), sc.data_ptr(),
+                                             sums.data_ptr(), loss.data_ptr(), _lib.stream_of(s)))
+        ctx.save_for_backward(s, x, t, sc, sums)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        s, x, t, sc, sums = ctx.saved_tensors
+        go = gout.contiguous().float().reshape(1)
+        d = torch.empty_like(s)
+        _lib.check(lib.vcr_scale_reg_backward(s.shape[0], s.data_ptr(), x.data_ptr(), t.data_ptr(), sc.data_ptr(),
+                                              sums.data_ptr(), go.data_ptr(), d.data_ptr(), _lib.stream_of(s)))
+        return d, None, None, None
+
+
+def scale_regulariser(scaling_raw, xyz, trans, scale):
+    """l1_scale (`trainer.py:243-245`): mean of the smallest activated scale over the Gaussians inside the
+    normalised bounding box (`tools/math_utils.py:50-74`), one kernel each way."""
+    return _ScaleReg.apply(scaling_raw, xyz, trans, scale)
 
 
 def monosdf_normal_loss(normal_pred, normal_gt, weight=None):

@@ -18,7 +18,7 @@ import torch.distributed as dist
 
 from .gaussian_model import GaussianModel
 from .gaussian_renderer import count_render, render, visi_acc_render
-from .loss_utils import l1_ssim, normal_loss
+from .loss_utils import l1_ssim, normal_loss, scale_regulariser
 from .normal_utils import get_edge_aware_distortion_map
 
 
@@ -55,15 +55,15 @@ class Trainer:
         l1, ssim_v = l1_ssim(data["render"], gt_image)
         L["l1"], L["ssim"] = l1, 1.0 - ssim_v
         if "l1_scale" in self.weights:
-            inside, _ = self.model.get_inside_gaus_normalized()
-            smin = torch.exp(self.model._scaling.min(-1)[0])
-            L["l1_scale"] = (smin * inside).sum() / inside.sum().clamp_min(1)
+            L["l1_scale"] = scale_regulariser(self.model._scaling, self.model._xyz, self.model.trans, self.model.scale)
         gt_normal = getattr(cam, "normal", None)
         if "mono_normal" in self.weights and it > cfg.optim.normal_from_iter:
             L["mono_normal"] = normal_loss(data["normal"], gt_normal)
         if "depth_normal" in self.weights and it > cfg.optim.dnormal_from_iter:
             L["depth_normal"] = normal_loss(data["est_normal"], gt_normal, weight_src=data["normal"].detach(),
-                                            exp_t=cfg.optim.exp_t, mask=data["mask"])
+                                            exp_t=cfg.optim.exp_t, mask=data.get("mask_static"),
+                                            depth=data["depth"] if cfg.optim.mask_depth_thr > 0 else None,
+                                            depth_max=self.extent * cfg.optim.mask_depth_thr)
         if "consistent_normal" in self.weights and it > cfg.optim.consistent_normal_from_iter:
             L["consistent_normal"] = normal_loss(data["est_normal"], data["normal"])
         if "distortion" in self.weights and it > cfg.optim.close_depth_from_iter and "distortion" in data:
@@ -75,12 +75,18 @@ class Trainer:
             L["semantic"] = torch.nn.functional.cross_entropy(logits, cam.mask.view(-1).long()) / \
                 torch.log(torch.tensor(float(self.model.num_cls)))
         self.losses = L
-        total = None
-        for k, w in self.weights.items():
-            if k in L:
-                total = L[k] * w if total is None else total + L[k] * w
+        names = [k for k in self.weights if k in L]
+        wvec = self._weight_vector(names)
+        total = torch.dot(torch.stack([L[k] for k in names]), wvec)      # one weighted sum instead of 2 ops per loss
         L["total"] = total
         return total
+
+    def _weight_vector(self, names):
+        key = tuple(names)
+        if getattr(self, "_wkey", None) != key:
+            self._wkey = key
+            self._wvec = torch.tensor([float(self.weights[k]) for k in names], device=self.device)
+        return self._wvec
 
     # ---- gradient exchange ------------------------------------------------------------------------------------
     def _allreduce_grads(self):
@@ -160,7 +166,7 @@ class Trainer:
             m.oneupSHdegree()
         cam = self.cameras[self._next_cameras()[self.rank]]
         bg = torch.rand(3, generator=self.gen).to(self.device) if cfg.optim.random_background else self.background
-        data = render(cam, m, cfg, bg, dirs=self.dirs)
+        data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True)
         loss = self._compute_loss(data, cam)
         loss.backward()
         with torch.no_grad():
