@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 2
+#define VCR_ABI_VERSION 3
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -90,6 +90,8 @@ typedef struct VcrBackwardIO {
     float* dL_dshs;          /* [N,K,3] (or [N,1,3] with dL_dshs_rest) or NULL */
     float* dL_dshs_rest;     /* [N,K-1,3] when shs_rest was given, else NULL */
     float* dL_dcolors;       /* [N,3] or NULL */
+    float* dL_drgb;          /* optional [N,3]: dL/d(SH-evaluated colour) after the clamp mask, for the factorised
+                                data-parallel exchange (vcr_sh_grad_from_rgb); dL_dshs may then be NULL */
     float* dL_dnormals;      /* [N,3] or NULL */
     float* dL_dsemantics;    /* [N,S] or NULL */
     float* dL_dopacities;    /* [N] */
@@ -122,6 +124,11 @@ int vcr_activate_backward(int N, const float* scaling_raw, const float* rotation
                           const float* R_w2c, const uint8_t* aux, const float* d_scales, const float* d_rots,
                           const float* d_opac, const float* d_normals /* any may be NULL */, float* d_scaling_raw,
                           float* d_rotation_raw, float* d_opacity_raw, void* stream);
+/* Data-parallel SH gradients without all-reducing them: per view the SH gradient is basis_k(dir) x dL/drgb, so ranks
+ * all-gather dL/drgb (drgb_all [nviews,N,3]) and rebuild sum_v basis_k(normalize(xyz - campos_all[v])) * drgb_all[v]
+ * into the split storage d_features_dc [N,1,3] / d_features_rest [N,15,3].  (No reference counterpart: DP is new.) */
+int vcr_sh_grad_from_rgb(int N, int sh_degree, int nviews, const float* xyz, const float* campos_all,
+                         const float* drgb_all, float* d_features_dc, float* d_features_rest, void* stream);
 /* One launch for all parameter groups; semantics of torch.optim.Adam(eps=1e-15) with per-group lr
  * (scene/gaussian_model.py:247-258).  Pointer arrays are HOST arrays of device pointers (<= 8 tensors).
  * grad_scale multiplies every gradient (1/world_size after a sum all-reduce). */

@@ -55,7 +55,9 @@ def view_data(view, model):
 
 def make_trainer(world, rank):
     cfg = make_config("tnt")
-    return Trainer(cfg, StubModel(), list(range(8)), 1.0, torch.device("cpu"), world=world, rank=rank, seed=3)
+    tr = Trainer(cfg, StubModel(), list(range(8)), 1.0, torch.device("cpu"), world=world, rank=rank, seed=3)
+    tr.factorised_sh = False          # the stub model has no SH groups; the factorised exchange is tested below
+    return tr
 
 
 def worker(rank, world, port, out):
@@ -106,3 +108,65 @@ def test_camera_batches_cover_every_view_once_per_epoch():
     for _ in range(2):
         seen += tr._next_cameras()
     assert sorted(seen) == list(range(8))
+
+
+def _basis_outer(xyz, campos, drgb, deg):
+    """torch stand-in for vcr_sh_grad_from_rgb: d/dshs of sum(eval_sh(shs, dir) * drgb) = basis_k(dir) x drgb."""
+    from oracle import raster_torch as OR
+    d = xyz - campos[None]
+    d = d / d.norm(dim=1, keepdim=True)
+    shs = torch.zeros(xyz.shape[0], 16, 3, requires_grad=True)
+    (OR.eval_sh(deg, shs, d) * drgb).sum().backward()
+    return shs.grad
+
+
+class _Cam:
+    def __init__(self, i):
+        self.camera_center = torch.tensor([1.0 + i, -0.5 * i, 2.0])
+
+
+def sh_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vcr_gaus_amd import rasterizer
+    cfg = make_config("tnt")
+    m = StubModel()
+    m._features_dc = torch.nn.Parameter(torch.zeros(N, 1, 3))
+    m._features_rest = torch.nn.Parameter(torch.zeros(N, 15, 3))
+    m.active_sh_degree = 3
+    m.optimizer.param_groups += [{"params": [m._features_dc], "lr": 0.1, "name": "f_dc"},
+                                 {"params": [m._features_rest], "lr": 0.1, "name": "f_rest"}]
+    tr = Trainer(cfg, m, [_Cam(i) for i in range(8)], 1.0, torch.device("cpu"), world=world, rank=rank, seed=3)
+    assert tr.factorised_sh and rasterizer.SH_GRAD_MODE == "rgb"
+
+    def rebuild(drgb_all, campos_all):
+        g = sum(_basis_outer(m._xyz.detach(), campos_all[v], drgb_all[v], 3) for v in range(drgb_all.shape[0]))
+        return g[:, :1].contiguous(), g[:, 1:].contiguous()
+
+    tr._sh_grads_from_rgb = rebuild
+    cams = tr._next_cameras()
+    view_data(cams[rank], m)
+    gen = torch.Generator().manual_seed(500 + cams[rank])
+    rasterizer.last_drgb["drgb"] = torch.randn(N, 3, generator=gen)
+    tr._allreduce_grads()
+    if rank == 0:
+        torch.save(dict(cams=cams, dc=m._features_dc.grad, rest=m._features_rest.grad, gx=m._xyz.grad), out)
+    rasterizer.SH_GRAD_MODE = "full"
+    dist.destroy_process_group()
+
+
+def test_factorised_sh_exchange_two_ranks(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "sh.pt")
+    mp.spawn(sh_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    m = StubModel()
+    ref = 0
+    gx = 0
+    for v in got["cams"]:
+        view_data(v, m)
+        gx = gx + m._xyz.grad
+        drgb = torch.randn(N, 3, generator=torch.Generator().manual_seed(500 + v))
+        ref = ref + _basis_outer(m._xyz.detach(), _Cam(v).camera_center, drgb, 3)
+    assert torch.allclose(got["dc"], ref[:, :1], atol=1e-6) and torch.allclose(got["rest"], ref[:, 1:], atol=1e-6)
+    assert torch.allclose(got["gx"], gx)

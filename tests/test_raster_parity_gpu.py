@@ -128,3 +128,43 @@ def test_depth_moment_channels_forward_backward(device):
     for k in ["means3D", "normals", "opac", "scales", "rots", "shs"]:
         e = util.rel_err(hl[k].grad, rl[k].grad)
         assert e < 5e-4, f"grad {k}: rel err {e}"
+
+
+def test_factorised_sh_gradient_exchange_equals_summed_full_gradients(device):
+    """DP path: dL/drgb per view + vcr_sh_grad_from_rgb == sum over views of the full SH gradients."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from vcr_gaus_amd import _lib, rasterizer, synthetic
+    n = 3001
+    _, inp, _ = util.make_case(n, 96, 64, 80.0, seed=17, scale_mult=6.0)
+    cams = synthetic.make_cameras(3, 96, 64, 80.0)
+    base = {k: (None if v is None else v.float().to(device)) for k, v in inp.items()}
+    bg = torch.zeros(3, device=device)
+    full_dc = full_rest = None
+    drgbs = []
+    for mode in ("full", "rgb"):
+        rasterizer.SH_GRAD_MODE = mode
+        try:
+            for cam in cams:
+                s = util.settings_for(cam, bg, GaussianRasterizationSettings, device=device, sh_degree=2)
+                dc = base["shs"][:, :1].contiguous().requires_grad_(True)
+                rest = base["shs"][:, 1:].contiguous().requires_grad_(True)
+                out, _ = GaussianRasterizer(s)(means3D=base["means3D"], means2D=torch.zeros(n, 3, device=device), shs=dc,
+                                               shs_rest=rest, opacities=base["opac"], scales=base["scales"],
+                                               rotations=base["rots"])
+                (out[:3] * torch.linspace(0.5, 1.5, 64 * 96, device=device).view(1, 64, 96)).sum().backward()
+                if mode == "full":
+                    full_dc = dc.grad.clone() if full_dc is None else full_dc + dc.grad
+                    full_rest = rest.grad.clone() if full_rest is None else full_rest + rest.grad
+                else:
+                    assert dc.grad is None and rest.grad is None
+                    drgbs.append(rasterizer.last_drgb.pop("drgb"))
+        finally:
+            rasterizer.SH_GRAD_MODE = "full"
+    drgb_all = torch.stack(drgbs).contiguous()
+    campos = torch.stack([c.camera_center for c in cams]).float().to(device).contiguous()
+    d_dc, d_rest = torch.empty(n, 1, 3, device=device), torch.empty(n, 15, 3, device=device)
+    lib = _lib.load()
+    _lib.check(lib.vcr_sh_grad_from_rgb(n, 2, 3, base["means3D"].data_ptr(), campos.data_ptr(), drgb_all.data_ptr(),
+                                        d_dc.data_ptr(), d_rest.data_ptr(), _lib.stream_of(drgb_all)))
+    assert util.rel_err(d_dc, full_dc) < 1e-5 and util.rel_err(d_rest, full_rest) < 1e-5
+    assert float(d_rest[:, 8:].abs().max()) == 0.0          # degree 2 active: degree-3 coefficients get no gradient

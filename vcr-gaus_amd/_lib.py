@@ -41,7 +41,7 @@ class VcrBackwardIO(C.Structure):
         ("dL_dout", C.c_void_p), ("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p),
         ("radii", C.c_void_p), ("num_rendered", C.c_int64),
         ("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dmeans2D_densify", C.c_void_p),
-        ("dL_dshs", C.c_void_p), ("dL_dshs_rest", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_dnormals", C.c_void_p),
+        ("dL_dshs", C.c_void_p), ("dL_dshs_rest", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_drgb", C.c_void_p), ("dL_dnormals", C.c_void_p),
         ("dL_dsemantics", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
         ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
     ]
@@ -55,6 +55,7 @@ SYMBOLS = {
     "vcr_rasterize_backward": (C.c_int, [C.POINTER(VcrRasterArgs), C.POINTER(VcrBackwardIO), ALLOC_FN, C.c_void_p, C.c_void_p]),
     "vcr_activate_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 12),
     "vcr_activate_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 13),
+    "vcr_sh_grad_from_rgb": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "vcr_adam_step": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_int64), c_float_p, C.c_float, C.c_float,
                                 C.c_float, C.c_int, C.c_float, C.c_void_p]),
@@ -97,7 +98,7 @@ def load():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.vcr_abi_version() != 2:
+    if lib.vcr_abi_version() != 3:
         raise ImportError("libvcr_raster.so ABI version mismatch")
     _lib = lib
     return lib

@@ -207,8 +207,8 @@ extern "C" int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* 
     if (N == 0) return 0;
     if (!io->dL_dout || !io->geom || !io->binning || !io->image || !io->radii || !io->dL_dmeans3D || !io->dL_dmeans2D ||
         !io->dL_dopacities) { vcr_set_error("backward: required pointer is NULL"); return 1; }
-    if (a.shs && !io->dL_dshs) { vcr_set_error("backward: dL_dshs is NULL"); return 1; }
-    if (a.shs_rest && !io->dL_dshs_rest) { vcr_set_error("backward: dL_dshs_rest is NULL"); return 1; }
+    if (a.shs && !io->dL_dshs && !io->dL_drgb) { vcr_set_error("backward: dL_dshs and dL_drgb are both NULL"); return 1; }
+    if (a.shs_rest && io->dL_dshs && !io->dL_dshs_rest) { vcr_set_error("backward: dL_dshs_rest is NULL"); return 1; }
     if (a.scales && (!io->dL_dscales || !io->dL_drotations)) { vcr_set_error("backward: dL_dscales/rotations NULL"); return 1; }
     if (a.cov3D_precomp && !io->dL_dcov3D) { vcr_set_error("backward: dL_dcov3D is NULL"); return 1; }
     const int gx = (a.W + VCR_TILE - 1) / VCR_TILE, gy = (a.H + VCR_TILE - 1) / VCR_TILE;
@@ -230,6 +230,7 @@ extern "C" int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* 
     if (!a.normals_precomp) io2.dL_dnormals = nullptr;
     if (a.S == 0) io2.dL_dsemantics = nullptr;
     if (a.colors_precomp == nullptr) io2.dL_dcolors = nullptr;
+    if (a.shs == nullptr) io2.dL_drgb = nullptr;
     StageTimer tm(ST_PREPROCESS_BWD, st);
     return vcr_launch_preprocess_backward(a, g, io->radii, sgrad, sgrad_sem, io2, st);
 }

@@ -400,17 +400,17 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
             sh_basis<true>(a.sh_degree, dx, dy, dz, b, bx, by, bz);
             float* shrow = STAGE ? (s_sh + threadIdx.x * SH_ROW) : nullptr;     // own row: read, then overwritten
             const float* sh = STAGE ? shrow : (a.shs + (size_t)i * a.K * 3);
-            float* dsh = STAGE ? shrow : (io.dL_dshs + (size_t)i * a.K * 3);
+            float* dsh = STAGE ? shrow : (io.dL_dshs ? io.dL_dshs + (size_t)i * a.K * 3 : nullptr);
             float ddx = 0.f, ddy = 0.f, ddz = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 if (k < nb) {
                     const float w = sh[3 * k] * dcol[0] + sh[3 * k + 1] * dcol[1] + sh[3 * k + 2] * dcol[2];
                     ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;
-                    dsh[3 * k] = b[k] * dcol[0]; dsh[3 * k + 1] = b[k] * dcol[1]; dsh[3 * k + 2] = b[k] * dcol[2];
+                    if (dsh) { dsh[3 * k] = b[k] * dcol[0]; dsh[3 * k + 1] = b[k] * dcol[1]; dsh[3 * k + 2] = b[k] * dcol[2]; }
                 }
             }
-            for (int k = nb; k < a.K; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+            if (dsh) for (int k = nb; k < a.K; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
             const float dot = dx * ddx + dy * ddy + dz * ddz;       // through normalize()
             dp[0] += (ddx - dx * dot) * il; dp[1] += (ddy - dy * dot) * il; dp[2] += (ddz - dz * dot) * il;
         }
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
         float* dsh = STAGE ? (s_sh + threadIdx.x * SH_ROW) : (io.dL_dshs + (size_t)i * a.K * 3);
         for (int k = 0; k < a.K * 3; ++k) dsh[k] = 0.f;
     }
-    if (STAGE) {                               // coalesced write-back of the block's SH gradients
+    if (STAGE && io.dL_dshs) {                 // coalesced write-back of the block's SH gradients
         __syncthreads();
         if (io.dL_dshs_rest) {
             coop_copy_out(io.dL_dshs + (size_t)blk_base * 3, blk_cnt * 3, 3, 0, s_sh);
@@ -450,8 +450,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
         } else {
             coop_copy_out(io.dL_dshs + (size_t)blk_base * 48, blk_cnt * 48, 48, 0, s_sh);
         }
-        if (!live) return;
     }
+    if (!live) return;
 
     io.dL_dmeans3D[i3] = dp[0]; io.dL_dmeans3D[i3 + 1] = dp[1]; io.dL_dmeans3D[i3 + 2] = dp[2];
     io.dL_dmeans2D[i3] = dm2[0]; io.dL_dmeans2D[i3 + 1] = dm2[1]; io.dL_dmeans2D[i3 + 2] = 0.f;
@@ -461,6 +461,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
     }
     io.dL_dopacities[i] = dop;
     if (io.dL_dcolors) { io.dL_dcolors[i3] = dcol[0]; io.dL_dcolors[i3 + 1] = dcol[1]; io.dL_dcolors[i3 + 2] = dcol[2]; }
+    if (io.dL_drgb) { io.dL_drgb[i3] = dcol[0]; io.dL_drgb[i3 + 1] = dcol[1]; io.dL_drgb[i3 + 2] = dcol[2]; }
     if (io.dL_dnormals) { io.dL_dnormals[i3] = dn[0]; io.dL_dnormals[i3 + 1] = dn[1]; io.dL_dnormals[i3 + 2] = dn[2]; }
     if (io.dL_dsemantics)
         for (int k = 0; k < a.S; ++k) io.dL_dsemantics[(size_t)i * a.S + k] = vis ? sgrad_sem[(size_t)i * a.S + k] : 0.f;
@@ -474,7 +475,53 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
     }
 }
 
+// ---- factorised SH-gradient exchange (data parallel) ----------------------------------------------------------------
+// For one view the SH gradient of a Gaussian is the rank-1 product basis_k(dir_view) x dL/drgb (clamp already applied),
+// so ranks exchange only dL/drgb [N,3] (all-gather, 12 B/Gaussian/view) and rebuild sum_views basis_k * dL/drgb_view
+// locally instead of all-reducing 192 B/Gaussian of SH gradients.
+__global__ void __launch_bounds__(256) sh_grad_from_rgb_kernel(int N, int deg, int nviews, const float* __restrict__ xyz,
+                                                               const float* __restrict__ campos,
+                                                               const float* __restrict__ drgb, float* __restrict__ d_dc,
+                                                               float* __restrict__ d_rest) {
+    extern __shared__ __attribute__((aligned(16))) float s_sh[];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int blk_base = blockIdx.x * 256, blk_cnt = min(256, N - blk_base);
+    float acc[48];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) acc[k] = 0.f;
+    if (i < N) {
+        const float p0 = xyz[3 * (size_t)i], p1 = xyz[3 * (size_t)i + 1], p2 = xyz[3 * (size_t)i + 2];
+        for (int v = 0; v < nviews; ++v) {
+            const float* g = drgb + ((size_t)v * N + i) * 3;
+            const float g0 = g[0], g1 = g[1], g2 = g[2];
+            if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;
+            float dx = p0 - campos[3 * v], dy = p1 - campos[3 * v + 1], dz = p2 - campos[3 * v + 2];
+            const float il = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+            float b[16];
+            sh_basis<false>(deg, dx * il, dy * il, dz * il, b, nullptr, nullptr, nullptr);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { acc[3 * k] += b[k] * g0; acc[3 * k + 1] += b[k] * g1; acc[3 * k + 2] += b[k] * g2; }
+        }
+    }
+    float* row = s_sh + threadIdx.x * SH_ROW;
+#pragma unroll
+    for (int k = 0; k < 48; ++k) row[k] = acc[k];
+    __syncthreads();
+    coop_copy_out(d_dc + (size_t)blk_base * 3, blk_cnt * 3, 3, 0, s_sh);
+    coop_copy_out(d_rest + (size_t)blk_base * 45, blk_cnt * 45, 45, 3, s_sh);
+}
+
 }  // namespace
+
+extern "C" int vcr_sh_grad_from_rgb(int N, int sh_degree, int nviews, const float* xyz, const float* campos_all,
+                                    const float* drgb_all, float* d_features_dc, float* d_features_rest, void* stream) {
+    if (N <= 0) return 0;
+    if (sh_degree < 0 || sh_degree > 3 || nviews <= 0) { vcr_set_error("vcr_sh_grad_from_rgb: bad degree/views"); return 1; }
+    hipLaunchKernelGGL(sh_grad_from_rgb_kernel, dim3((N + 255) / 256), dim3(256), 256 * SH_ROW * sizeof(float),
+                       (hipStream_t)stream, N, sh_degree, nviews, xyz, campos_all, drgb_all, d_features_dc, d_features_rest);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key, uint32_t* ids,
                           hipStream_t st) {

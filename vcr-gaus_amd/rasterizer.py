@@ -60,6 +60,8 @@ def _check(rc):
         raise RuntimeError("vcr_raster: " + _lib.last_error())
 
 
+SH_GRAD_MODE = "full"   # "rgb": backward skips the SH gradients and leaves dL/drgb [N,3] in `last_drgb` (DP exchange)
+last_drgb = {}
 NUM_DIST = 0      # trailing channels, the fork's compile-time `NUM_DIST` (README.md:155): 0, or 2 = sum w d, sum w d^2
 last_stats = {}   # R / V of the most recent forward (for benchmarks; not part of the reference API)
 
@@ -136,8 +138,10 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         d_means3D, d_means2D, d_opac = new(N, 3), new(N, 3), new(N, 1)
         d_dens = new(N, 3) if ctx.has else None
-        d_shs = new(*t["shs"].shape) if t["shs"] is not None else None
-        d_shr = new(*t["shs_rest"].shape) if t["shs_rest"] is not None else None
+        rgb_mode = SH_GRAD_MODE == "rgb" and t["shs"] is not None
+        d_shs = new(*t["shs"].shape) if (t["shs"] is not None and not rgb_mode) else None
+        d_shr = new(*t["shs_rest"].shape) if (t["shs_rest"] is not None and not rgb_mode) else None
+        d_rgb = new(N, 3) if rgb_mode else None
         d_col = new(N, 3) if t["colors"] is not None else None
         d_nrm = new(N, 3) if t["normals"] is not None else None
         d_sem = new(N, S) if t["sem"] is not None else None
@@ -148,13 +152,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                                 binning=_ptr(ctx.state[_lib.BUF_BINNING]), image=_ptr(ctx.state[_lib.BUF_IMAGE]),
                                 radii=_ptr(radii), num_rendered=ctx.num_rendered, dL_dmeans3D=_ptr(d_means3D),
                                 dL_dmeans2D=_ptr(d_means2D), dL_dmeans2D_densify=_ptr(d_dens), dL_dshs=_ptr(d_shs),
-                                dL_dshs_rest=_ptr(d_shr), dL_dcolors=_ptr(d_col), dL_dnormals=_ptr(d_nrm), dL_dsemantics=_ptr(d_sem),
+                                dL_dshs_rest=_ptr(d_shr), dL_drgb=_ptr(d_rgb), dL_dcolors=_ptr(d_col), dL_dnormals=_ptr(d_nrm), dL_dsemantics=_ptr(d_sem),
                                 dL_dopacities=_ptr(d_opac), dL_dscales=_ptr(d_sc), dL_drotations=_ptr(d_rot),
                                 dL_dcov3D=_ptr(d_cov))
         al = _Allocator(dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _check(lib.vcr_rasterize_backward(a, io, al.cb, None, stream))
+        if rgb_mode:
+            last_drgb["drgb"] = d_rgb
         return (d_means3D, d_means2D, d_dens, d_shs, d_col, d_nrm, d_sem, d_opac, d_sc, d_rot, d_cov, None, None, d_shr, None)
 
 

@@ -38,6 +38,12 @@ class Trainer:
         self.view_order = []
         self.visi_list = None
         self.last_stats = {}
+        self._picked = []
+        # DP: exchange dL/drgb (12 B/Gaussian/view, all-gather) instead of all-reducing the 192 B/Gaussian SH gradients
+        self.factorised_sh = world > 1
+        if self.factorised_sh:
+            from . import rasterizer
+            rasterizer.SH_GRAD_MODE = "rgb"
 
     # ---- camera batch: `world` cameras per step, rank r takes the r-th (`trainer.py:326-328`) -------
     def _next_cameras(self):
@@ -46,6 +52,7 @@ class Trainer:
             if not self.view_order:
                 self.view_order = list(range(len(self.cameras)))
             picked.append(self.view_order.pop(self.rng.randint(0, len(self.view_order) - 1)))
+        self._picked = picked
         return picked
 
     # ---- losses (`trainer.py:233-321`) -------------------------------------------------------------------
@@ -96,14 +103,38 @@ class Trainer:
             self.model.optimizer.grad_scale = 1.0
             return
         works = []
+        drgb_all = None
+        if self.factorised_sh:
+            from . import rasterizer
+            drgb = rasterizer.last_drgb.pop("drgb").contiguous()
+            flat = torch.empty((self.world * drgb.shape[0], 3), dtype=drgb.dtype, device=drgb.device)
+            works.append(dist.all_gather_into_tensor(flat, drgb, async_op=True))      # concatenated along dim 0
+            drgb_all = flat.view(self.world, drgb.shape[0], 3)
         for g in self.model.optimizer.param_groups:
+            if self.factorised_sh and g["name"] in ("f_dc", "f_rest"):
+                continue
             p = g["params"][0]
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
         for w in works:
             w.wait()
+        if self.factorised_sh:
+            campos_all = torch.stack([self.cameras[i].camera_center for i in self._picked]).float().contiguous()
+            self.model._features_dc.grad, self.model._features_rest.grad = self._sh_grads_from_rgb(drgb_all, campos_all)
         self.model.optimizer.grad_scale = 1.0 / self.world
+
+    def _sh_grads_from_rgb(self, drgb_all, campos_all):
+        """sum over the step's views of basis_k(dir_view) x dL/drgb_view (HIP kernel vcr_sh_grad_from_rgb)."""
+        from . import _lib
+        m = self.model
+        lib = _lib.load()
+        N = m._xyz.shape[0]
+        d_dc, d_rest = torch.empty_like(m._features_dc), torch.empty_like(m._features_rest)
+        _lib.check(lib.vcr_sh_grad_from_rgb(N, int(m.active_sh_degree), int(drgb_all.shape[0]), m._xyz.detach().data_ptr(),
+                                            campos_all.data_ptr(), drgb_all.data_ptr(), d_dc.data_ptr(), d_rest.data_ptr(),
+                                            _lib.stream_of(drgb_all)))
+        return d_dc, d_rest
 
     def _densify_stats(self, data):
         m = self.model
