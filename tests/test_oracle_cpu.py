@@ -201,3 +201,29 @@ def test_rasterizer_refuses_cpu_tensors():
     with pytest.raises(RuntimeError):
         GaussianRasterizer(s)(means3D=inp["means3D"], means2D=torch.zeros(8, 3), shs=inp["shs"], opacities=inp["opac"],
                               scales=inp["scales"], rotations=inp["rots"])
+
+
+def test_ply_roundtrip_and_reference_field_order(tmp_path):
+    """PLY wire format of scene/gaussian_model.py:272-320: field order, channel-major SH flattening, f4."""
+    from vcr_gaus_amd import synthetic
+    from vcr_gaus_amd.config import make_config
+    from vcr_gaus_amd.gaussian_model import GaussianModel
+    raw = synthetic.make_gaussians(123, seed=3, sem_channels=2)
+    cfg = make_config("tnt")
+    m = GaussianModel(cfg.model)
+    m.create_from_params(raw, 1.0, device="cpu")
+    path = str(tmp_path / "point_cloud" / "iteration_7" / "point_cloud.ply")
+    m.save_ply(path)
+    head = open(path, "rb").read(4096).split(b"end_header\n")[0].decode()
+    props = [l.split()[-1] for l in head.splitlines() if l.startswith("property")]
+    assert props[:6] == ["x", "y", "z", "nx", "ny", "nz"] and props[6:9] == ["f_dc_0", "f_dc_1", "f_dc_2"]
+    assert props[9] == "f_rest_0" and props[9 + 44] == "f_rest_44" and props[54] == "opacity"
+    assert props[55:62] == ["scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+    assert props[62:] == ["obj_dc_0", "obj_dc_1"] and "element vertex 123" in head
+    # f_rest_k is channel-major: f_rest_0..14 = red coefficients 1..15
+    body = np.frombuffer(open(path, "rb").read().split(b"end_header\n", 1)[1], dtype="<f4").reshape(123, len(props))
+    assert np.allclose(body[:, 9:24], raw["f_rest"][:, :, 0].numpy())
+    m2 = GaussianModel(cfg.model)
+    m2.load_ply(path, device="cpu")
+    for a in ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "_objects_dc"]:
+        assert torch.equal(getattr(m, a).detach(), getattr(m2, a).detach()), a

@@ -41,16 +41,19 @@ __device__ __forceinline__ void block_accumulate(double* __restrict__ slots, con
 // mode 0: result[k] = sums[k] * scale (means);  mode 1: result[0] = count > 0 ? (sums[0]+sums[1])/sums[2] : 0
 __global__ void finalize_sums_kernel(int K, double* __restrict__ sums, int mode, double scale, float* __restrict__ result) {
     __shared__ double s_t[8];
-    const int k = threadIdx.x;
-    if (k < K) {
+    // 64 lanes: lane l folds slots l, l+64, l+128, l+192 (fixed order), then a fixed butterfly
+    for (int k = 0; k < K; ++k) {
         double t = 0.0;
-        for (int s = 0; s < VCR_NSLOT; ++s) t += sums[K + (size_t)s * K + k];
-        sums[k] = t;
-        s_t[k] = t;
-        if (mode == 0 && result) result[k] = (float)(t * scale);
+        for (int s = threadIdx.x; s < VCR_NSLOT; s += 64) t += sums[K + (size_t)s * K + k];
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (threadIdx.x == 0) {
+            sums[k] = t;
+            s_t[k] = t;
+            if (mode == 0 && result) result[k] = (float)(t * scale);
+        }
     }
     __syncthreads();
-    if (mode == 1 && k == 0 && result) result[0] = s_t[2] > 0.0 ? (float)((s_t[0] + s_t[1]) / s_t[2]) : 0.f;
+    if (mode == 1 && threadIdx.x == 0 && result) result[0] = s_t[2] > 0.0 ? (float)((s_t[0] + s_t[1]) / s_t[2]) : 0.f;
 }
 
 // ---------------- depth -> normal ----------------------------------------------------------------

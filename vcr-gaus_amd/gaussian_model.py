@@ -390,6 +390,78 @@ class GaussianModel:
         thr = s[int(percent * (s.shape[0] - 1))]
         self.prune_points((import_score <= thr).squeeze())
 
+    # ---- PLY wire format (scene/gaussian_model.py:272-320,366-423): binary little-endian, all-f4 vertex element
+    def construct_list_of_attributes(self):
+        l = ["x", "y", "z", "nx", "ny", "nz"]
+        l += [f"f_dc_{i}" for i in range(self._features_dc.shape[1] * self._features_dc.shape[2])]
+        l += [f"f_rest_{i}" for i in range(self._features_rest.shape[1] * self._features_rest.shape[2])]
+        l += ["opacity"] + [f"scale_{i}" for i in range(3)] + [f"rot_{i}" for i in range(4)]
+        if self.enable_semantic:
+            l += [f"obj_dc_{i}" for i in range(self._objects_dc.shape[1] * self._objects_dc.shape[2])]
+        return l
+
+    @torch.no_grad()
+    def save_ply(self, path, normals=None):
+        """Same fields, order and channel-major SH flattening as the reference's `point_cloud.ply`, so files go
+        straight into its viewer / mesh / eval tools.  Written with numpy (plyfile is not a dependency)."""
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        cpu = lambda t: t.detach().float().cpu().numpy()
+        xyz = cpu(self._xyz)
+        cols = [xyz, np.zeros_like(xyz) if normals is None else cpu(normals),
+                cpu(self._features_dc.transpose(1, 2).flatten(start_dim=1)),
+                cpu(self._features_rest.transpose(1, 2).flatten(start_dim=1)), cpu(self._opacity), cpu(self._scaling),
+                cpu(self._rotation)]
+        if self.enable_semantic:
+            cols.append(cpu(self._objects_dc.transpose(1, 2).flatten(start_dim=1)))
+        data = np.ascontiguousarray(np.concatenate(cols, axis=1).astype("<f4"))
+        names = self.construct_list_of_attributes()
+        assert data.shape[1] == len(names)
+        header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % data.shape[0]
+        header += "".join(f"property float {n}\n" for n in names) + "end_header\n"
+        with open(path, "wb") as f:
+            f.write(header.encode("ascii"))
+            f.write(data.tobytes())
+
+    def load_ply(self, path, device="cuda"):
+        with open(path, "rb") as f:
+            names, n = [], 0
+            line = f.readline().strip()
+            assert line == b"ply"
+            while True:
+                line = f.readline().strip().decode("ascii")
+                if line.startswith("element vertex"):
+                    n = int(line.split()[-1])
+                elif line.startswith("property"):
+                    parts = line.split()
+                    assert parts[1] in ("float", "float32"), "only all-float vertex elements are supported"
+                    names.append(parts[2])
+                elif line.startswith("format"):
+                    assert "binary_little_endian" in line
+                elif line == "end_header":
+                    break
+            data = np.frombuffer(f.read(4 * n * len(names)), dtype="<f4").reshape(n, len(names))
+        col = {nm: i for i, nm in enumerate(names)}
+        pick = lambda keys: torch.from_numpy(np.stack([data[:, col[k]] for k in keys], 1).copy())
+        srt = lambda pre: sorted([k for k in names if k.startswith(pre)], key=lambda k: int(k.split("_")[-1]))
+        K = (self.max_sh_degree + 1) ** 2
+        rest = srt("f_rest_")
+        assert len(rest) == 3 * (K - 1), "PLY SH degree does not match the model"
+        mk = lambda t: torch.nn.Parameter(t.float().to(device).contiguous().requires_grad_(True))
+        self._xyz = mk(pick(["x", "y", "z"]))
+        self._features_dc = mk(pick(srt("f_dc_")).reshape(n, 3, 1).transpose(1, 2))
+        self._features_rest = mk(pick(rest).reshape(n, 3, K - 1).transpose(1, 2))
+        self._opacity = mk(pick(["opacity"]))
+        self._scaling = mk(pick(srt("scale_")))
+        self._rotation = mk(pick(srt("rot_")))
+        obj = srt("obj_dc_")
+        if obj:
+            self.enable_semantic = True
+            self.ch_sem_feat = len(obj)
+            self._objects_dc = mk(pick(obj).reshape(n, len(obj), 1).transpose(1, 2))
+        self.max_radii2D = torch.zeros(n, device=device)
+        self.active_sh_degree = self.max_sh_degree
+
     # ---- checkpoint (scene/gaussian_model.py:88-123) ---------------------------------------------------
     def capture(self):
         return (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
