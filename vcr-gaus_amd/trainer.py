@@ -35,6 +35,9 @@ class Trainer:
         self.background = torch.tensor([1.0, 1.0, 1.0] if cfg.model.white_background else [0.0, 0.0, 0.0], device=device)
         self.rng = random.Random(seed)            # identical on every rank
         self.gen = torch.Generator(device="cpu").manual_seed(seed)
+        # random backgrounds (`trainer.py:334`) are drawn once on the host and kept on the device: a per-step H2D copy
+        # of a pageable tensor is a stream synchronisation that stops the host from running ahead of the GPU
+        self.bg_table = torch.rand(4096, 3, generator=self.gen).to(device)
         self.view_order = []
         self.visi_list = None
         self.last_stats = {}
@@ -196,7 +199,7 @@ class Trainer:
         if it % 1000 == 0:
             m.oneupSHdegree()
         cam = self.cameras[self._next_cameras()[self.rank]]
-        bg = torch.rand(3, generator=self.gen).to(self.device) if cfg.optim.random_background else self.background
+        bg = self.bg_table[it % self.bg_table.shape[0]] if cfg.optim.random_background else self.background
         data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True)
         loss = self._compute_loss(data, cam)
         loss.backward()
