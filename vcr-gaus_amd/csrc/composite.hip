@@ -290,47 +290,41 @@ __global__ void __launch_bounds__(256) composite_bwd_v2_kernel(VcrRasterArgs a, 
             const float zc = bcast(q0.z, b), pl = bcast(q1.w, b);
             const float nx = bcast(q3.x, b), ny = bcast(q3.y, b), nz = bcast(q3.z, b);
             const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, b);
+            // branch-free: every value is a product with w or dL/dpower, which are forced to 0 on lanes without a hit
             float v[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = 0.f;
             float vs[S > 0 ? S : 1];
-#pragma unroll
-            for (int k = 0; k < S; ++k) vs[k] = 0.f;
-            if (hit) {
+            {
                 const float inv1ma = fast_rcp(1.f - alpha);
-                T *= inv1ma;
-                const float w = alpha * T;
-                float dep = zc, den = 1.f, iden = 1.f;
+                const float Tn = T * inv1ma;                       // transmittance in front of this Gaussian
+                T = hit ? Tn : T;
+                const float w = hit ? alpha * Tn : 0.f;
+                float dep = zc, iden = 0.f;
                 bool isect = false;
                 if (ISECT) {
-                    den = nx * rx + ny * ry + nz * rz;
+                    const float den = nx * rx + ny * ry + nz * rz;
                     isect = den > VCR_PLANE_EPS;
-                    iden = fast_rcp(den);
-                    if (isect) dep = pl * iden * rz;
+                    iden = isect ? fast_rcp(den) : 0.f;
+                    dep = isect ? pl * iden * rz : zc;
                 }
                 float fg = cr * g[0] + cg * g[1] + cbl * g[2] + dep * g[3] + nx * g[4] + ny * g[5] + nz * g[6] + g[7];
                 if (ND == 2) fg += dep * dep * gm2;
 #pragma unroll
                 for (int k = 0; k < S; ++k) fg += semv[(size_t)gid * S + k] * g[8 + k];
-                const float dL_dalpha = T * fg - (Asuf + bgdot) * inv1ma;
+                const float dL_dalpha = hit ? Tn * fg - (Asuf + bgdot) * inv1ma : 0.f;
                 Asuf += w * fg;
-                const float dL_dpow = araw * dL_dalpha;
+                const float dL_dpow = hit ? araw * dL_dalpha : 0.f;       // alpha = o*G, clamp ignored (public rasterizer)
                 const float gdx = -(ca * dx + cb * dy) * dL_dpow;
                 const float gdy = -(cc * dy + cb * dx) * dL_dpow;
                 v[0] = gdx; v[1] = gdy; v[2] = fabsf(gdx); v[3] = fabsf(gdy);
                 v[4] = -0.5f * dx * dx * dL_dpow; v[5] = -dx * dy * dL_dpow; v[6] = -0.5f * dy * dy * dL_dpow;
-                v[7] = G * dL_dalpha;
+                v[7] = hit ? G * dL_dalpha : 0.f;
                 v[8] = w * g[0]; v[9] = w * g[1]; v[10] = w * g[2];
                 const float wd = w * (ND == 2 ? g[3] + 2.f * dep * gm2 : g[3]);
-                v[13] = w * g[4]; v[14] = w * g[5]; v[15] = w * g[6];
-                if (ISECT && isect) {
-                    const float k1 = wd * rz * iden;
-                    v[12] = k1;
-                    const float k2 = -k1 * pl * iden;
-                    v[13] += k2 * rx; v[14] += k2 * ry; v[15] += k2 * rz;
-                } else {
-                    v[11] = wd;
-                }
+                const float k1 = wd * rz * iden;                   // d dep / d plane (0 when the centre depth was used)
+                const float k2 = -k1 * pl * iden;
+                v[11] = isect ? 0.f : wd;
+                v[12] = k1;
+                v[13] = w * g[4] + k2 * rx; v[14] = w * g[5] + k2 * ry; v[15] = w * g[6] + k2 * rz;
 #pragma unroll
                 for (int k = 0; k < S; ++k) vs[k] = w * g[8 + k];
             }
