@@ -39,7 +39,8 @@ typedef struct VcrRasterArgs {
     int32_t K;            /* SH coefficients stored per Gaussian in `shs` ((max_sh_degree+1)^2) */
     int32_t sh_degree;    /* active degree 0..3 */
     int32_t f_count;      /* 0 render, 1 count+score+image, 2 same (countlist), 3 count only */
-    int32_t num_dist;     /* trailing channels: 0 none, 1 distortion, 2 depth moments (sum w d, sum w d^2) */
+    int32_t num_dist;     /* trailing channels: 0 none; 1 depth distortion A*M2 - M1^2 of the mapped depth
+                             m = far/(far-near)*(1-near/d) (2DGS form; near .01, far 100); 2 depth moments (sum w d, sum w d^2) */
     int32_t debug;
     float tanfovx, tanfovy, scale_modifier;
     const float* bg;            /* [3]  */

@@ -282,6 +282,10 @@ def composite_tile(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem, num_dist
         outs.append(wgt @ pre["sem"][idx].to(dt))
     if num_dist == 2:                                  # depth moments (gaussian_renderer/__init__.py:155-157)
         outs += [out_d, (wgt * dep * dep).sum(1, keepdim=True)]
+    if num_dist == 1:                                  # U2: 2DGS-form distortion of the mapped depth (near .01, far 100)
+        md = -(100.0 / (100.0 - 0.01)) * 0.01 / dep          # mapped depth minus its constant term (shift-invariant)
+        m1, m2 = (wgt * md).sum(1, keepdim=True), (wgt * md * md).sum(1, keepdim=True)
+        outs.append(out_a * m2 - m1 * m1)
     out = torch.cat(outs, 1)
     return xs, ys, out, Tfin, contrib, wgt
 

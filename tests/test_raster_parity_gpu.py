@@ -168,3 +168,22 @@ def test_factorised_sh_gradient_exchange_equals_summed_full_gradients(device):
                                         d_dc.data_ptr(), d_rest.data_ptr(), _lib.stream_of(drgb_all)))
     assert util.rel_err(d_dc, full_dc) < 1e-5 and util.rel_err(d_rest, full_rest) < 1e-5
     assert float(d_rest[:, 8:].abs().max()) == 0.0          # degree 2 active: degree-3 coefficients get no gradient
+
+
+def test_distortion_channel_forward_backward(device):
+    """num_dist=1: A*M2 - M1^2 of the mapped depth (2DGS-form distortion), forward and backward."""
+    cam, inp, dirs = util.make_case(2500, 96, 64, 80.0, seed=23, scale_mult=6.0)
+    bg = torch.tensor([0.2, 0.1, 0.4])
+    (ref, _, _), rl = util.oracle_forward(cam, inp, dirs, bg, dtype=torch.float64, requires_grad=True, num_dist=1)
+    assert ref.shape[0] == 9 and float(ref[8].min()) > -1e-9
+    g = torch.Generator().manual_seed(6)
+    wgt = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    wgt[8] *= 1e4                                           # distortion values are ~1e-5
+    (ref * wgt).sum().backward()
+    (out, _), hl = util.hip_forward(cam, inp, dirs, bg, device, requires_grad=True, num_dist=1)
+    assert util.frac_bad(out[:8], ref[:8], 1e-4, 2e-4) < 1e-4
+    assert util.frac_bad(out[8], ref[8], 1e-3, 1e-8) < 1e-3
+    (out * wgt.float().to(device)).sum().backward()
+    for k in ["means3D", "normals", "opac", "scales", "rots", "shs"]:
+        e = util.rel_err(hl[k].grad, rl[k].grad)
+        assert e < 2e-3, f"grad {k}: rel err {e}"

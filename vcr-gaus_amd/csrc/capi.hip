@@ -72,9 +72,9 @@ int validate(const VcrRasterArgs* a) {
     if (!a) { vcr_set_error("args is NULL"); return 1; }
     if (a->N < 0 || a->H <= 0 || a->W <= 0) { vcr_set_error("bad sizes N=%d H=%d W=%d", a->N, a->H, a->W); return 1; }
     if (a->S < 0 || a->S > VCR_MAX_SEM) { vcr_set_error("semantic channels S=%d unsupported (0..%d)", a->S, VCR_MAX_SEM); return 1; }
-    if (a->num_dist != 0 && a->num_dist != 2) {
-        vcr_set_error("num_dist=%d unsupported: 0 (none) or 2 (depth moments sum w d, sum w d^2); the single distortion "
-                      "channel is not built yet", a->num_dist);
+    if (a->num_dist < 0 || a->num_dist > 2) {
+        vcr_set_error("num_dist=%d unsupported: 0 (none), 1 (depth distortion) or 2 (depth moments sum w d, sum w d^2)",
+                      a->num_dist);
         return 1;
     }
     if (a->num_dist != 0 && a->f_count != 0) { vcr_set_error("num_dist needs f_count=0"); return 1; }

@@ -120,8 +120,8 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
                                                                const uint2* __restrict__ ranges,
                                                                const uint32_t* __restrict__ tile_order,
                                                                float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                               float* __restrict__ out, int32_t* __restrict__ count,
-                                                               float* __restrict__ score) {
+                                                               float* __restrict__ moments, float* __restrict__ out,
+                                                               int32_t* __restrict__ count, float* __restrict__ score) {
     const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
     const PixelMap pm = pixel_of_thread(tile, gx, a.W, a.H);
@@ -138,7 +138,8 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
     float SM[S > 0 ? S : 1];
 #pragma unroll
     for (int k = 0; k < S; ++k) SM[k] = 0.f;
-    float M2 = 0.f;                              // ND == 2: sum w d^2 (sum w d equals the depth channel)
+    float M1 = 0.f, M2 = 0.f;   // ND == 2: sum w d^2 (sum w d is the depth channel); ND == 1: sum w m, sum w m^2
+    const float zc_map = VCR_ZFAR / (VCR_ZFAR - VCR_ZNEAR);
     uint32_t last = 0;
     bool done = !pm.inside;
 
@@ -190,6 +191,10 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
             C0 += w * cr; C1 += w * cg; C2 += w * cbl;
             D += w * dep;
             if (ND == 2) M2 += w * dep * dep;
+            if (ND == 1) {
+                const float md = -zc_map * VCR_ZNEAR * fast_rcp(dep);     // shifted by the constant far/(far-near): same distortion, no cancellation
+                M1 += w * md; M2 += w * md * md;
+            }
             N0 += w * nx; N1 += w * ny; N2 += w * nz;
             A += w;
             if (S > 0) {
@@ -222,6 +227,10 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
                 out[(8 + S) * (size_t)P + pm.pix] = D;
                 out[(9 + S) * (size_t)P + pm.pix] = M2;
             }
+            if (ND == 1) {          // 2DGS distortion sum_{i,j} w_i w_j (m_i-m_j)^2 / 2 = A*M2 - M1^2
+                out[(8 + S) * (size_t)P + pm.pix] = A * M2 - M1 * M1;
+                moments[pm.pix] = M1; moments[P + pm.pix] = M2;
+            }
         }
     }
 }
@@ -234,6 +243,7 @@ __global__ void __launch_bounds__(256) composite_bwd_v2_kernel(VcrRasterArgs a, 
                                                                const uint32_t* __restrict__ tile_order,
                                                                const float* __restrict__ final_T,
                                                                const uint32_t* __restrict__ n_contrib,
+                                                               const float* __restrict__ moments,
                                                                const float* __restrict__ dL_dout, GradRec* __restrict__ sgrad,
                                                                float* __restrict__ sgrad_sem) {
     const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
@@ -253,6 +263,13 @@ __global__ void __launch_bounds__(256) composite_bwd_v2_kernel(VcrRasterArgs a, 
     float gm2 = 0.f;                               // ND == 2: gradients of (sum w d) fold into g[3], of (sum w d^2) here
     if (ND == 2 && pm.inside) { g[3] += dL_dout[(8 + S) * (size_t)P + pm.pix]; gm2 = dL_dout[(9 + S) * (size_t)P + pm.pix]; }
     const float Tf = pm.inside ? final_T[pm.pix] : 1.f;
+    float gm1 = 0.f;                                // ND == 1: gradients on sum w m / sum w m^2 from dist = A*M2 - M1^2
+    const float zc_map = VCR_ZFAR / (VCR_ZFAR - VCR_ZNEAR);
+    if (ND == 1 && pm.inside) {
+        const float gd = dL_dout[(8 + S) * (size_t)P + pm.pix];
+        const float m1 = moments[pm.pix], m2 = moments[P + pm.pix];
+        gm1 = -2.f * m1 * gd; gm2 = (1.f - Tf) * gd; g[7] += m2 * gd;
+    }
     const uint32_t lastc = pm.inside ? n_contrib[pm.pix] : 0u;
     const float bgdot = Tf * (a.bg[0] * g[0] + a.bg[1] * g[1] + a.bg[2] * g[2]);
     // deepest contributor of this quad (1-based index in the tile list)
@@ -308,6 +325,12 @@ __global__ void __launch_bounds__(256) composite_bwd_v2_kernel(VcrRasterArgs a, 
                 }
                 float fg = cr * g[0] + cg * g[1] + cbl * g[2] + dep * g[3] + nx * g[4] + ny * g[5] + nz * g[6] + g[7];
                 if (ND == 2) fg += dep * dep * gm2;
+                float md = 0.f, idep = 0.f;
+                if (ND == 1) {
+                    idep = fast_rcp(dep);
+                    md = -zc_map * VCR_ZNEAR * idep;
+                    fg += md * gm1 + md * md * gm2;
+                }
 #pragma unroll
                 for (int k = 0; k < S; ++k) fg += semv[(size_t)gid * S + k] * g[8 + k];
                 const float dL_dalpha = hit ? Tn * fg - (Asuf + bgdot) * inv1ma : 0.f;
@@ -319,7 +342,8 @@ __global__ void __launch_bounds__(256) composite_bwd_v2_kernel(VcrRasterArgs a, 
                 v[4] = -0.5f * dx * dx * dL_dpow; v[5] = -dx * dy * dL_dpow; v[6] = -0.5f * dy * dy * dL_dpow;
                 v[7] = hit ? G * dL_dalpha : 0.f;
                 v[8] = w * g[0]; v[9] = w * g[1]; v[10] = w * g[2];
-                const float wd = w * (ND == 2 ? g[3] + 2.f * dep * gm2 : g[3]);
+                const float wd = w * (ND == 2 ? g[3] + 2.f * dep * gm2
+                                              : (ND == 1 ? g[3] + (gm1 + 2.f * md * gm2) * zc_map * VCR_ZNEAR * idep * idep : g[3]));
                 const float k1 = wd * rz * iden;                   // d dep / d plane (0 when the centre depth was used)
                 const float k2 = -k1 * pl * iden;
                 v[11] = isect ? 0.f : wd;
@@ -360,7 +384,7 @@ int launch_fwd_fc(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im
                   hipStream_t st) {
 #define VCR_FWD(FC, NDD)                                                                                          \
     hipLaunchKernelGGL((composite_fwd_v2_kernel<S, ISECT, FC, NDD>), dim3(tiles), dim3(256), 0, st, a, g.rec, g.sem, \
-                       b.point_list, b.ranges, b.tile_order, im.final_T, im.n_contrib, o.out, o.count, o.score)
+                       b.point_list, b.ranges, b.tile_order, im.final_T, im.n_contrib, im.moments, o.out, o.count, o.score)
     switch (a.f_count) {
         case 0: VCR_FWD(0, ND); break;
         case 1: case 2: VCR_FWD(1, 0); break;
@@ -388,7 +412,7 @@ int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
                  float* sgrad_sem, int tiles, hipStream_t st) {
 #define VCR_BWD(SS)                                                                                              \
     hipLaunchKernelGGL((composite_bwd_v2_kernel<SS, ISECT, ND>), dim3(tiles), dim3(256), 0, st, a, g.rec, g.sem,  \
-                       b.point_list, b.ranges, b.tile_order, im.final_T, im.n_contrib, dL_dout, sgrad, sgrad_sem)
+                       b.point_list, b.ranges, b.tile_order, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem)
     switch (a.S) {
         case 0: VCR_BWD(0); break;
         case 1: VCR_BWD(1); break;
@@ -409,6 +433,8 @@ int vcr_launch_composite_forward(const VcrRasterArgs& a, GeomState g, BinState b
     const bool isect = a.dirs != nullptr && a.normals_precomp != nullptr;
     if (a.num_dist == 2)
         return isect ? launch_fwd_s<true, 2>(a, g, b, im, o, tiles, st) : launch_fwd_s<false, 2>(a, g, b, im, o, tiles, st);
+    if (a.num_dist == 1)
+        return isect ? launch_fwd_s<true, 1>(a, g, b, im, o, tiles, st) : launch_fwd_s<false, 1>(a, g, b, im, o, tiles, st);
     return isect ? launch_fwd_s<true, 0>(a, g, b, im, o, tiles, st) : launch_fwd_s<false, 0>(a, g, b, im, o, tiles, st);
 }
 
@@ -419,6 +445,9 @@ int vcr_launch_composite_backward(const VcrRasterArgs& a, GeomState g, BinState 
     if (a.num_dist == 2)
         return isect ? launch_bwd_s<true, 2>(a, g, b, im, dL_dout, sgrad, sgrad_sem, tiles, st)
                      : launch_bwd_s<false, 2>(a, g, b, im, dL_dout, sgrad, sgrad_sem, tiles, st);
+    if (a.num_dist == 1)
+        return isect ? launch_bwd_s<true, 1>(a, g, b, im, dL_dout, sgrad, sgrad_sem, tiles, st)
+                     : launch_bwd_s<false, 1>(a, g, b, im, dL_dout, sgrad, sgrad_sem, tiles, st);
     return isect ? launch_bwd_s<true, 0>(a, g, b, im, dL_dout, sgrad, sgrad_sem, tiles, st)
                  : launch_bwd_s<false, 0>(a, g, b, im, dL_dout, sgrad, sgrad_sem, tiles, st);
 }

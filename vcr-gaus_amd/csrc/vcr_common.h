@@ -13,6 +13,9 @@
 #define VCR_LOWPASS 0.3f
 #define VCR_PLANE_EPS 1e-4f
 #define VCR_MAX_SEM 4
+// distortion channel: depth mapped like 2DGS, m = far/(far-near) * (1 - near/d), camera znear/zfar (scene/cameras.py:62-63)
+#define VCR_ZNEAR 0.01f
+#define VCR_ZFAR 100.0f
 
 // Per-Gaussian screen-space record consumed by the compositing kernels: one 64-byte line, so a
 // gather by sorted id touches exactly one half cache line.
@@ -79,12 +82,17 @@ struct BinState {
 struct ImageState {
     float* final_T;        // [H*W]
     uint32_t* n_contrib;   // [H*W] index (1-based, within the tile list) of the last contributor
-    static size_t bytes(int P) { return vcr_align(sizeof(float) * (size_t)P) + vcr_align(sizeof(uint32_t) * (size_t)P); }
+    float* moments;        // [2,H*W] sum w m, sum w m^2 of the mapped depth m (distortion channel, num_dist == 1)
+    static size_t bytes(int P) {
+        return vcr_align(sizeof(float) * (size_t)P) + vcr_align(sizeof(uint32_t) * (size_t)P) +
+               vcr_align(2 * sizeof(float) * (size_t)P);
+    }
     static ImageState view(void* p, int P) {
         ImageState s;
         char* c = (char*)p;
-        s.final_T = (float*)c;  c += vcr_align(sizeof(float) * (size_t)P);
-        s.n_contrib = (uint32_t*)c;
+        s.final_T = (float*)c;      c += vcr_align(sizeof(float) * (size_t)P);
+        s.n_contrib = (uint32_t*)c; c += vcr_align(sizeof(uint32_t) * (size_t)P);
+        s.moments = (float*)c;
         return s;
     }
 };

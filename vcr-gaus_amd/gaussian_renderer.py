@@ -42,7 +42,8 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
     rs = _settings(viewpoint_camera, pc, bg_color, scaling_modifier, cfg.pipline.debug, 0)
     lw = cfg.optim.loss_weight
     want_var = getattr(lw, "depth_var", 0) > 0
-    rasterizer = GaussianRasterizer(raster_settings=rs, num_dist=2 if want_var else None)
+    want_dist = getattr(lw, "distortion", 0) > 0 and not want_var
+    rasterizer = GaussianRasterizer(raster_settings=rs, num_dist=2 if want_var else (1 if want_dist else None))
 
     act = fused_activate(pc, viewpoint_camera.camera_center, _cam_rotation(viewpoint_camera, dev), return_normal)
     scales, rotations, opacity = act[:3]
@@ -87,6 +88,8 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
     if want_var:                                    # gaussian_renderer/__init__.py:154-158
         d1, d2 = rendered_out[-2:-1], rendered_out[-1:]
         out["depth_var"] = d2 / rendered_alpha - (d1 / rendered_alpha) ** 2
+    if want_dist:                                   # gaussian_renderer/__init__.py:160-162
+        out["distortion"] = rendered_out[-1:]
     return out
 
 

@@ -62,7 +62,7 @@ def _check(rc):
 
 SH_GRAD_MODE = "full"   # "rgb": backward skips the SH gradients and leaves dL/drgb [N,3] in `last_drgb` (DP exchange)
 last_drgb = {}
-NUM_DIST = 0      # trailing channels, the fork's compile-time `NUM_DIST` (README.md:155): 0, or 2 = sum w d, sum w d^2
+NUM_DIST = 0      # trailing channels, the fork's compile-time `NUM_DIST` (README.md:155): 0, 1 = distortion, 2 = sum w d, sum w d^2
 last_stats = {}   # R / V of the most recent forward (for benchmarks; not part of the reference API)
 
 
