@@ -130,6 +130,9 @@ int vcr_activate_backward(int N, const float* scaling_raw, const float* rotation
  * into the split storage d_features_dc [N,1,3] / d_features_rest [N,15,3].  (No reference counterpart: DP is new.) */
 int vcr_sh_grad_from_rgb(int N, int sh_degree, int nviews, const float* xyz, const float* campos_all,
                          const float* drgb_all, float* d_features_dc, float* d_features_rest, void* stream);
+/* simple_knn._C.distCUDA2 (scene/gaussian_model.py:17-20,211): mean squared distance to the 3 nearest neighbours,
+ * points [N,3] -> out [N].  Exact brute force (one-time initialisation from the SfM point cloud). */
+int vcr_knn3_mean_dist2(int N, const float* points, float* out, void* stream);
 /* One launch for all parameter groups; semantics of torch.optim.Adam(eps=1e-15) with per-group lr
  * (scene/gaussian_model.py:247-258).  Pointer arrays are HOST arrays of device pointers (<= 8 tensors).
  * grad_scale multiplies every gradient (1/world_size after a sum all-reduce). */

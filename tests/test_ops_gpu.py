@@ -188,3 +188,20 @@ def test_scale_regulariser_and_fused_depth_mask(device):
     a = normal_loss(p, q, weight_src=p, exp_t=0.01, mask=base & (depth[0] < 2.5))
     b = normal_loss(p, q, weight_src=p, exp_t=0.01, mask=base, depth=depth, depth_max=2.5)
     assert float(a) == float(b)
+
+
+def test_knn3_init_matches_bruteforce(device):
+    """vcr_knn3_mean_dist2 (replaces simple_knn.distCUDA2) and create_from_pcd (`scene/gaussian_model.py:199-229`)."""
+    from vcr_gaus_amd.config import make_config
+    from vcr_gaus_amd.gaussian_model import GaussianModel
+    g = torch.Generator().manual_seed(11)
+    pts = torch.rand(3000, 3, generator=g)
+    d = torch.cdist(pts.double(), pts.double()) ** 2
+    d.fill_diagonal_(float("inf"))
+    ref = d.topk(3, largest=False).values.mean(1)
+    m = GaussianModel(make_config("tnt").model)
+    m.create_from_pcd(pts.numpy(), torch.rand(3000, 3, generator=g).numpy(), 1.0, device=device)
+    got = torch.exp(m._scaling.detach()[:, 0]).cpu().double() ** 2
+    assert torch.allclose(got, ref.clamp_min(1e-7), rtol=1e-4)
+    assert m._rotation.shape == (3000, 4) and float(m._rotation[:, 0].min()) == 1.0
+    assert abs(float(torch.sigmoid(m._opacity).mean()) - 0.1) < 1e-6 and m._features_rest.abs().max() == 0

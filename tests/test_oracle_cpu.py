@@ -227,3 +227,21 @@ def test_ply_roundtrip_and_reference_field_order(tmp_path):
     m2.load_ply(path, device="cpu")
     for a in ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "_objects_dc"]:
         assert torch.equal(getattr(m, a).detach(), getattr(m2, a).detach()), a
+
+
+def test_virtual_visibility_cameras_look_at_box_floor():
+    """bb_camera (random mode) restatement: centres inside the box, optical axis through the target, valid w2c."""
+    from vcr_gaus_amd.camera_utils import bb_camera_random, sample_cameras
+    trans, scale = torch.tensor([0.2, -0.1, 0.3]), torch.tensor([2.0, 1.5, 1.0])
+    T = bb_camera_random(50, trans, scale, generator=torch.Generator().manual_seed(0))
+    assert T.shape == (50, 4, 4)
+    R = T[:, :3, :3]
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3).expand(50, 3, 3), atol=1e-5)
+    centre = -(R.transpose(1, 2) @ T[:, :3, 3:]).squeeze(-1)
+    assert bool((((centre - trans) / scale).abs() <= 1 + 1e-5).all())
+    target = torch.tensor([0.0, 1.0, 0.0]) * scale + trans
+    t_cam = (R @ (target - centre)[..., None]).squeeze(-1)
+    assert float(t_cam[:, :2].abs().max()) < 1e-4 and bool((t_cam[:, 2] > 0).all())       # on the +z axis of the camera
+    cams = sample_cameras(3, trans, scale, device="cpu", generator=torch.Generator().manual_seed(1))
+    assert cams[0].image_width == 1500 and abs(cams[0].FoVx - 2.5) < 1e-9
+    assert torch.allclose(cams[0].camera_center, -(cams[0].world_view_transform[:3, :3] @ cams[0].world_view_transform[3, :3]), atol=1e-4)

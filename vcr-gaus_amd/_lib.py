@@ -56,6 +56,7 @@ SYMBOLS = {
     "vcr_activate_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 12),
     "vcr_activate_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 13),
     "vcr_sh_grad_from_rgb": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
+    "vcr_knn3_mean_dist2": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vcr_adam_step": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_int64), c_float_p, C.c_float, C.c_float,
                                 C.c_float, C.c_int, C.c_float, C.c_void_p]),

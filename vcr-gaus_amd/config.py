@@ -33,7 +33,7 @@ _BASE = {
         "loss_weight": {"l1": 0.8, "ssim": 0.2, "l1_scale": 1.0, "mono_normal": 0.01, "depth_normal": 0.0,
                         "consistent_normal": 0.0, "distortion": 0.0, "depth_var": 0.0, "semantic": 0.0,
                         "mono_depth": 0.0, "entropy": 0.0},
-        "densify_large": {"percent_dense": 0.0, "sample_cams": {"random": True, "num": 0, "up": False, "around": False}},
+        "densify_large": {"percent_dense": 0.0, "sample_cams": {"random": True, "num": 0, "up": False, "around": True}},
         "prune": {"iterations": [], "percent": 0.5, "decay": 0.6, "v_pow": 0.1},
     },
     "pipline": {"convert_SHs_python": False, "compute_cov3D_python": False, "debug": False},

@@ -161,7 +161,48 @@ __global__ void __launch_bounds__(256) densify_stats_kernel(int N, const float* 
     max_radii[i] = fmaxf(max_radii[i], (float)r);
 }
 
+// Mean squared distance to the 3 nearest neighbours (simple-knn's distCUDA2, scene/gaussian_model.py:211), exact
+// brute force: 256 queries per block, candidates streamed through LDS in 256-point tiles.  One-time initialisation.
+__global__ void __launch_bounds__(256) knn3_kernel(int N, const float* __restrict__ pts, float* __restrict__ out) {
+    __shared__ float s_p[256][3];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (i < N) { px = pts[3 * (size_t)i]; py = pts[3 * (size_t)i + 1]; pz = pts[3 * (size_t)i + 2]; }
+    float b0 = 3.4e38f, b1 = 3.4e38f, b2 = 3.4e38f;
+    for (int base = 0; base < N; base += 256) {
+        const int j = base + threadIdx.x;
+        __syncthreads();
+        if (j < N) { s_p[threadIdx.x][0] = pts[3 * (size_t)j]; s_p[threadIdx.x][1] = pts[3 * (size_t)j + 1]; s_p[threadIdx.x][2] = pts[3 * (size_t)j + 2]; }
+        __syncthreads();
+        const int n = min(256, N - base);
+        for (int k = 0; k < n; ++k) {
+            const float dx = s_p[k][0] - px, dy = s_p[k][1] - py, dz = s_p[k][2] - pz;
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (base + k == i) continue;
+            if (d < b2) {
+                if (d < b1) { b2 = b1; if (d < b0) { b1 = b0; b0 = d; } else b1 = d; }
+                else b2 = d;
+            }
+        }
+    }
+    if (i < N) {
+        const int have = N - 1 < 3 ? N - 1 : 3;
+        float s = 0.f;
+        if (have > 0) s += b0;
+        if (have > 1) s += b1;
+        if (have > 2) s += b2;
+        out[i] = have > 0 ? s / 3.f : 0.f;            // simple-knn divides by 3 regardless
+    }
+}
+
 }  // namespace
+
+extern "C" int vcr_knn3_mean_dist2(int N, const float* points, float* out, void* stream) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(knn3_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, points, out);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 extern "C" int vcr_activate_forward(int N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
                                     const float* xyz, const float* campos, const float* R_w2c, float* scales, float* rots,

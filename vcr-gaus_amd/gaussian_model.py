@@ -170,6 +170,28 @@ class GaussianModel:
         self.trans = self.trans.to(device)
         self.scale = self.scale.to(device)
 
+    def create_from_pcd(self, points, colors, spatial_lr_scale, device="cuda"):
+        """`scene/gaussian_model.py:199-229`: isotropic Gaussians at the SfM points, scale = sqrt(mean squared 3-NN
+        distance) (HIP `vcr_knn3_mean_dist2` replaces simple-knn's `distCUDA2`), identity rotation, opacity 0.1,
+        SH DC from the point colours."""
+        from .sh_utils import RGB2SH
+        lib = _lib.load()
+        pts = torch.as_tensor(points, dtype=torch.float32, device=device).contiguous()
+        col = torch.as_tensor(colors, dtype=torch.float32, device=device)
+        n = pts.shape[0]
+        dist2 = torch.empty(n, device=device)
+        _lib.check(lib.vcr_knn3_mean_dist2(n, pts.data_ptr(), dist2.data_ptr(), _lib.stream_of(pts)))
+        dist2 = torch.clamp_min(dist2, 0.0000001)
+        K = (self.max_sh_degree + 1) ** 2
+        rot = torch.zeros(n, 4, device=device)
+        rot[:, 0] = 1
+        raw = dict(xyz=pts, f_dc=RGB2SH(col)[:, None, :], f_rest=torch.zeros(n, K - 1, 3, device=device),
+                   scaling=torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3), rotation=rot,
+                   opacity=inverse_sigmoid(0.1 * torch.ones(n, 1, device=device)))
+        if self.enable_semantic and self.ch_sem_feat:
+            raw["obj_dc"] = RGB2SH(torch.rand(n, 1, self.ch_sem_feat, device=device))
+        self.create_from_params(raw, spatial_lr_scale, device=device)
+
     # ---- getters (scene/gaussian_model.py:125-195) -----------------------------------------------
     @property
     def device(self):

@@ -184,6 +184,15 @@ class Trainer:
             dist.all_reduce(imp, op=dist.ReduceOp.SUM)
         return cnt, imp
 
+    def _visibility_cameras(self, sc):
+        """`Trainer.get_visi_mask_acc` (`trainer.py:688-702`): virtual bounding-box cameras when
+        `sample_cams.random`, else `num` training cameras drawn with replacement.  Seeded identically on every rank."""
+        if sc.random:
+            from .camera_utils import sample_cameras
+            return sample_cameras(sc.num, self.model.trans, self.model.scale, up=getattr(sc, "up", False),
+                                  around=getattr(sc, "around", True), device=self.device, generator=self.gen)
+        return [self.cameras[self.rng.randrange(len(self.cameras))] for _ in range(sc.num)]
+
     def v_imp_score(self, imp, v_pow):
         """`tools/prune.py:6-22`."""
         vol = torch.prod(self.model.get_scaling, dim=1)
@@ -212,8 +221,7 @@ class Trainer:
                     visi = None
                     dl = cfg.optim.densify_large
                     if dl.percent_dense and dl.sample_cams.num > 0:
-                        n = min(dl.sample_cams.num, len(self.cameras))
-                        visi = self.visibility_mask(self.rng.sample(self.cameras, n))
+                        visi = self.visibility_mask(self._visibility_cameras(dl.sample_cams))
                     m.densify_and_prune(cfg.optim.densify_grad_threshold, 0.005, self.extent, size_threshold, visi)
                 if it % cfg.optim.opacity_reset_interval == 0 or (cfg.model.white_background and it == cfg.optim.densify_from_iter):
                     m.reset_opacity()
