@@ -285,10 +285,21 @@ class BenchTrainer:
 
     def step(self, i):
         from . import rasterizer
-        self.tr.train_step()
+        try:
+            self.tr.train_step()
+        except Exception as e:                      # safety net for the multi-GPU run: fall back to the plain all-reduce
+            if not (self.tr.world > 1 and self.tr.factorised_sh and i == 0):
+                raise
+            print(f"[bench] factorised SH exchange failed ({e!r}); falling back to dense all-reduce", flush=True)
+            self.tr.factorised_sh = False
+            rasterizer.SH_GRAD_MODE = "full"
+            rasterizer.last_drgb.clear()
+            self.tr.model.optimizer.zero_grad(set_to_none=True)
+            self.tr.train_step()
         self.last_R, self.last_V = rasterizer.last_stats.get("R", 0), rasterizer.last_stats.get("V", 0)
 
     def describe(self):
         w = self.tr.weights
         return "render fwd (activate, raster, normals) + losses[" + ",".join(sorted(w)) + "] + bwd + " + \
-            ("RCCL grad all-reduce + " if self.tr.world > 1 else "") + "fused Adam (densify/prune off in the timed window)"
+            (("RCCL exchange (all-gather dL/drgb + all-reduce 44 B/Gaussian) + " if self.tr.factorised_sh
+              else "RCCL grad all-reduce + ") if self.tr.world > 1 else "") + "fused Adam (densify/prune off in the timed window)"
