@@ -15,6 +15,9 @@
 
 namespace {
 
+// rocPRIM falls back to a 20-launch merge sort below 2^20 items; the N-Gaussian depth sort is always worth onesweep.
+using DepthSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+
 struct GatherTiles {
     const uint32_t* tiles;
     __host__ __device__ uint32_t operator()(uint32_t id) const { return tiles[id]; }
@@ -89,7 +92,7 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t R, const uint3
 size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits) {
     size_t b0 = 0, b1 = 0, b2 = 0;
     uint32_t* d = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, b0, d, d, d, d, (size_t)N, 0, 32, (hipStream_t)0);
+    (void)rocprim::radix_sort_pairs<DepthSortConfig>(nullptr, b0, d, d, d, d, (size_t)N, 0, 32, (hipStream_t)0);
     auto it = rocprim::make_transform_iterator(d, GatherTiles{d});
     (void)rocprim::inclusive_scan(nullptr, b1, it, d, (size_t)N, rocprim::plus<uint32_t>(), (hipStream_t)0);
     if (R > 0) (void)rocprim::radix_sort_pairs(nullptr, b2, d, d, d, d, (size_t)R, 0, tile_bits, (hipStream_t)0);
@@ -104,7 +107,7 @@ int vcr_depth_sort_and_scan(int N, const uint32_t* depth_key, const uint32_t* id
                             uint32_t* ids_sorted, const uint32_t* tiles, uint32_t* offsets, void* temp, size_t temp_bytes,
                             hipStream_t st) {
     size_t tb = temp_bytes;
-    VCR_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, depth_key, key_sorted, ids, ids_sorted, (size_t)N, 0, 32, st));
+    VCR_HIP_CHECK(rocprim::radix_sort_pairs<DepthSortConfig>(temp, tb, depth_key, key_sorted, ids, ids_sorted, (size_t)N, 0, 32, st));
     tb = temp_bytes;
     auto it = rocprim::make_transform_iterator(ids_sorted, GatherTiles{tiles});
     VCR_HIP_CHECK(rocprim::inclusive_scan(temp, tb, it, offsets, (size_t)N, rocprim::plus<uint32_t>(), st));
