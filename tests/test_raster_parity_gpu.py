@@ -187,3 +187,57 @@ def test_distortion_channel_forward_backward(device):
     for k in ["means3D", "normals", "opac", "scales", "rots", "shs"]:
         e = util.rel_err(hl[k].grad, rl[k].grad)
         assert e < 2e-3, f"grad {k}: rel err {e}"
+
+
+def test_precomputed_covariance_and_colours_path(device):
+    """cov3D_precomp + colors_precomp inputs (`pipline.compute_cov3D_python` / `override_color`,
+    gaussian_renderer/__init__.py:68-91): forward and gradients against the oracle."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from oracle import raster_torch as OR
+    cam, inp, dirs = util.make_case(2000, 96, 64, 80.0, seed=31, scale_mult=6.0)
+    bg = torch.tensor([0.3, 0.3, 0.1])
+    g = torch.Generator().manual_seed(2)
+    S3 = OR.cov3d_from_scale_rot(inp["scales"].double(), 1.0, inp["rots"].double())
+    cov6 = torch.stack([S3[:, 0, 0], S3[:, 0, 1], S3[:, 0, 2], S3[:, 1, 1], S3[:, 1, 2], S3[:, 2, 2]], 1)
+    col = torch.rand(2000, 3, generator=g, dtype=torch.float64)
+    wgt = None
+    res = {}
+    for name in ("oracle", "hip"):
+        dt, dev = (torch.float64, "cpu") if name == "oracle" else (torch.float32, device)
+        leaf = {k: v.to(dt).to(dev).clone().requires_grad_(True) for k, v in
+                dict(xyz=inp["means3D"], cov=cov6, col=col, op=inp["opac"], nrm=inp["normals"]).items()}
+        if name == "oracle":
+            s = util.settings_for(cam, bg, OR.Settings)
+            out, radii, _ = OR.rasterize(s, leaf["xyz"], torch.zeros(2000, 3, dtype=dt), None, None, leaf["col"], leaf["nrm"],
+                                         None, leaf["op"], None, None, leaf["cov"], dirs)
+            wgt = torch.randn(out.shape, generator=g, dtype=torch.float64)
+        else:
+            s = util.settings_for(cam, bg, GaussianRasterizationSettings, device=device)
+            out, radii = GaussianRasterizer(s)(means3D=leaf["xyz"], means2D=torch.zeros(2000, 3, device=device),
+                                               colors_precomp=leaf["col"], normals_precomp=leaf["nrm"], opacities=leaf["op"],
+                                               cov3D_precomp=leaf["cov"], dirs=dirs.to(device))
+        (out * wgt.to(dt).to(dev)).sum().backward()
+        res[name] = (out.detach(), leaf)
+    assert util.frac_bad(res["hip"][0], res["oracle"][0], 1e-4, 2e-4) < 1e-4
+    for k in ["xyz", "cov", "col", "op", "nrm"]:
+        e = util.rel_err(res["hip"][1][k].grad, res["oracle"][1][k].grad)
+        assert e < 5e-4, f"grad {k}: rel err {e}"
+
+
+def test_empty_model_and_single_gaussian(device):
+    """N = 0 renders the background; N = 1 matches the closed form of tests/test_oracle_cpu.py."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    cam, inp, dirs = util.make_case(4, 48, 32, 40.0, seed=1)
+    bg = torch.tensor([0.5, 0.25, 0.125], device=device)
+    s = util.settings_for(cam, bg, GaussianRasterizationSettings, device=device)
+    e = lambda *sh: torch.empty(*sh, device=device)
+    out, radii = GaussianRasterizer(s)(means3D=e(0, 3), means2D=e(0, 3), shs=e(0, 16, 3), opacities=e(0, 1), scales=e(0, 3),
+                                       rotations=e(0, 4))
+    assert out.shape == (8, 32, 48) and radii.numel() == 0
+    assert torch.allclose(out[:3], bg[:, None, None].expand(3, 32, 48)) and float(out[3:].abs().max()) == 0.0
+    one = {k: (None if v is None else v[:1].float().to(device)) for k, v in inp.items()}
+    (ref, _, _), _ = util.oracle_forward(cam, {k: (None if v is None else v[:1]) for k, v in inp.items()}, dirs, bg.cpu())
+    out1, _ = GaussianRasterizer(s)(means3D=one["means3D"], means2D=torch.zeros(1, 3, device=device), shs=one["shs"],
+                                    opacities=one["opac"], scales=one["scales"] * 20, rotations=one["rots"],
+                                    normals_precomp=one["normals"], dirs=dirs.to(device))
+    assert torch.isfinite(out1).all()

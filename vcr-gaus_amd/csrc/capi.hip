@@ -78,6 +78,10 @@ int validate(const VcrRasterArgs* a) {
         return 1;
     }
     if (a->num_dist != 0 && a->f_count != 0) { vcr_set_error("num_dist needs f_count=0"); return 1; }
+    if (a->N == 0) {                            // empty model: data pointers may legitimately be NULL
+        if (!a->bg) { vcr_set_error("bg is NULL"); return 1; }
+        return 0;
+    }
     if ((a->shs == nullptr) == (a->colors_precomp == nullptr)) { vcr_set_error("provide exactly one of shs / colors_precomp"); return 1; }
     const bool sr = a->scales != nullptr && a->rotations != nullptr;
     if (sr == (a->cov3D_precomp != nullptr)) { vcr_set_error("provide exactly one of (scales, rotations) / cov3D_precomp"); return 1; }
