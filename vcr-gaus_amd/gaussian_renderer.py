@@ -33,11 +33,10 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
     render[3,H,W] depth[1,H,W] normal[H,W,3] est_normal[H,W,3] alpha[1,H,W] viewspace_points[N,3]
     viewspace_points_densify[N,3] visibility_filter[N] mask[H,W] radii[N] (+render_sem)."""
     dev = pc.get_xyz.device
-    screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True) + 0
-    screenspace_points_densify = torch.zeros_like(pc.get_xyz, requires_grad=True) + 0
-    if screenspace_points.requires_grad:           # not under no_grad (the reference guards with try/except)
-        screenspace_points.retain_grad()
-        screenspace_points_densify.retain_grad()
+    # gradient holders for the 2D means (`:31-37`); leaves, so `.grad` is populated without the reference's `+ 0` copies
+    grad_on = torch.is_grad_enabled()
+    screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=grad_on)
+    screenspace_points_densify = torch.zeros_like(pc.get_xyz, requires_grad=grad_on)
 
     rs = _settings(viewpoint_camera, pc, bg_color, scaling_modifier, cfg.pipline.debug, 0)
     lw = cfg.optim.loss_weight
