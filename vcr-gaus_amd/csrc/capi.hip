@@ -68,6 +68,13 @@ __global__ void fill_background_kernel(int P, int C, const float* __restrict__ b
     for (int c = 0; c < C; ++c) out[(size_t)c * P + i] = c < 3 ? bg[c] : 0.f;
 }
 
+__global__ void max_tile_len_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ out) {
+    uint32_t m = 0;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < T; t += gridDim.x * 256) m = max(m, ranges[t].y - ranges[t].x);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
 int validate(const VcrRasterArgs* a) {
     if (!a) { vcr_set_error("args is NULL"); return 1; }
     if (a->N < 0 || a->H <= 0 || a->W <= 0) { vcr_set_error("bad sizes N=%d H=%d W=%d", a->N, a->H, a->W); return 1; }
@@ -180,6 +187,13 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
                 return 1;
         }
         out->num_rendered = R;
+        if (a.debug) {                       // diagnostics only: longest per-tile list (one extra sync)
+            VCR_HIP_CHECK(hipMemsetAsync(vis_counter, 0, sizeof(uint32_t), st));
+            hipLaunchKernelGGL(max_tile_len_kernel, dim3(32), dim3(256), 0, st, T, b.ranges, vis_counter);
+            VCR_HIP_CHECK(hipMemcpyAsync(&rb->R, vis_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            VCR_HIP_CHECK(hipStreamSynchronize(st));
+            out->max_tile_len = (int32_t)rb->R;
+        }
         {
             StageTimer tm(ST_COMPOSITE_FWD, st);
             if (vcr_launch_composite_forward(a, g, b, im, *out, st)) return 1;

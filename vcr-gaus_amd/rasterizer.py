@@ -101,7 +101,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _check(lib.vcr_rasterize_forward(a, fo, al.cb, None, stream))
-        last_stats.update(R=int(fo.num_rendered), V=int(fo.num_visible), N=N)
+        last_stats.update(R=int(fo.num_rendered), V=int(fo.num_visible), N=N, max_tile_len=int(fo.max_tile_len))
         if fc == 0:
             ctx.rs, ctx.args_t, ctx.state = rs, t, al.bufs
             ctx.num_rendered = int(fo.num_rendered)
