@@ -83,13 +83,28 @@ __device__ __forceinline__ float edge_min(float a2, float c2, float b, float xe,
     return 0.5f * a2 * xe * xe + b * xe * ys + 0.5f * c2 * ys * ys;
 }
 
-// Can this Gaussian reach alpha >= 1/255 at any pixel centre of the quad [X0,X0+7]x[Y0,Y0+7]?  Conservative.
-__device__ __forceinline__ bool quad_touch(const float4 q0, const float4 q1, float X0, float Y0) {
+// Bounding box (in quad-local pixel units) of the lanes set in `live` (lane = 8*y + x): the culling rectangle
+// shrinks to the pixels that can still change -- once most of a quad has saturated (T < 1e-4) a long list is only
+// walked for the Gaussians that reach the few remaining pixels, which is what bounds the slowest wave of a launch.
+__device__ __forceinline__ void live_box(unsigned long long live, float X0, float Y0, float& bx0, float& by0, float& bw,
+                                         float& bh) {
+    if (live == 0) { bx0 = X0; by0 = Y0; bw = 7.f; bh = 7.f; return; }
+    const int y0 = __builtin_ctzll(live) >> 3, y1 = (63 - __builtin_clzll(live)) >> 3;
+    unsigned long long c = live | (live >> 32);
+    c |= c >> 16; c |= c >> 8;
+    const unsigned cols = (unsigned)c & 0xFFu;
+    const int x0 = __builtin_ctz(cols), x1 = 31 - __builtin_clz(cols);
+    bx0 = X0 + (float)x0; by0 = Y0 + (float)y0; bw = (float)(x1 - x0); bh = (float)(y1 - y0);
+}
+
+// Can this Gaussian reach alpha >= 1/255 at any pixel centre of the rectangle [X0,X0+bw]x[Y0,Y0+bh]?  Conservative.
+__device__ __forceinline__ bool quad_touch(const float4 q0, const float4 q1, float X0, float Y0, float bw = 7.f,
+                                           float bh = 7.f) {
     const float A = q1.x, B = q1.y, C = q1.z;
     const float tau = __logf(255.f * q0.w);
     if (!(tau >= 0.f)) return false;                      // opacity below 1/255 never contributes
     if (!(A > 0.f) || !(C > 0.f)) return true;            // degenerate conic: leave it to the per-pixel test
-    const float x0 = X0 - q0.x, x1 = X0 + 7.f - q0.x, y0 = Y0 - q0.y, y1 = Y0 + 7.f - q0.y;
+    const float x0 = X0 - q0.x, x1 = X0 + bw - q0.x, y0 = Y0 - q0.y, y1 = Y0 + bh - q0.y;
     if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return true;
     const float ia = 1.f / A, ic = 1.f / C;
     float qm = edge_min(A, C, B, x0, ic, y0, y1);
@@ -128,6 +143,11 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
     const uint2 range = ranges[tile];
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#ifdef VCR_TIMING
+    const long long t_start = wall_clock64();
+    int n_surv = 0, n_hit = 0, n_chunks = 0;
+    long long t_cull = 0, t_surv = 0, t_mark = 0;
+#endif
     const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8), Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8);
     const float fx = (float)pm.x, fy = (float)pm.y;
     float rx = 0.f, ry = 0.f, rz = 1.f;
@@ -153,8 +173,17 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
         const uint32_t npos = pos + 64;
         VCR_GATHER_REC(nid, nq0, nq1, nq2, nq3);                     // records of the next chunk
         VCR_LOAD_ID(npos + 64 + lane, range.y, nnid, nnvalid);       // ids of the chunk after that
-        const bool keep = valid && quad_touch(q0, q1, X0, Y0);
+#ifdef VCR_TIMING
+        t_mark = wall_clock64();
+#endif
+        float bx0, by0, bw, bh;
+        live_box(__builtin_amdgcn_ballot_w64(!done), X0, Y0, bx0, by0, bw, bh);
+        const bool keep = valid && quad_touch(q0, q1, bx0, by0, bw, bh);
         unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+#ifdef VCR_TIMING
+        n_chunks++; n_surv += __popcll(m);
+        { const long long t2 = wall_clock64(); t_cull += t2 - t_mark; t_mark = t2; }
+#endif
         while (m) {
             const int b = __builtin_ctzll(m);
             m &= m - 1;
@@ -171,6 +200,9 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
                 if (__builtin_amdgcn_ballot_w64(!done) == 0) { m = 0; pos = range.y; }
                 continue;
             }
+#ifdef VCR_TIMING
+            n_hit++;
+#endif
             const float w = hit ? alpha * T : 0.f;
             if (FC != 0) {
                 const float ws = wave_sum(w);
@@ -204,9 +236,20 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
             }
             if (hit) { T = test_T; last = pos - range.x + (uint32_t)b + 1u; }
         }
+#ifdef VCR_TIMING
+        t_surv += wall_clock64() - t_mark;
+#endif
         if (pos >= range.y) break;
         pos = npos; id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; valid = nvalid; nid = nnid; nvalid = nnvalid;
     }
+#ifdef VCR_TIMING
+    if (lane == 0 && count) {       // experiment builds only: (start, end) wall-clock ticks per wave
+        reinterpret_cast<long long*>(count)[4 * (blockIdx.x * 4 + wv)] = t_start;
+        reinterpret_cast<long long*>(count)[4 * (blockIdx.x * 4 + wv) + 1] = wall_clock64();
+        reinterpret_cast<long long*>(count)[4 * (blockIdx.x * 4 + wv) + 2] = ((long long)n_chunks << 32) | (unsigned)n_surv;
+        reinterpret_cast<long long*>(count)[4 * (blockIdx.x * 4 + wv) + 3] = (t_cull << 32) | (t_surv & 0xFFFFFFFF);
+    }
+#endif
     if (pm.inside) {
         final_T[pm.pix] = T;
         n_contrib[pm.pix] = last;
@@ -288,7 +331,9 @@ __global__ void __launch_bounds__(256) composite_bwd_v2_kernel(VcrRasterArgs a, 
         uint32_t nnid; float4 nq0, nq1, nq2, nq3; bool nnvalid;
         VCR_GATHER_REC(nid, nq0, nq1, nq2, nq3);
         VCR_LOAD_ID(chunk > 1 ? range.x + (uint32_t)(chunk - 2) * 64u + lane : lim, lim, nnid, nnvalid);
-        const bool keep = valid && quad_touch(q0, q1, X0, Y0);
+        float bx0, by0, bw, bh;
+        live_box(__builtin_amdgcn_ballot_w64(lastc > (uint32_t)chunk * 64u), X0, Y0, bx0, by0, bw, bh);
+        const bool keep = valid && quad_touch(q0, q1, bx0, by0, bw, bh);
         unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
         while (m) {
             const int b = 63 - __builtin_clzll(m);

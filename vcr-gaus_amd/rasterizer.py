@@ -95,6 +95,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         out = torch.empty((C if fc == 0 else 3, H, W), dtype=torch.float32, device=dev) if fc != 3 else None
         radii = torch.zeros(N, dtype=torch.int32, device=dev)
         count = torch.zeros(N, dtype=torch.int32, device=dev) if fc != 0 else None
+        import os as _os
+        if fc == 0 and _os.environ.get("VCR_TIMING"):       # experiment builds only (-DVCR_TIMING)
+            count = torch.zeros(((H + 15) // 16) * ((W + 15) // 16) * 32, dtype=torch.int32, device=dev)
+            last_stats["timing"] = count
         score = torch.zeros(N, dtype=torch.float32, device=dev) if fc in (1, 2) else None
         fo = _lib.VcrForwardOut(out=_ptr(out), radii=_ptr(radii), count=_ptr(count), score=_ptr(score))
         al = _Allocator(dev)
