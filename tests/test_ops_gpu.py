@@ -205,3 +205,27 @@ def test_knn3_init_matches_bruteforce(device):
     assert torch.allclose(got, ref.clamp_min(1e-7), rtol=1e-4)
     assert m._rotation.shape == (3000, 4) and float(m._rotation[:, 0].min()) == 1.0
     assert abs(float(torch.sigmoid(m._opacity).mean()) - 0.1) < 1e-6 and m._features_rest.abs().max() == 0
+
+
+def test_factorised_sh_path_trains_like_the_dense_path(device):
+    """The DP exchange path (backward leaves dL/drgb, SH gradients rebuilt by vcr_sh_grad_from_rgb) run at world size 1
+    must follow the same trajectory as the ordinary path."""
+    from vcr_gaus_amd import rasterizer, synthetic
+    from vcr_gaus_amd.trainer import make_synthetic_trainer
+    raw = synthetic.make_gaussians(8000, seed=2)
+    raw["scaling"] = raw["scaling"] + 1.0
+    finals = []
+    try:
+        for force in (False, True):
+            cams = synthetic.make_cameras(3, 128, 96, 110.0, device=device)
+            tr = make_synthetic_trainer(raw, cams, device, preset="tnt", force_factorised=force,
+                                        optim={"densify_from_iter": 10 ** 9})
+            for _ in range(12):
+                tr.train_step()
+            finals.append({k: getattr(tr.model, k).detach().clone() for k in ["_features_dc", "_features_rest", "_xyz", "_opacity"]})
+            rasterizer.SH_GRAD_MODE = "full"
+    finally:
+        rasterizer.SH_GRAD_MODE = "full"
+    for k in finals[0]:
+        d = float((finals[0][k] - finals[1][k]).abs().max())
+        assert d < 2e-3 * max(1.0, float(finals[0][k].abs().max())), (k, d)

@@ -23,7 +23,7 @@ from .normal_utils import get_edge_aware_distortion_map
 
 
 class Trainer:
-    def __init__(self, cfg, model, cameras, extent, device, world=1, rank=0, dirs=None, seed=0):
+    def __init__(self, cfg, model, cameras, extent, device, world=1, rank=0, dirs=None, seed=0, force_factorised=False):
         self.cfg, self.model, self.cameras = cfg, model, cameras
         self.device, self.world, self.rank = device, world, rank
         self.extent = extent
@@ -43,7 +43,7 @@ class Trainer:
         self.last_stats = {}
         self._picked = []
         # DP: exchange dL/drgb (12 B/Gaussian/view, all-gather) instead of all-reducing the 192 B/Gaussian SH gradients
-        self.factorised_sh = world > 1
+        self.factorised_sh = world > 1 or force_factorised       # (forcing it at world 1 exercises the path in tests)
         if self.factorised_sh:
             from . import rasterizer
             rasterizer.SH_GRAD_MODE = "rgb"
@@ -102,7 +102,14 @@ class Trainer:
     def _allreduce_grads(self):
         """Sum the per-Gaussian gradients of all ranks (RCCL over xGMI).  One collective per parameter
         tensor, all in flight together; the 1/world scale is folded into the Adam kernel."""
-        if self.world == 1:
+        if self.world == 1 and not self.factorised_sh:
+            self.model.optimizer.grad_scale = 1.0
+            return
+        if self.world == 1:                              # single-rank factorised path: no collectives, same kernels
+            from . import rasterizer
+            drgb = rasterizer.last_drgb.pop("drgb").contiguous()
+            campos = self.cameras[self._picked[0]].camera_center.float().reshape(1, 3).contiguous()
+            self.model._features_dc.grad, self.model._features_rest.grad = self._sh_grads_from_rgb(drgb[None].contiguous(), campos)
             self.model.optimizer.grad_scale = 1.0
             return
         works = []
@@ -235,7 +242,8 @@ class Trainer:
         return data
 
 
-def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_jitter=0.02, seed=0, **overrides):
+def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_jitter=0.02, seed=0,
+                           force_factorised=False, **overrides):
     """Model + GT (renders of a perturbed copy of the scene, so every loss is non-trivial) + Trainer."""
     from . import synthetic
     from .config import make_config
@@ -253,7 +261,8 @@ def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_
     extent = synthetic.cameras_extent(cams)
     dirs = get_all_px_dir(cams[0].intr, cams[0].image_height, cams[0].image_width) \
         if cfg.model.depth_type == "intersection" else None
-    tr = Trainer(cfg, model, cams, extent, device, world=world, rank=rank, dirs=dirs, seed=seed)
+    tr = Trainer(cfg, model, cams, extent, device, world=world, rank=rank, dirs=dirs, seed=seed,
+                 force_factorised=force_factorised)
     # ground truth from a jittered copy
     g = torch.Generator().manual_seed(seed + 1)
     raw2 = {k: v.clone() for k, v in raw.items()}
