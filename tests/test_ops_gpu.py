@@ -229,3 +229,35 @@ def test_factorised_sh_path_trains_like_the_dense_path(device):
     for k in finals[0]:
         d = float((finals[0][k] - finals[1][k]).abs().max())
         assert d < 2e-3 * max(1.0, float(finals[0][k].abs().max())), (k, d)
+
+
+def test_rccl_exchange_path_single_rank_group(device):
+    """Runs the REAL collective branch of Trainer._allreduce_grads (all_gather_into_tensor of dL/drgb + all_reduce of the
+    remaining gradients, backend 'nccl' = RCCL) inside a one-rank process group: same trajectory as without it."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from vcr_gaus_amd import rasterizer, synthetic
+    from vcr_gaus_amd.trainer import make_synthetic_trainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        raw = synthetic.make_gaussians(6000, seed=4)
+        raw["scaling"] = raw["scaling"] + 1.0
+        finals = []
+        for coll in (False, True):
+            cams = synthetic.make_cameras(3, 128, 96, 110.0, device=device)
+            tr = make_synthetic_trainer(raw, cams, device, preset="tnt", force_factorised=True,
+                                        optim={"densify_from_iter": 10 ** 9, "densify_until_iter": 100})
+            tr.force_collectives = coll
+            for _ in range(8):
+                tr.train_step()
+            finals.append({k: getattr(tr.model, k).detach().clone() for k in ["_features_rest", "_xyz", "_scaling"]})
+            stats = (tr.model.xyz_gradient_accum.clone(), tr.model.denom.clone(), tr.model.max_radii2D.clone())
+            finals[-1]["stats"] = torch.cat([stats[0].flatten(), stats[1].flatten(), stats[2].flatten()])
+        for k in finals[0]:
+            assert torch.allclose(finals[0][k], finals[1][k], rtol=1e-4, atol=1e-6), k
+    finally:
+        rasterizer.SH_GRAD_MODE = "full"
+        dist.destroy_process_group()

@@ -105,7 +105,7 @@ class Trainer:
         if self.world == 1 and not self.factorised_sh:
             self.model.optimizer.grad_scale = 1.0
             return
-        if self.world == 1:                              # single-rank factorised path: no collectives, same kernels
+        if self.world == 1 and not getattr(self, "force_collectives", False):   # single-rank factorised path: no collectives
             from . import rasterizer
             drgb = rasterizer.last_drgb.pop("drgb").contiguous()
             campos = self.cameras[self._picked[0]].camera_center.float().reshape(1, 3).contiguous()
@@ -149,7 +149,7 @@ class Trainer:
     def _densify_stats(self, data):
         m = self.model
         vp = data["viewspace_points_densify"]
-        if self.world == 1:
+        if self.world == 1 and not getattr(self, "force_collectives", False):
             m.add_densification_stats(vp, data["visibility_filter"], radii=data["radii"])
             return
         N = m._xyz.shape[0]
