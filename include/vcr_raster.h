@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 3
+#define VCR_ABI_VERSION 4
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -164,7 +164,8 @@ int vcr_normal_loss_forward(int P, const float* pred, const float* gt, const flo
                             void* stream);
 int vcr_normal_loss_backward(int P, const float* pred, const float* gt, const float* wsrc, float exp_t,
                              const uint8_t* mask, const float* depth, float depth_max, const double* sums3,
-                             const float* gout, float* dpred, float* dgt, void* stream);
+                             const float* gout, float* dpred, float* dgt,
+                             int accumulate /* bit0: dpred +=, bit1: dgt += (several losses on one tensor) */, void* stream);
 /* l1_scale regulariser: mean over Gaussians inside the bounding box of min_axis(exp(_scaling))
  * (trainer.py:243-245, tools/math_utils.py:50-74 with vector trans/scale).  sums3 as above. */
 int vcr_scale_reg_forward(int N, const float* scaling_raw, const float* xyz, const float* trans, const float* scale,

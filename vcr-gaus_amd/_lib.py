@@ -69,7 +69,7 @@ SYMBOLS = {
                                           C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vcr_normal_loss_backward": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                            C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                           C.c_void_p]),
+                                           C.c_int, C.c_void_p]),
     "vcr_scale_reg_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 7),
     "vcr_scale_reg_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 8),
     "vcr_sums_elems": (C.c_int, [C.c_int]),
@@ -99,7 +99,7 @@ def load():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.vcr_abi_version() != 3:
+    if lib.vcr_abi_version() != 4:
         raise ImportError("libvcr_raster.so ABI version mismatch")
     _lib = lib
     return lib

@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(256) normal_loss_bwd_kernel(int P, const float
                                                               float exp_t, const uint8_t* __restrict__ mask,
                                                               const float* __restrict__ depth, float depth_max,
                                                               const double* __restrict__ sums, const float* __restrict__ gout,
-                                                              float* __restrict__ dpred, float* __restrict__ dgt) {
+                                                              float* __restrict__ dpred, float* __restrict__ dgt, int acc) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     float d[3] = {0.f, 0.f, 0.f}, e[3] = {0.f, 0.f, 0.f};
@@ -232,8 +232,12 @@ __global__ void __launch_bounds__(256) normal_loss_bwd_kernel(int P, const float
             e[k] = scale * w * (-sg - p[k]);
         }
     }
+    if (acc & 1) { d[0] += dpred[3 * (size_t)i]; d[1] += dpred[3 * (size_t)i + 1]; d[2] += dpred[3 * (size_t)i + 2]; }
     dpred[3 * (size_t)i] = d[0]; dpred[3 * (size_t)i + 1] = d[1]; dpred[3 * (size_t)i + 2] = d[2];
-    if (dgt) { dgt[3 * (size_t)i] = e[0]; dgt[3 * (size_t)i + 1] = e[1]; dgt[3 * (size_t)i + 2] = e[2]; }
+    if (dgt) {
+        if (acc & 2) { e[0] += dgt[3 * (size_t)i]; e[1] += dgt[3 * (size_t)i + 1]; e[2] += dgt[3 * (size_t)i + 2]; }
+        dgt[3 * (size_t)i] = e[0]; dgt[3 * (size_t)i + 1] = e[1]; dgt[3 * (size_t)i + 2] = e[2];
+    }
 }
 
 // ---------------- fused L1 + SSIM ------------------------------------------------------------------
@@ -405,9 +409,9 @@ extern "C" int vcr_normal_loss_forward(int P, const float* pred, const float* gt
 
 extern "C" int vcr_normal_loss_backward(int P, const float* pred, const float* gt, const float* wsrc, float exp_t,
                                         const uint8_t* mask, const float* depth, float depth_max, const double* sums3,
-                                        const float* gout, float* dpred, float* dgt, void* stream) {
+                                        const float* gout, float* dpred, float* dgt, int accumulate, void* stream) {
     hipLaunchKernelGGL(normal_loss_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, pred, gt, wsrc,
-                       exp_t, mask, depth, depth_max, sums3, gout, dpred, dgt);
+                       exp_t, mask, depth, depth_max, sums3, gout, dpred, dgt, accumulate);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }

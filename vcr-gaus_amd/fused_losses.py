@@ -1,0 +1,132 @@
+"""The whole image-space loss of `Trainer._compute_loss` (`trainer.py:233-321`) as ONE autograd node.
+
+Same HIP kernels as `loss_utils` / `normal_utils`, but driven from a single forward and a single backward: the
+rasterizer output [C,H,W] goes in, the weighted total comes out, and backward writes dL/d(out) plane by plane into one
+buffer (colour <- L1+SSIM, depth <- depth-to-normal adjoint, normal <- normalisation adjoint) -- no per-loss autograd
+nodes, no `split`/`cat` of channel gradients, ~12 Python-level operator calls less per step."""
+import torch
+
+from . import _lib
+
+NAMES = ["l1", "ssim", "l1_scale", "mono_normal", "depth_normal", "consistent_normal"]
+
+
+class _FusedLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, scaling_raw, xyz, gt_image, gt_normal, mask, intr, wvec, active, exp_t, depth_max, trans, scale):
+        lib = _lib.load()
+        o = out.detach().contiguous()
+        C, H, W = o.shape
+        P = H * W
+        dev = o.device
+        st = _lib.stream_of(o)
+        base = o.data_ptr()
+        normal = torch.empty(P * 3, device=dev)
+        est = torch.empty(P * 3, device=dev)
+        lib.vcr_normalize_chw_forward(P, base + 4 * P * 4, normal.data_ptr(), st)
+        lib.vcr_depth_to_normal_forward(H, W, *intr, base + 3 * P * 4, est.data_ptr(), st)
+        res = torch.zeros(6, device=dev)
+        n2, n3 = lib.vcr_sums_elems(2), lib.vcr_sums_elems(3)
+        sums = torch.empty(n2 + 4 * n3, dtype=torch.float64, device=dev)
+        sp = lambda k: sums.data_ptr() + 8 * (n2 + (k - 1) * n3) if k else sums.data_ptr()
+        rp = lambda k: res.data_ptr() + 4 * k
+        gi = gt_image.detach().contiguous()
+        part = torch.empty(9, H, W, device=dev)
+        _lib.check(lib.vcr_l1_ssim_forward(H, W, base, gi.data_ptr(), sp(0), rp(0), part.data_ptr(), st))
+        sr, xz = scaling_raw.detach().contiguous(), xyz.detach().contiguous()
+        if active[2]:
+            _lib.check(lib.vcr_scale_reg_forward(sr.shape[0], sr.data_ptr(), xz.data_ptr(), trans.data_ptr(), scale.data_ptr(),
+                                                 sp(1), rp(2), st))
+        gn = None if gt_normal is None else gt_normal.detach().contiguous()
+        m = None if mask is None else mask.detach().contiguous().view(-1).to(torch.uint8)
+        dptr = base + 3 * P * 4 if depth_max > 0 else None
+        if active[3]:
+            _lib.check(lib.vcr_normal_loss_forward(P, normal.data_ptr(), gn.data_ptr(), None, 0.0, None, None, 0.0, sp(2), rp(3), st))
+        if active[4]:
+            _lib.check(lib.vcr_normal_loss_forward(P, est.data_ptr(), gn.data_ptr(), normal.data_ptr(), float(exp_t),
+                                                   None if m is None else m.data_ptr(), dptr, float(depth_max), sp(3), rp(4), st))
+        if active[5]:
+            _lib.check(lib.vcr_normal_loss_forward(P, est.data_ptr(), normal.data_ptr(), None, 0.0, None, None, 0.0, sp(4), rp(5), st))
+        ctx.save_for_backward(o, normal, est, gi, part, sums, sr, xz, gn, m, wvec, trans, scale)
+        ctx.meta = (H, W, C, tuple(intr), tuple(active), float(exp_t), float(depth_max), n2, n3)
+        # total = sum_k w_k L_k with the ssim entry meaning (1 - ssim): wvec[1] = -w_ssim, constant +w_ssim added here
+        total = torch.dot(res, wvec) - wvec[1]
+        ctx.mark_non_differentiable(res)
+        return total, res
+
+    @staticmethod
+    def backward(ctx, g_total, _g_res):
+        lib = _lib.load()
+        o, normal, est, gi, part, sums, sr, xz, gn, m, wvec, trans, scale = ctx.saved_tensors
+        H, W, C, intr, active, exp_t, depth_max, n2, n3 = ctx.meta
+        P = H * W
+        dev = o.device
+        st = _lib.stream_of(o)
+        seeds = (g_total * wvec).contiguous()
+        gp = lambda k: seeds.data_ptr() + 4 * k
+        sp = lambda k: sums.data_ptr() + 8 * (n2 + (k - 1) * n3) if k else sums.data_ptr()
+        dout = torch.empty_like(o)
+        dbase = dout.data_ptr()
+        if C > 7:
+            dout[7:].zero_()
+        _lib.check(lib.vcr_l1_ssim_backward(H, W, o.data_ptr(), gi.data_ptr(), part.data_ptr(), gp(0), gp(1), dbase, st))
+        d_nrm = torch.empty(P * 3, device=dev)
+        d_est = torch.empty(P * 3, device=dev)
+        nrm_w = est_w = False
+        base = o.data_ptr()
+        dptr = base + 3 * P * 4 if depth_max > 0 else None
+        if active[3]:
+            _lib.check(lib.vcr_normal_loss_backward(P, normal.data_ptr(), gn.data_ptr(), None, 0.0, None, None, 0.0, sp(2), gp(3),
+                                                    d_nrm.data_ptr(), None, 0, st))
+            nrm_w = True
+        if active[4]:
+            _lib.check(lib.vcr_normal_loss_backward(P, est.data_ptr(), gn.data_ptr(), normal.data_ptr(), exp_t,
+                                                    None if m is None else m.data_ptr(), dptr, depth_max, sp(3), gp(4),
+                                                    d_est.data_ptr(), None, 0, st))
+            est_w = True
+        if active[5]:
+            if not nrm_w:
+                d_nrm.zero_()
+            _lib.check(lib.vcr_normal_loss_backward(P, est.data_ptr(), normal.data_ptr(), None, 0.0, None, None, 0.0, sp(4), gp(5),
+                                                    d_est.data_ptr(), d_nrm.data_ptr(), (1 if est_w else 0) | 2, st))
+            nrm_w = est_w = True
+        if est_w:
+            scratch = torch.empty(P * 6, device=dev)
+            _lib.check(lib.vcr_depth_to_normal_backward(H, W, *intr, base + 3 * P * 4, d_est.data_ptr(), scratch.data_ptr(),
+                                                        dbase + 3 * P * 4, st))
+        else:
+            dout[3].zero_()
+        if nrm_w:
+            _lib.check(lib.vcr_normalize_chw_backward(P, base + 4 * P * 4, d_nrm.data_ptr(), dbase + 4 * P * 4, st))
+        else:
+            dout[4:7].zero_()
+        d_sc = None
+        if active[2]:
+            d_sc = torch.empty_like(sr)
+            _lib.check(lib.vcr_scale_reg_backward(sr.shape[0], sr.data_ptr(), xz.data_ptr(), trans.data_ptr(), scale.data_ptr(),
+                                                  sp(1), gp(2), d_sc.data_ptr(), st))
+        return (dout, d_sc) + (None,) * 11
+
+
+def fused_losses(out, model, cam, weights, it, optim_cfg, extent, mask=None):
+    """-> (total, {name: value}) for the losses of `weights` that this node covers (`NAMES`)."""
+    w = [float(weights.get(n, 0.0)) for n in NAMES]
+    has_n = getattr(cam, "normal", None) is not None
+    active = [True, True, w[2] != 0,
+              w[3] != 0 and has_n and it > optim_cfg.normal_from_iter,
+              w[4] != 0 and has_n and it > optim_cfg.dnormal_from_iter,
+              w[5] != 0 and it > optim_cfg.consistent_normal_from_iter]
+    wv = [w[0], -w[1]] + [w[k] if active[k] else 0.0 for k in range(2, 6)]
+    key = tuple(wv)
+    cache = fused_losses.__dict__.setdefault("_wcache", {})
+    if key not in cache:
+        cache[key] = torch.tensor(wv, device=out.device)
+    depth_max = extent * optim_cfg.mask_depth_thr if optim_cfg.mask_depth_thr > 0 else 0.0
+    total, res = _FusedLosses.apply(out, model._scaling, model._xyz, cam.original_image, getattr(cam, "normal", None), mask,
+                                    cam.intr_scalars, cache[key], tuple(active), optim_cfg.exp_t, depth_max, model.trans,
+                                    model.scale)
+    vals = {"l1": res[0], "ssim": 1.0 - res[1]}
+    for k in range(2, 6):
+        if active[k]:
+            vals[NAMES[k]] = res[k]
+    return total, vals

@@ -28,7 +28,7 @@ def _cam_rotation(cam, device):
 
 
 def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_color=None, return_normal=True,
-           is_all=True, dirs=None, mask_depth_thr=0.8, lazy_mask=False):
+           is_all=True, dirs=None, mask_depth_thr=0.8, lazy_mask=False, geometry=True):
     """Background tensor (bg_color) must be on the GPU.  Returns the reference's dict:
     render[3,H,W] depth[1,H,W] normal[H,W,3] est_normal[H,W,3] alpha[1,H,W] viewspace_points[N,3]
     viewspace_points_densify[N,3] visibility_filter[N] mask[H,W] radii[N] (+render_sem)."""
@@ -74,13 +74,15 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
             if mask is None:
                 mask = torch.ones(rendered_depth.shape[1:], dtype=torch.bool, device=dev)
 
-    normal = normalize_rendered_normal(rendered_normal)
-    est_normal = compute_normals(rendered_depth, viewpoint_camera.intr,
-                                 getattr(viewpoint_camera, "intr_scalars", None))
+    normal = est_normal = None
+    if geometry:       # the fused loss node (fused_losses.py) derives both itself from `render_out`
+        normal = normalize_rendered_normal(rendered_normal)
+        est_normal = compute_normals(rendered_depth, viewpoint_camera.intr,
+                                     getattr(viewpoint_camera, "intr_scalars", None))
     out = {"render": rendered_image, "depth": rendered_depth, "normal": normal, "est_normal": est_normal,
            "alpha": rendered_alpha, "viewspace_points": screenspace_points,
            "viewspace_points_densify": screenspace_points_densify, "visibility_filter": radii > 0, "mask": mask,
-           "mask_static": cam_mask, "radii": radii}
+           "mask_static": cam_mask, "radii": radii, "render_out": rendered_out}
     if cfg.optim.loss_weight.semantic > 0:
         sem = rendered_out[8:8 + cfg.model.ch_sem_feat]
         out["render_sem"] = pc.classifier(sem[None])[0].permute(1, 2, 0)

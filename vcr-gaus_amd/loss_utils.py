@@ -84,7 +84,7 @@ class _NormalLoss(torch.autograd.Function):
         _lib.check(lib.vcr_normal_loss_backward(p.shape[0], p.data_ptr(), g.data_ptr(), None if w is None else w.data_ptr(),
                                                 ctx.exp_t, None if m is None else m.data_ptr(),
                                                 None if d is None else d.data_ptr(), ctx.depth_max, sums.data_ptr(),
-                                                go.data_ptr(), dp.data_ptr(), None if dg is None else dg.data_ptr(),
+                                                go.data_ptr(), dp.data_ptr(), None if dg is None else dg.data_ptr(), 0,
                                                 _lib.stream_of(p)))
         return dp.view(ctx.shape), (dg.view(ctx.shape) if dg is not None else None), None, None, None, None, None, None
 

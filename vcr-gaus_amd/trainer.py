@@ -60,6 +60,14 @@ class Trainer:
 
     # ---- losses (`trainer.py:233-321`) -------------------------------------------------------------------
     def _compute_loss(self, data, cam):
+        extra = [k for k in ("distortion", "depth_var", "semantic", "entropy", "mono_depth") if k in self.weights]
+        if not extra and "render_out" in data and getattr(self, "use_fused_losses", True):
+            from .fused_losses import fused_losses          # one autograd node for the whole image-space loss
+            total, vals = fused_losses(data["render_out"], self.model, cam, self.weights, self.current_iteration,
+                                       self.cfg.optim, self.extent, mask=data.get("mask_static"))
+            vals["total"] = total
+            self.losses = vals
+            return total
         cfg, it, L = self.cfg, self.current_iteration, {}
         gt_image = cam.original_image
         l1, ssim_v = l1_ssim(data["render"], gt_image)
@@ -216,7 +224,9 @@ class Trainer:
             m.oneupSHdegree()
         cam = self.cameras[self._next_cameras()[self.rank]]
         bg = self.bg_table[it % self.bg_table.shape[0]] if cfg.optim.random_background else self.background
-        data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True)
+        fused = getattr(self, "use_fused_losses", True) and not any(
+            k in self.weights for k in ("distortion", "depth_var", "semantic", "entropy", "mono_depth"))
+        data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True, geometry=not fused)
         loss = self._compute_loss(data, cam)
         loss.backward()
         with torch.no_grad():
