@@ -86,9 +86,12 @@ class FusedAdam:
         return st
 
     @torch.no_grad()
-    def step(self):
+    def step(self, only=None):
+        """`only`: optional set of group names to update now (their gradients are released afterwards), used by the
+        data-parallel trainer to run Adam on the SH groups while the other groups' all-reduce is still in flight."""
         lib = _lib.load()
-        live = [g for g in self.param_groups if g["params"][0].grad is not None and g["params"][0].numel() > 0]
+        live = [g for g in self.param_groups if g["params"][0].grad is not None and g["params"][0].numel() > 0
+                and (only is None or g["name"] in only)]
         if not live:
             return
         by_step = {}
@@ -111,6 +114,9 @@ class FusedAdam:
                 numel[k], lr[k] = p.numel(), g["lr"]
             _lib.check(lib.vcr_adam_step(n, P, G, M, V, numel, lr, self.betas[0], self.betas[1], self.eps, step,
                                          float(self.grad_scale), _lib.stream_of(gs[0]["params"][0])))
+        if only is not None:
+            for g in live:
+                g["params"][0].grad = None
 
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:

@@ -107,9 +107,12 @@ class Trainer:
         return self._wvec
 
     # ---- gradient exchange ------------------------------------------------------------------------------------
-    def _allreduce_grads(self):
+    def _allreduce_grads(self, early_feature_step=False):
         """Sum the per-Gaussian gradients of all ranks (RCCL over xGMI).  One collective per parameter
-        tensor, all in flight together; the 1/world scale is folded into the Adam kernel."""
+        tensor, all in flight together; the 1/world scale is folded into the Adam kernel.  With the factorised SH
+        exchange the all-gather of dL/drgb is awaited first, the SH gradients are rebuilt and (on iterations without
+        densify / prune / opacity-reset surgery) their Adam update runs while the all-reduce of the remaining
+        44 B/Gaussian is still in flight."""
         if self.world == 1 and not self.factorised_sh:
             self.model.optimizer.grad_scale = 1.0
             return
@@ -121,12 +124,14 @@ class Trainer:
             self.model.optimizer.grad_scale = 1.0
             return
         works = []
+        gather = None
         drgb_all = None
+        self.model.optimizer.grad_scale = 1.0 / self.world
         if self.factorised_sh:
             from . import rasterizer
             drgb = rasterizer.last_drgb.pop("drgb").contiguous()
             flat = torch.empty((self.world * drgb.shape[0], 3), dtype=drgb.dtype, device=drgb.device)
-            works.append(dist.all_gather_into_tensor(flat, drgb, async_op=True))      # concatenated along dim 0
+            gather = dist.all_gather_into_tensor(flat, drgb, async_op=True)           # concatenated along dim 0
             drgb_all = flat.view(self.world, drgb.shape[0], 3)
         for g in self.model.optimizer.param_groups:
             if self.factorised_sh and g["name"] in ("f_dc", "f_rest"):
@@ -135,12 +140,14 @@ class Trainer:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
-        for w in works:
-            w.wait()
-        if self.factorised_sh:
+        if gather is not None:
+            gather.wait()
             campos_all = torch.stack([self.cameras[i].camera_center for i in self._picked]).float().contiguous()
             self.model._features_dc.grad, self.model._features_rest.grad = self._sh_grads_from_rgb(drgb_all, campos_all)
-        self.model.optimizer.grad_scale = 1.0 / self.world
+            if early_feature_step:
+                self.model.optimizer.step(only={"f_dc", "f_rest"})
+        for w in works:
+            w.wait()
 
     def _sh_grads_from_rgb(self, drgb_all, campos_all):
         """sum over the step's views of basis_k(dir_view) x dL/drgb_view (HIP kernel vcr_sh_grad_from_rgb)."""
@@ -230,7 +237,11 @@ class Trainer:
         loss = self._compute_loss(data, cam)
         loss.backward()
         with torch.no_grad():
-            self._allreduce_grads()
+            surgery = (it < cfg.optim.densify_until_iter and it > cfg.optim.densify_from_iter
+                       and it % cfg.optim.densification_interval == 0) \
+                or it % cfg.optim.opacity_reset_interval == 0 or it in cfg.optim.prune.iterations \
+                or (cfg.model.white_background and it == cfg.optim.densify_from_iter)
+            self._allreduce_grads(early_feature_step=not surgery)
             if it < cfg.optim.densify_until_iter:
                 self._densify_stats(data)
                 if it > cfg.optim.densify_from_iter and it % cfg.optim.densification_interval == 0:
