@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 4
+#define VCR_ABI_VERSION 5
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -161,7 +161,7 @@ int vcr_sums_elems(int k);
  * (the mask_depth_thr test of gaussian_renderer/__init__.py:125-131).  `loss` (device float[1]) receives the value. */
 int vcr_normal_loss_forward(int P, const float* pred, const float* gt, const float* wsrc, float exp_t,
                             const uint8_t* mask, const float* depth, float depth_max, double* sums3, float* loss,
-                            void* stream);
+                            int sums_prezeroed /* caller already zeroed sums3 (one memset for several losses) */, void* stream);
 int vcr_normal_loss_backward(int P, const float* pred, const float* gt, const float* wsrc, float exp_t,
                              const uint8_t* mask, const float* depth, float depth_max, const double* sums3,
                              const float* gout, float* dpred, float* dgt,
@@ -169,13 +169,13 @@ int vcr_normal_loss_backward(int P, const float* pred, const float* gt, const fl
 /* l1_scale regulariser: mean over Gaussians inside the bounding box of min_axis(exp(_scaling))
  * (trainer.py:243-245, tools/math_utils.py:50-74 with vector trans/scale).  sums3 as above. */
 int vcr_scale_reg_forward(int N, const float* scaling_raw, const float* xyz, const float* trans, const float* scale,
-                          double* sums3, float* loss, void* stream);
+                          double* sums3, float* loss, int sums_prezeroed, void* stream);
 int vcr_scale_reg_backward(int N, const float* scaling_raw, const float* xyz, const float* trans, const float* scale,
                            const double* sums3, const float* gout, float* dscaling, void* stream);
 /* l1_loss + ssim (tools/loss_utils.py:36,49-92) in one pass over [3,H,W] images.  sums2 (device, fp64) =
  * {sum|a-b|, sum ssim_map}; partials9: [9,H,W] scratch kept for backward (NULL for inference). */
 int vcr_l1_ssim_forward(int H, int W, const float* img1, const float* img2, double* sums2, float* means2 /* {l1, ssim} */,
-                        float* partials9, void* stream);
+                        float* partials9, int sums_prezeroed, void* stream);
 int vcr_l1_ssim_backward(int H, int W, const float* img1, const float* img2, const float* partials9, const float* g_l1,
                          const float* g_ssim, float* dimg1, void* stream);
 

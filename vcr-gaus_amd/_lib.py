@@ -66,14 +66,14 @@ SYMBOLS = {
     "vcr_normalize_chw_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 3),
     "vcr_normalize_chw_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 4),
     "vcr_normal_loss_forward": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
-                                          C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                          C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vcr_normal_loss_backward": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                            C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_void_p]),
-    "vcr_scale_reg_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 7),
+    "vcr_scale_reg_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "vcr_scale_reg_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 8),
     "vcr_sums_elems": (C.c_int, [C.c_int]),
-    "vcr_l1_ssim_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 6),
+    "vcr_l1_ssim_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
     "vcr_l1_ssim_backward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 7),
     "vcr_profile_enable": (None, [C.c_int]),
     "vcr_profile_num_stages": (C.c_int, []),
@@ -99,7 +99,7 @@ def load():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.vcr_abi_version() != 4:
+    if lib.vcr_abi_version() != 5:
         raise ImportError("libvcr_raster.so ABI version mismatch")
     _lib = lib
     return lib

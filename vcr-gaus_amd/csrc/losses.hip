@@ -397,8 +397,8 @@ extern "C" int vcr_normalize_chw_backward(int P, const float* in_chw, const floa
 
 extern "C" int vcr_normal_loss_forward(int P, const float* pred, const float* gt, const float* wsrc, float exp_t,
                                        const uint8_t* mask, const float* depth, float depth_max, double* sums3,
-                                       float* loss, void* stream) {
-    VCR_HIP_CHECK(hipMemsetAsync(sums3, 0, 3 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
+                                       float* loss, int sums_prezeroed, void* stream) {
+    if (!sums_prezeroed) VCR_HIP_CHECK(hipMemsetAsync(sums3, 0, 3 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
     const int blocks = min((P + 255) / 256, 2048);
     hipLaunchKernelGGL(normal_loss_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, pred, gt, wsrc, exp_t, mask,
                        depth, depth_max, sums3);
@@ -425,8 +425,8 @@ static GaussWin make_window() {
 }
 
 extern "C" int vcr_l1_ssim_forward(int H, int W, const float* img1, const float* img2, double* sums2, float* means2,
-                                   float* partials9, void* stream) {
-    VCR_HIP_CHECK(hipMemsetAsync(sums2, 0, 2 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
+                                   float* partials9, int sums_prezeroed, void* stream) {
+    if (!sums_prezeroed) VCR_HIP_CHECK(hipMemsetAsync(sums2, 0, 2 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
     const dim3 grid((W + SSIM_TX - 1) / SSIM_TX, (H + SSIM_TY - 1) / SSIM_TY, 3);
     hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, make_window(), img1, img2, sums2,
                        partials9);
@@ -484,8 +484,8 @@ __global__ void __launch_bounds__(256) scale_reg_bwd_kernel(int N, const float* 
 }  // namespace
 
 extern "C" int vcr_scale_reg_forward(int N, const float* scaling_raw, const float* xyz, const float* trans, const float* scale,
-                                     double* sums3, float* loss, void* stream) {
-    VCR_HIP_CHECK(hipMemsetAsync(sums3, 0, 3 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
+                                     double* sums3, float* loss, int sums_prezeroed, void* stream) {
+    if (!sums_prezeroed) VCR_HIP_CHECK(hipMemsetAsync(sums3, 0, 3 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
     if (N > 0)
         hipLaunchKernelGGL(scale_reg_fwd_kernel, dim3(min((N + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, N,
                            scaling_raw, xyz, trans, scale, sums3);

@@ -27,26 +27,26 @@ class _FusedLosses(torch.autograd.Function):
         lib.vcr_depth_to_normal_forward(H, W, *intr, base + 3 * P * 4, est.data_ptr(), st)
         res = torch.zeros(6, device=dev)
         n2, n3 = lib.vcr_sums_elems(2), lib.vcr_sums_elems(3)
-        sums = torch.empty(n2 + 4 * n3, dtype=torch.float64, device=dev)
+        sums = torch.zeros(n2 + 4 * n3, dtype=torch.float64, device=dev)       # ONE memset for all five reductions
         sp = lambda k: sums.data_ptr() + 8 * (n2 + (k - 1) * n3) if k else sums.data_ptr()
         rp = lambda k: res.data_ptr() + 4 * k
         gi = gt_image.detach().contiguous()
         part = torch.empty(9, H, W, device=dev)
-        _lib.check(lib.vcr_l1_ssim_forward(H, W, base, gi.data_ptr(), sp(0), rp(0), part.data_ptr(), st))
+        _lib.check(lib.vcr_l1_ssim_forward(H, W, base, gi.data_ptr(), sp(0), rp(0), part.data_ptr(), 1, st))
         sr, xz = scaling_raw.detach().contiguous(), xyz.detach().contiguous()
         if active[2]:
             _lib.check(lib.vcr_scale_reg_forward(sr.shape[0], sr.data_ptr(), xz.data_ptr(), trans.data_ptr(), scale.data_ptr(),
-                                                 sp(1), rp(2), st))
+                                                 sp(1), rp(2), 1, st))
         gn = None if gt_normal is None else gt_normal.detach().contiguous()
         m = None if mask is None else mask.detach().contiguous().view(-1).to(torch.uint8)
         dptr = base + 3 * P * 4 if depth_max > 0 else None
         if active[3]:
-            _lib.check(lib.vcr_normal_loss_forward(P, normal.data_ptr(), gn.data_ptr(), None, 0.0, None, None, 0.0, sp(2), rp(3), st))
+            _lib.check(lib.vcr_normal_loss_forward(P, normal.data_ptr(), gn.data_ptr(), None, 0.0, None, None, 0.0, sp(2), rp(3), 1, st))
         if active[4]:
             _lib.check(lib.vcr_normal_loss_forward(P, est.data_ptr(), gn.data_ptr(), normal.data_ptr(), float(exp_t),
-                                                   None if m is None else m.data_ptr(), dptr, float(depth_max), sp(3), rp(4), st))
+                                                   None if m is None else m.data_ptr(), dptr, float(depth_max), sp(3), rp(4), 1, st))
         if active[5]:
-            _lib.check(lib.vcr_normal_loss_forward(P, est.data_ptr(), normal.data_ptr(), None, 0.0, None, None, 0.0, sp(4), rp(5), st))
+            _lib.check(lib.vcr_normal_loss_forward(P, est.data_ptr(), normal.data_ptr(), None, 0.0, None, None, 0.0, sp(4), rp(5), 1, st))
         ctx.save_for_backward(o, normal, est, gi, part, sums, sr, xz, gn, m, wvec, trans, scale)
         ctx.meta = (H, W, C, tuple(intr), tuple(active), float(exp_t), float(depth_max), n2, n3)
         # total = sum_k w_k L_k with the ssim entry meaning (1 - ssim): wvec[1] = -w_ssim, constant +w_ssim added here

@@ -12,6 +12,19 @@ from .gaussian_model import fused_activate
 from .normal_utils import compute_normals, normalize_rendered_normal
 
 
+_ZEROS = {}
+
+
+def _zero_holder(like):
+    """An [N,3] zero tensor that is never written (the rasterizer only reads the holders' shape), cached per size."""
+    key = (like.shape[0], like.device)
+    z = _ZEROS.get(key)
+    if z is None:
+        _ZEROS.clear()
+        z = _ZEROS[key] = torch.zeros_like(like)
+    return z
+
+
 def _settings(cam, pc, bg_color, scaling_modifier, debug, f_count):
     return GaussianRasterizationSettings(
         image_height=int(cam.image_height), image_width=int(cam.image_width),
@@ -35,8 +48,9 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
     dev = pc.get_xyz.device
     # gradient holders for the 2D means (`:31-37`); leaves, so `.grad` is populated without the reference's `+ 0` copies
     grad_on = torch.is_grad_enabled()
-    screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=grad_on)
-    screenspace_points_densify = torch.zeros_like(pc.get_xyz, requires_grad=grad_on)
+    z = _zero_holder(pc.get_xyz)        # shared all-zero storage; fresh leaf views so each call gets its own .grad
+    screenspace_points = z.detach().requires_grad_(grad_on)
+    screenspace_points_densify = z.detach().requires_grad_(grad_on)
 
     rs = _settings(viewpoint_camera, pc, bg_color, scaling_modifier, cfg.pipline.debug, 0)
     lw = cfg.optim.loss_weight

@@ -19,7 +19,7 @@ class _L1SSIM(torch.autograd.Function):
         need = img1.requires_grad
         part = torch.empty(9, H, W, dtype=torch.float32, device=a.device) if need else None
         _lib.check(lib.vcr_l1_ssim_forward(H, W, a.data_ptr(), b.data_ptr(), sums.data_ptr(), res.data_ptr(),
-                                           part.data_ptr() if need else None, _lib.stream_of(a)))
+                                           part.data_ptr() if need else None, 0, _lib.stream_of(a)))
         ctx.save_for_backward(a, b, part)
         return res[0], res[1]
 
@@ -69,7 +69,7 @@ class _NormalLoss(torch.autograd.Function):
         _lib.check(lib.vcr_normal_loss_forward(P, p.data_ptr(), g.data_ptr(), None if w is None else w.data_ptr(),
                                                float(exp_t), None if m is None else m.data_ptr(),
                                                None if d is None else d.data_ptr(), float(depth_max), sums.data_ptr(),
-                                               loss.data_ptr(), _lib.stream_of(p)))
+                                               loss.data_ptr(), 0, _lib.stream_of(p)))
         ctx.save_for_backward(p, g, w, m, d, sums)
         ctx.exp_t, ctx.shape, ctx.gt_grad, ctx.depth_max = float(exp_t), pred.shape, bool(gt_grad), float(depth_max)
         return loss[0]
@@ -109,7 +109,7 @@ class _ScaleReg(torch.autograd.Function):
         sums = torch.empty(lib.vcr_sums_elems(3), dtype=torch.float64, device=s.device)
         loss = torch.empty(1, dtype=torch.float32, device=s.device)
         _lib.check(lib.vcr_scale_reg_forward(s.shape[0], s.data_ptr(), x.data_ptr(), t.data_ptr(), sc.data_ptr(),
-                                             sums.data_ptr(), loss.data_ptr(), _lib.stream_of(s)))
+                                             sums.data_ptr(), loss.data_ptr(), 0, _lib.stream_of(s)))
         ctx.save_for_backward(s, x, t, sc, sums)
         return loss[0]
 

@@ -93,7 +93,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         fc = int(rs.f_count)
         C = 8 + S + int(num_dist)
         out = torch.empty((C if fc == 0 else 3, H, W), dtype=torch.float32, device=dev) if fc != 3 else None
-        radii = torch.zeros(N, dtype=torch.int32, device=dev)
+        radii = torch.empty(N, dtype=torch.int32, device=dev)      # fully written by the preprocess kernel
         count = torch.zeros(N, dtype=torch.int32, device=dev) if fc != 0 else None
         import os as _os
         if fc == 0 and _os.environ.get("VCR_TIMING"):       # experiment builds only (-DVCR_TIMING)
