@@ -9,6 +9,7 @@
 // sort primitives come from rocPRIM (plain library primitives); everything else is hand-written.
 #include "vcr_common.h"
 #include <cstring>
+#include <cstdlib>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
@@ -87,6 +88,18 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t R, const uint3
     if (i == R - 1) ranges[k].y = (uint32_t)R;
 }
 
+// Longest-first order, folded boustrophedon-wise with the period of the chip (256 CUs: block b lands on XCD b % 8 and,
+// within it, on the next CU in turn): CU c then receives ranks c, 511-c, 512+c, 1023-c, ... so the per-CU sums of list
+// lengths even out instead of CU 0 collecting the heaviest tile of every band.
+__global__ void snake_order_kernel(int T, const uint32_t* __restrict__ sorted, uint32_t* __restrict__ order) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T) return;
+    const int band = i >> 8, j = i & 255;
+    const int band_len = min(256, T - (band << 8));
+    const int src = (band & 1) ? (band << 8) + (band_len - 1 - j) : i;
+    order[i] = (j < band_len) ? sorted[src] : sorted[i];
+}
+
 }  // namespace
 
 size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits) {
@@ -131,8 +144,14 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
     VCR_HIP_CHECK(hipGetLastError());
     // longest-first tile order; keys_a / vals_a are free again and hold >= 2*T words each (caller guarantees)
     uint32_t* lk = keys_a; uint32_t* lv = vals_a; uint32_t* lk2 = keys_a + num_tiles;
+    static const bool no_lpt = getenv("VCR_NO_LPT") != nullptr;          // experiment switch
+    if (no_lpt) return vcr_launch_tile_len(num_tiles, ranges, lk, tile_order, st);
     if (vcr_launch_tile_len(num_tiles, ranges, lk, lv, st)) return 1;
     tb = temp_bytes;
-    VCR_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, lk, lk2, lv, tile_order, (size_t)num_tiles, 0, 32, st));
+    static const bool no_snake = getenv("VCR_NO_SNAKE") != nullptr;      // experiment switch
+    uint32_t* sorted = no_snake ? tile_order : lv + num_tiles;           // vals_a has >= 2*T words
+    VCR_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, lk, lk2, lv, sorted, (size_t)num_tiles, 0, 32, st));
+    if (!no_snake)
+        hipLaunchKernelGGL(snake_order_kernel, dim3((num_tiles + 255) / 256), dim3(256), 0, st, num_tiles, sorted, tile_order);
     return 0;
 }
