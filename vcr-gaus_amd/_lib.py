@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvcr_raster.so")
+# VCR_LIB: another build of the same library (A/B measurements of kernel variants); never a different backend
+LIB_PATH = os.environ.get("VCR_LIB") or os.path.join(_HERE, "libvcr_raster.so")
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int32)

@@ -29,25 +29,34 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
-// Reduce 16 per-lane values over the wave with a halving butterfly: v_permlane32_swap / v_permlane16_swap
-// exchange half of the live values per step (8+4 swaps), then 4 row rotations finish the remaining 4.
-// On return lane l holds, in out[0..3], the wave totals of v[8*(l>>5) + 4*((l>>4)&1) + 0..3].
-__device__ __forceinline__ void wave_reduce16(const float v[16], float out[4]) {
-    float u[8];
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float row_sum16(float x) {
+    x = dpp_add<0x128>(x);
+    x = dpp_add<0x124>(x);
+    x = dpp_add<0x122>(x);
+    return dpp_add<0x121>(x);
+}
+
+// Reduce 16 per-lane values (8 pairs) over the wave with a halving butterfly: v_permlane32_swap / v_permlane16_swap
+// exchange half of the live values per step (8+4 swaps, the sums as packed adds), then 4 row rotations finish the
+// remaining 4.  On return lane l holds, in out[0..3], the wave totals of slots 8*(l>>5) + 4*((l>>4)&1) + 0..3
+// (slot 2j = v[j].x, slot 2j+1 = v[j].y).
+__device__ __forceinline__ void wave_reduce16(const f2 v[8], float out[4]) {
+    f2 u[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[k]), __float_as_uint(v[8 + k]), false, false);
-        u[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    for (int j = 0; j < 4; ++j) {
+        auto r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j].x), __float_as_uint(v[4 + j].x), false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j].y), __float_as_uint(v[4 + j].y), false, false);
+        u[j] = f2{__uint_as_float(r0[0]), __uint_as_float(r1[0])} + f2{__uint_as_float(r0[1]), __uint_as_float(r1[1])};
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[k]), __float_as_uint(u[4 + k]), false, false);
-        float x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-        x = dpp_add<0x128>(x);
-        x = dpp_add<0x124>(x);
-        x = dpp_add<0x122>(x);
-        x = dpp_add<0x121>(x);
-        out[k] = x;
+    for (int j = 0; j < 2; ++j) {
+        auto r0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[j].x), __float_as_uint(u[2 + j].x), false, false);
+        auto r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[j].y), __float_as_uint(u[2 + j].y), false, false);
+        const f2 x = f2{__uint_as_float(r0[0]), __uint_as_float(r1[0])} + f2{__uint_as_float(r0[1]), __uint_as_float(r1[1])};
+        out[2 * j] = row_sum16(x.x);
+        out[2 * j + 1] = row_sum16(x.y);
     }
 }
 
@@ -128,6 +137,25 @@ __device__ __forceinline__ bool quad_touch(const float4 q0, const float4 q1, flo
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// Packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue two fp32 lanes-worth per instruction on CDNA3/4):
+// the shading loops are VALU-issue-bound, so everything that comes in natural pairs is written on this type.
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
+
+// Exponent of one Gaussian at one pixel in base 2: alpha_raw = opacity * exp(power) = 2^e with
+//   e = log2(opacity) + 0.5 * (u . d),  u = s d,  s = -log2(e) * conic (scaled once per Gaussian by its culler lane),
+// d = (gaussian centre - pixel).  `u` (= d e / d d) is what the backward needs anyway; `hs` = u . d has the sign of the
+// reference's `power`.  Forward and backward share this function so that their hit decisions agree bit for bit.
+__device__ __forceinline__ float gauss_exponent(f2 d, f2 sAC, float sB, float lop, f2& u, float& hs) {
+    const f2 t = splat(sB) * d.yx;
+    u = pk_fma(sAC, d, t);
+    const f2 h = u * d;
+    hs = h.x + h.y;
+    return fmaf(0.5f, hs, lop);
+}
+#define VCR_L2E 1.4426950408889634f
+#define VCR_LN2 0.6931471805599453f
+
 template <int S, bool ISECT, int FC, int ND>
 __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
                                                                const float* __restrict__ semv,
@@ -149,12 +177,12 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
     long long t_cull = 0, t_surv = 0, t_mark = 0;
 #endif
     const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8), Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8);
-    const float fx = (float)pm.x, fy = (float)pm.y;
+    const f2 fxy = {(float)pm.x, (float)pm.y};
     float rx = 0.f, ry = 0.f, rz = 1.f;
     if (ISECT && pm.inside) { rx = a.dirs[pm.pix]; ry = a.dirs[P + pm.pix]; rz = a.dirs[2 * P + pm.pix]; }
 
     float T = 1.f;
-    float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, A = 0.f;
+    f2 acc_c01 = {0.f, 0.f}, acc_c2n = {0.f, 0.f}, acc_n12 = {0.f, 0.f}, acc_da = {0.f, 0.f};   // (C0,C1) (C2,N0) (N1,N2) (D,A)
     float SM[S > 0 ? S : 1];
 #pragma unroll
     for (int k = 0; k < S; ++k) SM[k] = 0.f;
@@ -184,16 +212,19 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
         n_chunks++; n_surv += __popcll(m);
         { const long long t2 = wall_clock64(); t_cull += t2 - t_mark; t_mark = t2; }
 #endif
+        // per-lane (= per Gaussian) rescale for the shading loop, see gauss_exponent()
+        const float sA = -VCR_L2E * q1.x, sB = -VCR_L2E * q1.y, sC = -VCR_L2E * q1.z;
+        const float lop = __builtin_amdgcn_logf(q0.w);                  // v_log_f32 = log2
         while (m) {
             const int b = __builtin_ctzll(m);
             m &= m - 1;
-            const float gxp = bcast(q0.x, b), gyp = bcast(q0.y, b), op = bcast(q0.w, b);
-            const float ca = bcast(q1.x, b), cb = bcast(q1.y, b), cc = bcast(q1.z, b);
-            const float dx = gxp - fx, dy = gyp - fy;
-            const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
-            const float alpha = fminf(VCR_ALPHA_MAX, op * __expf(power));
-            bool hit = !done && power <= 0.f && alpha >= VCR_ALPHA_MIN;
-            const float test_T = T * (1.f - alpha);
+            const f2 gxy = {bcast(q0.x, b), bcast(q0.y, b)};
+            const f2 sAC = {bcast(sA, b), bcast(sC, b)};
+            f2 u; float hs;
+            const float e = gauss_exponent(gxy - fxy, sAC, bcast(sB, b), bcast(lop, b), u, hs);
+            const float alpha = fminf(VCR_ALPHA_MAX, __builtin_amdgcn_exp2f(e));
+            bool hit = !done && hs <= 0.f && alpha >= VCR_ALPHA_MIN;
+            const float test_T = fmaf(-alpha, T, T);                    // T (1 - alpha)
             if (hit && test_T < VCR_T_EPS) { done = true; hit = false; }
             const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
             // no early `continue` when nobody is hit (8 % of survivors): the shading below is then a no-op with w = 0, and
@@ -211,23 +242,25 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
                     if (FC != 3) atomicAdd(score + gid, ws);
                 }
             }
-            const float cr = bcast(q2.x, b), cg = bcast(q2.y, b), cbl = bcast(q2.z, b);
+            const f2 c01 = {bcast(q2.x, b), bcast(q2.y, b)};
+            const f2 c2n = {bcast(q2.z, b), bcast(q3.x, b)};
+            const f2 n12 = {bcast(q3.y, b), bcast(q3.z, b)};
             float dep = bcast(q0.z, b);
-            const float nx = bcast(q3.x, b), ny = bcast(q3.y, b), nz = bcast(q3.z, b);
             if (ISECT) {
                 const float pl = bcast(q1.w, b);
-                const float den = nx * rx + ny * ry + nz * rz;
+                const float den = c2n.y * rx + n12.x * ry + n12.y * rz;
                 if (den > VCR_PLANE_EPS) dep = pl * fast_rcp(den) * rz;
             }
-            C0 += w * cr; C1 += w * cg; C2 += w * cbl;
-            D += w * dep;
+            const f2 ww = splat(w);
+            acc_c01 = pk_fma(ww, c01, acc_c01);
+            acc_c2n = pk_fma(ww, c2n, acc_c2n);
+            acc_n12 = pk_fma(ww, n12, acc_n12);
+            acc_da = pk_fma(ww, f2{dep, 1.f}, acc_da);
             if (ND == 2) M2 += w * dep * dep;
             if (ND == 1) {
                 const float md = -zc_map * VCR_ZNEAR * fast_rcp(dep);     // shifted by the constant far/(far-near): same distortion, no cancellation
                 M1 += w * md; M2 += w * md * md;
             }
-            N0 += w * nx; N1 += w * ny; N2 += w * nz;
-            A += w;
             if (S > 0) {
                 const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, b);
 #pragma unroll
@@ -250,6 +283,8 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
         reinterpret_cast<long long*>(count)[4 * (blockIdx.x * 4 + wv) + 3] = (t_cull << 32) | (t_surv & 0xFFFFFFFF);
     }
 #endif
+    const float C0 = acc_c01.x, C1 = acc_c01.y, C2 = acc_c2n.x, N0 = acc_c2n.y, N1 = acc_n12.x, N2 = acc_n12.y;
+    const float D = acc_da.x, A = acc_da.y;
     if (pm.inside) {
         final_T[pm.pix] = T;
         n_contrib[pm.pix] = last;
@@ -279,7 +314,7 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
 }
 
 template <int S, bool ISECT, int ND>
-__global__ void __launch_bounds__(256) composite_bwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 0 && ND == 0) ? 6 : 4))) composite_bwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
                                                                const float* __restrict__ semv,
                                                                const uint32_t* __restrict__ point_list,
                                                                const uint2* __restrict__ ranges,
@@ -296,7 +331,7 @@ __global__ void __launch_bounds__(256) composite_bwd_v2_kernel(VcrRasterArgs a, 
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8), Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8);
-    const float fx = (float)pm.x, fy = (float)pm.y;
+    const f2 fxy = {(float)pm.x, (float)pm.y};
     float rx = 0.f, ry = 0.f, rz = 1.f;
     if (ISECT && pm.inside) { rx = a.dirs[pm.pix]; ry = a.dirs[P + pm.pix]; rz = a.dirs[2 * P + pm.pix]; }
 
@@ -319,7 +354,9 @@ __global__ void __launch_bounds__(256) composite_bwd_v2_kernel(VcrRasterArgs a, 
     uint32_t maxc = lastc;
     for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, o));
     if (maxc == 0) return;                                 // wave-uniform
-    float T = Tf, Asuf = 0.f;
+    // Bsuf = bgdot + sum over the Gaussians behind the current one of w_j (f_j . g)
+    float T = Tf, Bsuf = bgdot;
+    const f2 g01 = {g[0], g[1]}, g24 = {g[2], g[4]}, g56 = {g[5], g[6]}, ryz = {ry, rz};
 
     int chunk = (int)((maxc - 1) / 64);                    // chunks of 64 list entries, walked back to front
     uint32_t id, nid; float4 q0, q1, q2, q3; bool valid, nvalid;
@@ -335,40 +372,48 @@ __global__ void __launch_bounds__(256) composite_bwd_v2_kernel(VcrRasterArgs a, 
         live_box(__builtin_amdgcn_ballot_w64(lastc > (uint32_t)chunk * 64u), X0, Y0, bx0, by0, bw, bh);
         const bool keep = valid && quad_touch(q0, q1, bx0, by0, bw, bh);
         unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        // per-lane (= per Gaussian) rescale for the shading loop, see gauss_exponent()
+        const float sA = -VCR_L2E * q1.x, sB = -VCR_L2E * q1.y, sC = -VCR_L2E * q1.z;
+        const float lop = __builtin_amdgcn_logf(q0.w);
         while (m) {
             const int b = 63 - __builtin_clzll(m);
             m &= ~(1ull << b);
             const uint32_t idx1 = (uint32_t)chunk * 64u + (uint32_t)b + 1u;
-            const float gxp = bcast(q0.x, b), gyp = bcast(q0.y, b), op = bcast(q0.w, b);
-            const float ca = bcast(q1.x, b), cb = bcast(q1.y, b), cc = bcast(q1.z, b);
-            const float dx = gxp - fx, dy = gyp - fy;
-            const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
-            const float G = __expf(power);
-            const float araw = op * G;
-            const float alpha = fminf(VCR_ALPHA_MAX, araw);
-            const bool hit = idx1 <= lastc && power <= 0.f && alpha >= VCR_ALPHA_MIN;
+            const f2 gxy = {bcast(q0.x, b), bcast(q0.y, b)};
+            const f2 sAC = {bcast(sA, b), bcast(sC, b)};
+            const f2 d = gxy - fxy;
+            f2 u; float hs;
+            const float e = gauss_exponent(d, sAC, bcast(sB, b), bcast(lop, b), u, hs);
+            const float araw = __builtin_amdgcn_exp2f(e);           // opacity * G, before the 0.99 clamp
+            const bool hit = idx1 <= lastc && hs <= 0.f && araw >= VCR_ALPHA_MIN;
             if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
-            const float cr = bcast(q2.x, b), cg = bcast(q2.y, b), cbl = bcast(q2.z, b);
+            const f2 c01 = {bcast(q2.x, b), bcast(q2.y, b)};
+            const f2 c2n = {bcast(q2.z, b), bcast(q3.x, b)};
+            const f2 n12 = {bcast(q3.y, b), bcast(q3.z, b)};
             const float zc = bcast(q0.z, b), pl = bcast(q1.w, b);
-            const float nx = bcast(q3.x, b), ny = bcast(q3.y, b), nz = bcast(q3.z, b);
             const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, b);
-            // branch-free: every value is a product with w or dL/dpower, which are forced to 0 on lanes without a hit
-            float v[16];
+            // branch-free: lanes without a hit run with alpha = 0, which makes T, Bsuf and every slot below a no-op / zero.
+            // Slots are RAW sums; preprocess_bwd applies the per-Gaussian constants (GradRec in vcr_common.h).
+            f2 v[8];
             float vs[S > 0 ? S : 1];
             {
+                const float ah = hit ? araw : 0.f;
+                const float alpha = fminf(VCR_ALPHA_MAX, ah);
                 const float inv1ma = fast_rcp(1.f - alpha);
-                const float Tn = T * inv1ma;                       // transmittance in front of this Gaussian
-                T = hit ? Tn : T;
-                const float w = hit ? alpha * Tn : 0.f;
+                T *= inv1ma;                                        // transmittance in front of this Gaussian
+                const float w = alpha * T;
                 float dep = zc, iden = 0.f;
                 bool isect = false;
                 if (ISECT) {
-                    const float den = nx * rx + ny * ry + nz * rz;
+                    const float den = c2n.y * rx + n12.x * ry + n12.y * rz;
                     isect = den > VCR_PLANE_EPS;
                     iden = isect ? fast_rcp(den) : 0.f;
                     dep = isect ? pl * iden * rz : zc;
                 }
-                float fg = cr * g[0] + cg * g[1] + cbl * g[2] + dep * g[3] + nx * g[4] + ny * g[5] + nz * g[6] + g[7];
+                f2 fa = pk_fma(c01, g01, f2{g[7], 0.f});
+                fa = pk_fma(c2n, g24, fa);
+                fa = pk_fma(n12, g56, fa);
+                float fg = fmaf(dep, g[3], fa.x + fa.y);
                 if (ND == 2) fg += dep * dep * gm2;
                 float md = 0.f, idep = 0.f;
                 if (ND == 1) {
@@ -378,22 +423,24 @@ __global__ void __launch_bounds__(256) composite_bwd_v2_kernel(VcrRasterArgs a, 
                 }
 #pragma unroll
                 for (int k = 0; k < S; ++k) fg += semv[(size_t)gid * S + k] * g[8 + k];
-                const float dL_dalpha = hit ? Tn * fg - (Asuf + bgdot) * inv1ma : 0.f;
-                Asuf += w * fg;
-                const float dL_dpow = hit ? araw * dL_dalpha : 0.f;       // alpha = o*G, clamp ignored (public rasterizer)
-                const float gdx = -(ca * dx + cb * dy) * dL_dpow;
-                const float gdy = -(cc * dy + cb * dx) * dL_dpow;
-                v[0] = gdx; v[1] = gdy; v[2] = fabsf(gdx); v[3] = fabsf(gdy);
-                v[4] = -0.5f * dx * dx * dL_dpow; v[5] = -dx * dy * dL_dpow; v[6] = -0.5f * dy * dy * dL_dpow;
-                v[7] = hit ? G * dL_dalpha : 0.f;
-                v[8] = w * g[0]; v[9] = w * g[1]; v[10] = w * g[2];
+                const float dL_dalpha = fmaf(T, fg, -Bsuf * inv1ma);
+                Bsuf = fmaf(w, fg, Bsuf);
+                const float pw = ah * dL_dalpha;                    // dL/dpower; alpha = o*G, clamp ignored (public rasterizer)
+                const f2 pp = splat(pw);
+                v[0] = u * pp;                                      // log2(e) * dL/d(centre)
+                v[1] = f2{fabsf(v[0].x), fabsf(v[0].y)};
+                const f2 dp = d * pp;
+                v[2] = d * dp;                                      // dx^2 p, dy^2 p   (-2 dL/dA, -2 dL/dC)
+                v[3] = f2{d.x * dp.y, pw};                          // dx dy p (-dL/dB), p (opacity * dL/dopacity)
+                const f2 ww = splat(w);
+                v[4] = ww * g01;
                 const float wd = w * (ND == 2 ? g[3] + 2.f * dep * gm2
                                               : (ND == 1 ? g[3] + (gm1 + 2.f * md * gm2) * zc_map * VCR_ZNEAR * idep * idep : g[3]));
+                v[5] = f2{w * g24.x, isect ? 0.f : wd};
                 const float k1 = wd * rz * iden;                   // d dep / d plane (0 when the centre depth was used)
                 const float k2 = -k1 * pl * iden;
-                v[11] = isect ? 0.f : wd;
-                v[12] = k1;
-                v[13] = w * g[4] + k2 * rx; v[14] = w * g[5] + k2 * ry; v[15] = w * g[6] + k2 * rz;
+                v[6] = f2{k1, fmaf(k2, rx, w * g24.y)};
+                v[7] = pk_fma(splat(k2), ryz, ww * g56);
 #pragma unroll
                 for (int k = 0; k < S; ++k) vs[k] = w * g[8 + k];
             }

@@ -318,7 +318,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
         const Cam cam = load_cam(a);
         const float* V = cam.V;
         const float* P = cam.P;
-        const GradRec gr = sgrad[i];
+        GradRec gr = sgrad[i];
+        gr.finish(a.opacities[i]);
         const float p[3] = {a.means3D[i3], a.means3D[i3 + 1], a.means3D[i3 + 2]};
         Proj pr;
         project(a, cam, p, pr);

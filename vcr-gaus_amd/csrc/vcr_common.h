@@ -29,11 +29,21 @@ static_assert(sizeof(GeomRec) == 64, "GeomRec must be one 64-byte line");
 
 // Per-Gaussian screen-space gradient record written by the compositing backward (atomics) and
 // consumed by the preprocess backward.
+// The first eight slots are RAW sums over pixels of p = dL/dpower (the shading loop is VALU-bound, so the
+// per-Gaussian constants are applied once by GradRec::finish() in the consumer): with d = centre - pixel,
+//   gx,gy = log2(e) * dL/d(centre); agx,agy = the same with |.| per pixel; ca = sum dx^2 p = -2 dL/dA,
+//   cc = sum dy^2 p = -2 dL/dC, cb = sum dx dy p = -dL/dB, opacity = sum p = opacity * dL/dopacity.
 struct __attribute__((aligned(16))) GradRec {
     float gx, gy, agx, agy;       // dL/dpx, dL/dpy, sum|dL/dpx|, sum|dL/dpy|
-    float ca, cb, cc, opacity;    // dL/dconic, dL/dopacity
+    float ca, cc, cb, opacity;    // dL/dconic (A, C, B), dL/dopacity
     float r, g, b, z;             // dL/drgb, dL/dz (centre depth)
     float plane, nx, ny, nz;      // dL/dplane, dL/dnormal
+    __host__ __device__ void finish(float op) {
+        const float ln2 = 0.6931471805599453f;
+        gx *= ln2; gy *= ln2; agx *= ln2; agy *= ln2;
+        ca *= -0.5f; cc *= -0.5f; cb = -cb;
+        opacity = op > 0.f ? opacity / op : 0.f;
+    }
 };
 static_assert(sizeof(GradRec) == 64, "GradRec must be 64 bytes");
 #define VCR_GRAD_FLOATS 16
