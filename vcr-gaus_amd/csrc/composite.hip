@@ -30,6 +30,7 @@ __device__ __forceinline__ float wave_sum(float x) {
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float row_sum16(float x) {
     x = dpp_add<0x128>(x);
@@ -171,6 +172,8 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
     const uint2 range = ranges[tile];
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ float4 s_rec_all[4 * 256];                 // per wave: 4 planes x 64 slots x 16 B (conflict-free b128 writes)
+    float4* const srec = s_rec_all + wv * 256;
 #ifdef VCR_TIMING
     const long long t_start = wall_clock64();
     int n_surv = 0, n_hit = 0, n_chunks = 0;
@@ -212,62 +215,95 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
         n_chunks++; n_surv += __popcll(m);
         { const long long t2 = wall_clock64(); t_cull += t2 - t_mark; t_mark = t2; }
 #endif
-        // per-lane (= per Gaussian) rescale for the shading loop, see gauss_exponent()
-        const float sA = -VCR_L2E * q1.x, sB = -VCR_L2E * q1.y, sC = -VCR_L2E * q1.z;
-        const float lop = __builtin_amdgcn_logf(q0.w);                  // v_log_f32 = log2
-        while (m) {
-            const int b = __builtin_ctzll(m);
+        // Survivors stage their record -- rescaled for the shading loop, see gauss_exponent() -- in this wave's private LDS
+        // planes; the shading loop then fetches one survivor per iteration with four wave-uniform ds_read_b128 (LDS
+        // broadcast reads, 4 CU cycles each) one survivor ahead.  v_readlane_b32 costs 8.3 SIMD cycles on gfx950
+        // (profiles/microbench), so the 14 register broadcasts it replaces were half of this loop.
+        if (keep) {
+            srec[0 * 64 + lane] = make_float4(q0.x, q0.y, -VCR_L2E * q1.x, -VCR_L2E * q1.z);
+            srec[1 * 64 + lane] = make_float4(-VCR_L2E * q1.y, __builtin_amdgcn_logf(q0.w), q0.z, q1.w);   // v_log_f32 = log2
+            srec[2 * 64 + lane] = make_float4(q2.x, q2.y, q2.z, q3.x);
+            srec[3 * 64 + lane] = make_float4(q3.y, q3.z, __uint_as_float(id), 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();          // same wave, DS ops execute in order: no s_barrier needed
+        // Shading of one survivor whose staged record sits in R0..R3 (a macro, not a lambda: captured-by-reference bools
+        // become byte-sized phis in VGPRs instead of lane masks in SGPRs).  No early skip when nobody is hit (8 % of
+        // survivors): the shading is then a no-op with w = 0 and a single-block body spares the phi copies of the
+        // accumulators; the "whole quad saturated" exit is tested once per chunk (below), not per survivor.
+#define VCR_SHADE_FWD(R, B)                                                                                              \
+        do {                                                                                                             \
+            const float4 r0 = R##0, r1 = R##1, r2 = R##2, r3 = R##3; const int sb_ = (B);                                  \
+            const f2 gxy = {r0.x, r0.y}, sAC = {r0.z, r0.w};                                                             \
+            f2 u; float hs;                                                                                              \
+            const float e = gauss_exponent(gxy - fxy, sAC, r1.x, r1.y, u, hs);                                           \
+            const float alpha = fminf(VCR_ALPHA_MAX, __builtin_amdgcn_exp2f(e));                                         \
+            bool hit = !done && hs <= 0.f && alpha >= VCR_ALPHA_MIN;                                                     \
+            const float test_T = fmaf(-alpha, T, T);                                                                     \
+            if (hit && test_T < VCR_T_EPS) { done = true; hit = false; }                                                 \
+            const float w = hit ? alpha * T : 0.f;                                                                       \
+            if (FC != 0) {                                                                                               \
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);                                          \
+                if (hm != 0) {                                                                                           \
+                    const float ws = wave_sum(w);                                                                        \
+                    if (lane == 0) {                                                                                     \
+                        const uint32_t gid = __float_as_uint(r3.z);                                                      \
+                        atomicAdd(count + gid, (int)__popcll(hm));                                                       \
+                        if (FC != 3) atomicAdd(score + gid, ws);                                                         \
+                    }                                                                                                    \
+                }                                                                                                        \
+            }                                                                                                            \
+            const f2 c01 = {r2.x, r2.y}, c2n = {r2.z, r2.w}, n12 = {r3.x, r3.y};                                         \
+            float dep = r1.z;                                                                                            \
+            if (ISECT) {                                                                                                 \
+                const float den = c2n.y * rx + n12.x * ry + n12.y * rz;                                                  \
+                if (den > VCR_PLANE_EPS) dep = r1.w * fast_rcp(den) * rz;                                                \
+            }                                                                                                            \
+            const f2 ww = splat(w);                                                                                      \
+            acc_c01 = pk_fma(ww, c01, acc_c01);                                                                          \
+            acc_c2n = pk_fma(ww, c2n, acc_c2n);                                                                          \
+            acc_n12 = pk_fma(ww, n12, acc_n12);                                                                          \
+            acc_da = pk_fma(ww, f2{dep, 1.f}, acc_da);                                                                   \
+            if (ND == 2) M2 += w * dep * dep;                                                                            \
+            if (ND == 1) {                                                                                               \
+                const float md = -zc_map * VCR_ZNEAR * fast_rcp(dep);                                                    \
+                M1 += w * md; M2 += w * md * md;                                                                         \
+            }                                                                                                            \
+            if (S > 0) {                                                                                                 \
+                const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(r3.z));               \
+_Pragma("unroll")                                                                                                        \
+                for (int k = 0; k < S; ++k) SM[k] += w * semv[(size_t)gid * S + k];                                      \
+            }                                                                                                            \
+            T = hit ? test_T : T;                                                                                        \
+            last = hit ? pos - range.x + (uint32_t)sb_ + 1u : last;                                                        \
+        } while (0)
+        // the empty asm (memory clobber) keeps the compiler from sinking the prefetch of the other buffer below the
+        // shading of the current one; it does not wait for the data
+#define VCR_LDS_FETCH(R, B)                                                                                   \
+        do {                                                                                                  \
+            R##0 = srec[(B)]; R##1 = srec[64 + (B)]; R##2 = srec[128 + (B)]; R##3 = srec[192 + (B)];          \
+            asm volatile("" ::: "memory");                                                                    \
+        } while (0)
+        if (m) {
+            float4 A0, A1, A2, A3, B0, B1, B2, B3;
+            int b = __builtin_ctzll(m);
             m &= m - 1;
-            const f2 gxy = {bcast(q0.x, b), bcast(q0.y, b)};
-            const f2 sAC = {bcast(sA, b), bcast(sC, b)};
-            f2 u; float hs;
-            const float e = gauss_exponent(gxy - fxy, sAC, bcast(sB, b), bcast(lop, b), u, hs);
-            const float alpha = fminf(VCR_ALPHA_MAX, __builtin_amdgcn_exp2f(e));
-            bool hit = !done && hs <= 0.f && alpha >= VCR_ALPHA_MIN;
-            const float test_T = fmaf(-alpha, T, T);                    // T (1 - alpha)
-            if (hit && test_T < VCR_T_EPS) { done = true; hit = false; }
-            const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
-            // no early `continue` when nobody is hit (8 % of survivors): the shading below is then a no-op with w = 0, and
-            // keeping the loop body a single block spares the ~10 v_mov phi copies of the accumulators per iteration; the
-            // "whole quad saturated" exit is tested once per chunk (below), not per survivor
-#ifdef VCR_TIMING
-            n_hit += hm != 0;
-#endif
-            const float w = hit ? alpha * T : 0.f;
-            if (FC != 0 && hm != 0) {
-                const float ws = wave_sum(w);
-                if (lane == 0) {
-                    const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, b);
-                    atomicAdd(count + gid, (int)__popcll(hm));
-                    if (FC != 3) atomicAdd(score + gid, ws);
-                }
+            VCR_LDS_FETCH(A, b);
+            for (;;) {                                   // ping-pong: the other buffer is in flight while one is shaded
+                int nb = m ? __builtin_ctzll(m) : 0;
+                bool more = m != 0;
+                m &= m - 1;
+                VCR_LDS_FETCH(B, nb);
+                VCR_SHADE_FWD(A, b);
+                if (!more) break;
+                b = nb;
+                nb = m ? __builtin_ctzll(m) : 0;
+                more = m != 0;
+                m &= m - 1;
+                VCR_LDS_FETCH(A, nb);
+                VCR_SHADE_FWD(B, b);
+                if (!more) break;
+                b = nb;
             }
-            const f2 c01 = {bcast(q2.x, b), bcast(q2.y, b)};
-            const f2 c2n = {bcast(q2.z, b), bcast(q3.x, b)};
-            const f2 n12 = {bcast(q3.y, b), bcast(q3.z, b)};
-            float dep = bcast(q0.z, b);
-            if (ISECT) {
-                const float pl = bcast(q1.w, b);
-                const float den = c2n.y * rx + n12.x * ry + n12.y * rz;
-                if (den > VCR_PLANE_EPS) dep = pl * fast_rcp(den) * rz;
-            }
-            const f2 ww = splat(w);
-            acc_c01 = pk_fma(ww, c01, acc_c01);
-            acc_c2n = pk_fma(ww, c2n, acc_c2n);
-            acc_n12 = pk_fma(ww, n12, acc_n12);
-            acc_da = pk_fma(ww, f2{dep, 1.f}, acc_da);
-            if (ND == 2) M2 += w * dep * dep;
-            if (ND == 1) {
-                const float md = -zc_map * VCR_ZNEAR * fast_rcp(dep);     // shifted by the constant far/(far-near): same distortion, no cancellation
-                M1 += w * md; M2 += w * md * md;
-            }
-            if (S > 0) {
-                const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, b);
-#pragma unroll
-                for (int k = 0; k < S; ++k) SM[k] += w * semv[(size_t)gid * S + k];
-            }
-            T = hit ? test_T : T;
-            last = hit ? pos - range.x + (uint32_t)b + 1u : last;
         }
 #ifdef VCR_TIMING
         t_surv += wall_clock64() - t_mark;
@@ -314,7 +350,7 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
 }
 
 template <int S, bool ISECT, int ND>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 0 && ND == 0) ? 6 : 4))) composite_bwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 0 && ND == 0) ? 5 : 4))) composite_bwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
                                                                const float* __restrict__ semv,
                                                                const uint32_t* __restrict__ point_list,
                                                                const uint2* __restrict__ ranges,
@@ -330,6 +366,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 
     const uint2 range = ranges[tile];
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ float4 s_rec_all[4 * 256];                 // per wave: 4 planes x 64 slots x 16 B
+    float4* const srec = s_rec_all + wv * 256;
     const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8), Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8);
     const f2 fxy = {(float)pm.x, (float)pm.y};
     float rx = 0.f, ry = 0.f, rz = 1.f;
@@ -372,90 +410,115 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 
         live_box(__builtin_amdgcn_ballot_w64(lastc > (uint32_t)chunk * 64u), X0, Y0, bx0, by0, bw, bh);
         const bool keep = valid && quad_touch(q0, q1, bx0, by0, bw, bh);
         unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-        // per-lane (= per Gaussian) rescale for the shading loop, see gauss_exponent()
-        const float sA = -VCR_L2E * q1.x, sB = -VCR_L2E * q1.y, sC = -VCR_L2E * q1.z;
-        const float lop = __builtin_amdgcn_logf(q0.w);
-        while (m) {
-            const int b = 63 - __builtin_clzll(m);
+        if (keep) {
+            srec[0 * 64 + lane] = make_float4(q0.x, q0.y, -VCR_L2E * q1.x, -VCR_L2E * q1.z);
+            srec[1 * 64 + lane] = make_float4(-VCR_L2E * q1.y, __builtin_amdgcn_logf(q0.w), q0.z, q1.w);
+            srec[2 * 64 + lane] = make_float4(q2.x, q2.y, q2.z, q3.x);
+            srec[3 * 64 + lane] = make_float4(q3.y, q3.z, __uint_as_float(id), 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // Shading + gradient of one survivor whose staged record sits in R0..R3 (see the forward kernel for the staging).
+        // Branch-free inside: lanes without a hit run with alpha = 0, which makes T, Bsuf and every slot a no-op / zero.
+        // Slots are RAW sums; preprocess_bwd applies the per-Gaussian constants (GradRec in vcr_common.h).
+#define VCR_SHADE_BWD(R, B)                                                                                              \
+        do {                                                                                                             \
+            const float4 r0 = R##0, r1 = R##1, r2 = R##2, r3 = R##3; const int sb_ = (B);                                \
+            const uint32_t idx1 = (uint32_t)chunk * 64u + (uint32_t)sb_ + 1u;                                            \
+            const f2 gxy = {r0.x, r0.y}, sAC = {r0.z, r0.w};                                                             \
+            const f2 d = gxy - fxy;                                                                                      \
+            f2 u; float hs;                                                                                              \
+            const float e = gauss_exponent(d, sAC, r1.x, r1.y, u, hs);                                                   \
+            const float araw = __builtin_amdgcn_exp2f(e);                                                                \
+            const bool hit = idx1 <= lastc && hs <= 0.f && araw >= VCR_ALPHA_MIN;                                        \
+            if (__builtin_amdgcn_ballot_w64(hit) != 0) {                                                                 \
+            const f2 c01 = {r2.x, r2.y}, c2n = {r2.z, r2.w}, n12 = {r3.x, r3.y};                                         \
+            const float zc = r1.z, pl = r1.w;                                                                            \
+            const uint32_t gid = __float_as_uint(r3.z);                                                                  \
+            f2 v[8];                                                                                                     \
+            float vs[S > 0 ? S : 1];                                                                                     \
+            {                                                                                                            \
+                const float ah = hit ? araw : 0.f;                                                                       \
+                const float alpha = fminf(VCR_ALPHA_MAX, ah);                                                            \
+                const float inv1ma = fast_rcp(1.f - alpha);                                                              \
+                T *= inv1ma;                                                                                             \
+                const float w = alpha * T;                                                                               \
+                float dep = zc, iden = 0.f;                                                                              \
+                bool isect = false;                                                                                      \
+                if (ISECT) {                                                                                             \
+                    const float den = c2n.y * rx + n12.x * ry + n12.y * rz;                                              \
+                    isect = den > VCR_PLANE_EPS;                                                                         \
+                    iden = isect ? fast_rcp(den) : 0.f;                                                                  \
+                    dep = isect ? pl * iden * rz : zc;                                                                   \
+                }                                                                                                        \
+                f2 fa = pk_fma(c01, g01, f2{g[7], 0.f});                                                                 \
+                fa = pk_fma(c2n, g24, fa);                                                                               \
+                fa = pk_fma(n12, g56, fa);                                                                               \
+                float fg = fmaf(dep, g[3], fa.x + fa.y);                                                                 \
+                if (ND == 2) fg += dep * dep * gm2;                                                                      \
+                float md = 0.f, idep = 0.f;                                                                              \
+                if (ND == 1) {                                                                                           \
+                    idep = fast_rcp(dep);                                                                                \
+                    md = -zc_map * VCR_ZNEAR * idep;                                                                     \
+                    fg += md * gm1 + md * md * gm2;                                                                      \
+                }                                                                                                        \
+_Pragma("unroll")                                                                                                        \
+                for (int k = 0; k < S; ++k) fg += semv[(size_t)gid * S + k] * g[8 + k];                                  \
+                const float dL_dalpha = fmaf(T, fg, -Bsuf * inv1ma);                                                     \
+                Bsuf = fmaf(w, fg, Bsuf);                                                                                \
+                const float pw = ah * dL_dalpha;                                                                         \
+                const f2 pp = splat(pw);                                                                                 \
+                v[0] = u * pp;                                                                                           \
+                v[1] = f2{fabsf(v[0].x), fabsf(v[0].y)};                                                                 \
+                const f2 dp = d * pp;                                                                                    \
+                v[2] = d * dp;                                                                                           \
+                v[3] = f2{d.x * dp.y, pw};                                                                               \
+                const f2 ww = splat(w);                                                                                  \
+                v[4] = ww * g01;                                                                                         \
+                const float wd = w * (ND == 2 ? g[3] + 2.f * dep * gm2                                                   \
+                                              : (ND == 1 ? g[3] + (gm1 + 2.f * md * gm2) * zc_map * VCR_ZNEAR * idep * idep : g[3])); \
+                v[5] = f2{w * g24.x, isect ? 0.f : wd};                                                                  \
+                const float k1 = wd * rz * iden;                                                                         \
+                const float k2 = -k1 * pl * iden;                                                                        \
+                v[6] = f2{k1, fmaf(k2, rx, w * g24.y)};                                                                  \
+                v[7] = pk_fma(splat(k2), ryz, ww * g56);                                                                 \
+_Pragma("unroll")                                                                                                        \
+                for (int k = 0; k < S; ++k) vs[k] = w * g[8 + k];                                                        \
+            }                                                                                                            \
+            float r4[4];                                                                                                 \
+            wave_reduce16(v, r4);                                                                                        \
+            if ((lane & 15) < 4) {                                                                                       \
+                const int sub = lane & 15;                                                                               \
+                const float val = sub == 0 ? r4[0] : (sub == 1 ? r4[1] : (sub == 2 ? r4[2] : r4[3]));                    \
+                const int k = 8 * (lane >> 5) + 4 * ((lane >> 4) & 1) + sub;                                             \
+                if (val != 0.f) atomicAdd(reinterpret_cast<float*>(sgrad + gid) + k, val);                               \
+            }                                                                                                            \
+_Pragma("unroll")                                                                                                        \
+            for (int k = 0; k < S; ++k) {                                                                                \
+                const float t = wave_sum(vs[k]);                                                                         \
+                if (lane == 0 && t != 0.f) atomicAdd(sgrad_sem + (size_t)gid * S + k, t);                                \
+            }                                                                                                            \
+            }                                                                                                            \
+        } while (0)
+        if (m) {
+            float4 A0, A1, A2, A3, B0, B1, B2, B3;
+            int b = 63 - __builtin_clzll(m);
             m &= ~(1ull << b);
-            const uint32_t idx1 = (uint32_t)chunk * 64u + (uint32_t)b + 1u;
-            const f2 gxy = {bcast(q0.x, b), bcast(q0.y, b)};
-            const f2 sAC = {bcast(sA, b), bcast(sC, b)};
-            const f2 d = gxy - fxy;
-            f2 u; float hs;
-            const float e = gauss_exponent(d, sAC, bcast(sB, b), bcast(lop, b), u, hs);
-            const float araw = __builtin_amdgcn_exp2f(e);           // opacity * G, before the 0.99 clamp
-            const bool hit = idx1 <= lastc && hs <= 0.f && araw >= VCR_ALPHA_MIN;
-            if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
-            const f2 c01 = {bcast(q2.x, b), bcast(q2.y, b)};
-            const f2 c2n = {bcast(q2.z, b), bcast(q3.x, b)};
-            const f2 n12 = {bcast(q3.y, b), bcast(q3.z, b)};
-            const float zc = bcast(q0.z, b), pl = bcast(q1.w, b);
-            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, b);
-            // branch-free: lanes without a hit run with alpha = 0, which makes T, Bsuf and every slot below a no-op / zero.
-            // Slots are RAW sums; preprocess_bwd applies the per-Gaussian constants (GradRec in vcr_common.h).
-            f2 v[8];
-            float vs[S > 0 ? S : 1];
-            {
-                const float ah = hit ? araw : 0.f;
-                const float alpha = fminf(VCR_ALPHA_MAX, ah);
-                const float inv1ma = fast_rcp(1.f - alpha);
-                T *= inv1ma;                                        // transmittance in front of this Gaussian
-                const float w = alpha * T;
-                float dep = zc, iden = 0.f;
-                bool isect = false;
-                if (ISECT) {
-                    const float den = c2n.y * rx + n12.x * ry + n12.y * rz;
-                    isect = den > VCR_PLANE_EPS;
-                    iden = isect ? fast_rcp(den) : 0.f;
-                    dep = isect ? pl * iden * rz : zc;
-                }
-                f2 fa = pk_fma(c01, g01, f2{g[7], 0.f});
-                fa = pk_fma(c2n, g24, fa);
-                fa = pk_fma(n12, g56, fa);
-                float fg = fmaf(dep, g[3], fa.x + fa.y);
-                if (ND == 2) fg += dep * dep * gm2;
-                float md = 0.f, idep = 0.f;
-                if (ND == 1) {
-                    idep = fast_rcp(dep);
-                    md = -zc_map * VCR_ZNEAR * idep;
-                    fg += md * gm1 + md * md * gm2;
-                }
-#pragma unroll
-                for (int k = 0; k < S; ++k) fg += semv[(size_t)gid * S + k] * g[8 + k];
-                const float dL_dalpha = fmaf(T, fg, -Bsuf * inv1ma);
-                Bsuf = fmaf(w, fg, Bsuf);
-                const float pw = ah * dL_dalpha;                    // dL/dpower; alpha = o*G, clamp ignored (public rasterizer)
-                const f2 pp = splat(pw);
-                v[0] = u * pp;                                      // log2(e) * dL/d(centre)
-                v[1] = f2{fabsf(v[0].x), fabsf(v[0].y)};
-                const f2 dp = d * pp;
-                v[2] = d * dp;                                      // dx^2 p, dy^2 p   (-2 dL/dA, -2 dL/dC)
-                v[3] = f2{d.x * dp.y, pw};                          // dx dy p (-dL/dB), p (opacity * dL/dopacity)
-                const f2 ww = splat(w);
-                v[4] = ww * g01;
-                const float wd = w * (ND == 2 ? g[3] + 2.f * dep * gm2
-                                              : (ND == 1 ? g[3] + (gm1 + 2.f * md * gm2) * zc_map * VCR_ZNEAR * idep * idep : g[3]));
-                v[5] = f2{w * g24.x, isect ? 0.f : wd};
-                const float k1 = wd * rz * iden;                   // d dep / d plane (0 when the centre depth was used)
-                const float k2 = -k1 * pl * iden;
-                v[6] = f2{k1, fmaf(k2, rx, w * g24.y)};
-                v[7] = pk_fma(splat(k2), ryz, ww * g56);
-#pragma unroll
-                for (int k = 0; k < S; ++k) vs[k] = w * g[8 + k];
-            }
-            float r4[4];
-            wave_reduce16(v, r4);
-            if ((lane & 15) < 4) {
-                const int sub = lane & 15;
-                const float val = sub == 0 ? r4[0] : (sub == 1 ? r4[1] : (sub == 2 ? r4[2] : r4[3]));
-                const int k = 8 * (lane >> 5) + 4 * ((lane >> 4) & 1) + sub;
-                if (val != 0.f) atomicAdd(reinterpret_cast<float*>(sgrad + gid) + k, val);
-            }
-#pragma unroll
-            for (int k = 0; k < S; ++k) {
-                const float t = wave_sum(vs[k]);
-                if (lane == 0 && t != 0.f) atomicAdd(sgrad_sem + (size_t)gid * S + k, t);
+            VCR_LDS_FETCH(A, b);
+            for (;;) {                                   // back to front, ping-pong as in the forward kernel
+                int nb = m ? 63 - __builtin_clzll(m) : 0;
+                bool more = m != 0;
+                m &= ~(1ull << nb);
+                VCR_LDS_FETCH(B, nb);
+                VCR_SHADE_BWD(A, b);
+                if (!more) break;
+                b = nb;
+                nb = m ? 63 - __builtin_clzll(m) : 0;
+                more = m != 0;
+                m &= ~(1ull << nb);
+                VCR_LDS_FETCH(A, nb);
+                VCR_SHADE_BWD(B, b);
+                if (!more) break;
+                b = nb;
             }
         }
         id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; valid = nvalid; nid = nnid; nvalid = nnvalid;
