@@ -5,8 +5,9 @@
 //   2. emit (tile, id) instances in that depth order with a load-balanced wave-cooperative kernel,
 //   3. STABLE radix sort of the R instances on the tile bits only (ceil(log2 T) <= 14 bits -> 2 passes
 //      over 8-byte pairs instead of 6 passes over 12-byte pairs),
-// which yields the same (tile, depth, id) order with ~3.5x less sort traffic.  Device-wide scan / radix
-// sort primitives come from rocPRIM (plain library primitives); everything else is hand-written.
+// which yields the same (tile, depth, id) order with ~3.5x less sort traffic.  Both sorts run on the hand-written
+// two-kernels-per-pass radix sort of radix_sort.hip up to VCR_SORT_HAND_MAX items (its block-prefix step is quadratic
+// in the block count); beyond that, and for the offsets scan, the rocPRIM device primitives are used.
 #include "vcr_common.h"
 #include <cstring>
 #include <cstdlib>
@@ -88,70 +89,69 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t R, const uint3
     if (i == R - 1) ranges[k].y = (uint32_t)R;
 }
 
-// Longest-first order, folded boustrophedon-wise with the period of the chip (256 CUs: block b lands on XCD b % 8 and,
-// within it, on the next CU in turn): CU c then receives ranks c, 511-c, 512+c, 1023-c, ... so the per-CU sums of list
-// lengths even out instead of CU 0 collecting the heaviest tile of every band.
-__global__ void snake_order_kernel(int T, const uint32_t* __restrict__ sorted, uint32_t* __restrict__ order) {
+__global__ void iota_kernel(int n, uint32_t* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= T) return;
-    const int band = i >> 8, j = i & 255;
-    const int band_len = min(256, T - (band << 8));
-    const int src = (band & 1) ? (band << 8) + (band_len - 1 - j) : i;
-    order[i] = (j < band_len) ? sorted[src] : sorted[i];
+    if (i < n) out[i] = (uint32_t)i;
 }
 
 }  // namespace
 
+constexpr int64_t VCR_SORT_HAND_MAX = 512ll * 8192ll;       // items; see radix_sort.hip
+
 size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits) {
     size_t b0 = 0, b1 = 0, b2 = 0;
     uint32_t* d = nullptr;
-    (void)rocprim::radix_sort_pairs<DepthSortConfig>(nullptr, b0, d, d, d, d, (size_t)N, 0, 32, (hipStream_t)0);
+    if (N > VCR_SORT_HAND_MAX)
+        (void)rocprim::radix_sort_pairs<DepthSortConfig>(nullptr, b0, d, d, d, d, (size_t)N, 0, 32, (hipStream_t)0);
+    else b0 = vcr_sort_scratch_bytes(N);
     auto it = rocprim::make_transform_iterator(d, GatherTiles{d});
     (void)rocprim::inclusive_scan(nullptr, b1, it, d, (size_t)N, rocprim::plus<uint32_t>(), (hipStream_t)0);
-    if (R > 0) (void)rocprim::radix_sort_pairs(nullptr, b2, d, d, d, d, (size_t)R, 0, tile_bits, (hipStream_t)0);
-    size_t b3 = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, b3, d, d, d, d, (size_t)(1 << tile_bits), 0, 32, (hipStream_t)0);
-    if (b3 > b2) b2 = b3;
+    if (R > VCR_SORT_HAND_MAX) (void)rocprim::radix_sort_pairs(nullptr, b2, d, d, d, d, (size_t)R, 0, tile_bits, (hipStream_t)0);
+    else if (R > 0) b2 = vcr_sort_scratch_bytes(R);
     size_t m = b0 > b1 ? b0 : b1;
     return vcr_align(m > b2 ? m : b2);
 }
 
-int vcr_depth_sort_and_scan(int N, const uint32_t* depth_key, const uint32_t* ids, uint32_t* key_sorted,
-                            uint32_t* ids_sorted, const uint32_t* tiles, uint32_t* offsets, void* temp, size_t temp_bytes,
-                            hipStream_t st) {
+// depth order of the N Gaussians (ties by index) and the inclusive scan of their tile counts in that order.
+// (tmp_k, tmp_v): N words each; `totals`: VCR_SORT_TOTALS_WORDS zeroed words.
+int vcr_depth_sort_and_scan(int N, const uint32_t* depth_key, uint32_t* tmp_k, uint32_t* tmp_v, uint32_t* key_sorted,
+                            uint32_t* ids_sorted, const uint32_t* tiles, uint32_t* offsets, uint32_t* totals, void* temp,
+                            size_t temp_bytes, hipStream_t st) {
     size_t tb = temp_bytes;
-    VCR_HIP_CHECK(rocprim::radix_sort_pairs<DepthSortConfig>(temp, tb, depth_key, key_sorted, ids, ids_sorted, (size_t)N, 0, 32, st));
+    if (N > VCR_SORT_HAND_MAX) {
+        hipLaunchKernelGGL(iota_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, tmp_v);
+        VCR_HIP_CHECK(rocprim::radix_sort_pairs<DepthSortConfig>(temp, tb, depth_key, key_sorted, tmp_v, ids_sorted, (size_t)N, 0, 32, st));
+    } else if (vcr_sort_pairs(N, depth_key, nullptr, tmp_k, tmp_v, key_sorted, ids_sorted, 0, 32, (uint32_t*)temp, totals, st)) {
+        return 1;
+    }
     tb = temp_bytes;
     auto it = rocprim::make_transform_iterator(ids_sorted, GatherTiles{tiles});
     VCR_HIP_CHECK(rocprim::inclusive_scan(temp, tb, it, offsets, (size_t)N, rocprim::plus<uint32_t>(), st));
     return 0;
 }
 
+// (keys_a, vals_a): instance buffers; (keys_t, vals_t): a second pair; keys_b / point_list: the sorted result.
 int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const uint32_t* ids_sorted,
                            const uint32_t* offsets, int64_t R, int tile_bits, uint32_t* keys_a, uint32_t* vals_a,
-                           uint32_t* keys_b, uint32_t* point_list, uint2* ranges, uint32_t* tile_order, int num_tiles,
-                           void* temp, size_t temp_bytes, hipStream_t st) {
+                           uint32_t* keys_t, uint32_t* vals_t, uint32_t* keys_b, uint32_t* point_list, uint2* ranges,
+                           uint32_t* tile_order, int num_tiles, uint32_t* totals, void* temp, size_t temp_bytes,
+                           hipStream_t st) {
+    static const bool no_lpt = getenv("VCR_NO_LPT") != nullptr;          // experiment switches
+    static const bool no_snake = getenv("VCR_NO_SNAKE") != nullptr;
     VCR_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, st));
-    if (R <= 0) return vcr_launch_tile_len(num_tiles, ranges, keys_a, tile_order, st);   // identity order
+    if (R <= 0) return vcr_launch_tile_order(num_tiles, ranges, tile_order, false, false, st);   // identity order
     const int blocks = (a.N + 255) / 256;
     hipLaunchKernelGGL(duplicate_kernel, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, offsets, g.rec, radii,
                        g.tiles, keys_a, vals_a);
     VCR_HIP_CHECK(hipGetLastError());
-    size_t tb = temp_bytes;
-    VCR_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, keys_a, keys_b, vals_a, point_list, (size_t)R, 0, tile_bits, st));
+    if (R > VCR_SORT_HAND_MAX) {
+        size_t tb = temp_bytes;
+        VCR_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, keys_a, keys_b, vals_a, point_list, (size_t)R, 0, tile_bits, st));
+    } else if (vcr_sort_pairs(R, keys_a, vals_a, keys_t, vals_t, keys_b, point_list, 0, tile_bits, (uint32_t*)temp, totals, st)) {
+        return 1;
+    }
     const int64_t rb = (R + 255) / 256;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)rb), dim3(256), 0, st, R, keys_b, ranges);
     VCR_HIP_CHECK(hipGetLastError());
-    // longest-first tile order; keys_a / vals_a are free again and hold >= 2*T words each (caller guarantees)
-    uint32_t* lk = keys_a; uint32_t* lv = vals_a; uint32_t* lk2 = keys_a + num_tiles;
-    static const bool no_lpt = getenv("VCR_NO_LPT") != nullptr;          // experiment switch
-    if (no_lpt) return vcr_launch_tile_len(num_tiles, ranges, lk, tile_order, st);
-    if (vcr_launch_tile_len(num_tiles, ranges, lk, lv, st)) return 1;
-    tb = temp_bytes;
-    static const bool no_snake = getenv("VCR_NO_SNAKE") != nullptr;      // experiment switch
-    uint32_t* sorted = no_snake ? tile_order : lv + num_tiles;           // vals_a has >= 2*T words
-    VCR_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, lk, lk2, lv, sorted, (size_t)num_tiles, 0, 32, st));
-    if (!no_snake)
-        hipLaunchKernelGGL(snake_order_kernel, dim3((num_tiles + 255) / 256), dim3(256), 0, st, num_tiles, sorted, tile_order);
-    return 0;
+    return vcr_launch_tile_order(num_tiles, ranges, tile_order, !no_lpt, !no_snake, st);
 }

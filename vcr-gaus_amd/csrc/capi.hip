@@ -43,7 +43,10 @@ struct StageTimer {
 };
 
 #define VCR_VIS_SLOTS 64
-struct Readback { uint32_t R; uint32_t V[VCR_VIS_SLOTS]; };
+// device counters of one forward call, zeroed by ONE memset: visible-count slots, tile-instance-count slots and the
+// digit totals of the two radix sorts
+#define VCR_CTR_WORDS (2 * VCR_VIS_SLOTS + 2 * VCR_SORT_TOTALS_WORDS)
+struct Readback { uint32_t V[VCR_VIS_SLOTS]; uint32_t R[VCR_VIS_SLOTS]; };
 
 Readback* pinned_readback() {
     static thread_local Readback* p = nullptr;
@@ -51,15 +54,27 @@ Readback* pinned_readback() {
     return p;
 }
 
+hipEvent_t readback_event() {
+    static thread_local hipEvent_t e = nullptr;
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+    return e;
+}
+
+// visible Gaussians and tile instances (R = sum of tiles touched), spread over slots to keep the atomics apart
 __global__ void __launch_bounds__(256) count_visible_kernel(int N, const uint32_t* __restrict__ tiles,
                                                             uint32_t* __restrict__ slots) {
-    uint32_t c = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) c += tiles[i] != 0 ? 1u : 0u;
-    const unsigned long long m = 0;
-    (void)m;
-    // wave popcount of per-lane counts via ballot is not applicable to multi-valued c: butterfly add
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(slots + ((blockIdx.x * 4 + (threadIdx.x >> 6)) % VCR_VIS_SLOTS), c);
+    uint32_t c = 0, r = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        const uint32_t t = tiles[i];
+        c += t != 0 ? 1u : 0u;
+        r += t;
+    }
+    for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); r += __shfl_xor(r, o); }
+    if ((threadIdx.x & 63) == 0 && c) {
+        const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) % VCR_VIS_SLOTS;
+        atomicAdd(slots + slot, c);
+        atomicAdd(slots + VCR_VIS_SLOTS + slot, r);
+    }
 }
 
 __global__ void fill_background_kernel(int P, int C, const float* __restrict__ bg, float* __restrict__ out) {
@@ -143,56 +158,67 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         const int tbits = tile_bits_for(T);
         const size_t tmp1 = vcr_binning_temp_bytes(N, 0, tbits);
         const size_t nb = vcr_align(sizeof(uint32_t) * (size_t)N);
-        char* s1 = (char*)alloc(user, VCR_BUF_SCRATCH, 5 * nb + 256 + tmp1);   // 256 B >= VCR_VIS_SLOTS words
+        const size_t ctr_bytes = vcr_align(sizeof(uint32_t) * VCR_CTR_WORDS);
+        char* s1 = (char*)alloc(user, VCR_BUF_SCRATCH, 6 * nb + ctr_bytes + tmp1);
         if (!s1) { vcr_set_error("allocator returned NULL"); return 1; }
         uint32_t* depth_key = (uint32_t*)s1;
-        uint32_t* ids = (uint32_t*)(s1 + nb);
+        uint32_t* ids = (uint32_t*)(s1 + nb);                 // iota from preprocess; reused as the sort's second key buffer
         uint32_t* key_sorted = (uint32_t*)(s1 + 2 * nb);
         uint32_t* ids_sorted = (uint32_t*)(s1 + 3 * nb);
         uint32_t* offsets = (uint32_t*)(s1 + 4 * nb);
-        uint32_t* vis_counter = (uint32_t*)(s1 + 5 * nb);
-        void* temp1 = s1 + 5 * nb + 256;
-        VCR_HIP_CHECK(hipMemsetAsync(vis_counter, 0, VCR_VIS_SLOTS * sizeof(uint32_t), st));
+        uint32_t* tmp_v = (uint32_t*)(s1 + 5 * nb);
+        uint32_t* ctr = (uint32_t*)(s1 + 6 * nb);
+        uint32_t* vis_counter = ctr;
+        uint32_t* totals_depth = ctr + 2 * VCR_VIS_SLOTS;
+        uint32_t* totals_tile = totals_depth + VCR_SORT_TOTALS_WORDS;
+        void* temp1 = s1 + 6 * nb + ctr_bytes;
+        VCR_HIP_CHECK(hipMemsetAsync(ctr, 0, sizeof(uint32_t) * VCR_CTR_WORDS, st));
         {
             StageTimer tm(ST_PREPROCESS, st);
             if (vcr_launch_preprocess(a, g, out->radii, depth_key, ids, st)) return 1;
         }
         hipLaunchKernelGGL(count_visible_kernel, dim3(min((N + 255) / 256, 512)), dim3(256), 0, st, N, g.tiles, vis_counter);
+        // R and V go back to the host now; the depth sort and the offsets scan do not need them and keep the GPU busy
+        // while the host wakes up, sizes the instance buffers and enqueues the rest
+        Readback* rb = pinned_readback();
+        hipEvent_t ev = readback_event();
+        if (!rb || !ev) { vcr_set_error("hipHostMalloc / hipEventCreate for the readback failed"); return 1; }
+        VCR_HIP_CHECK(hipMemcpyAsync(rb, vis_counter, sizeof(Readback), hipMemcpyDeviceToHost, st));
+        VCR_HIP_CHECK(hipEventRecord(ev, st));
         {
             StageTimer tm(ST_DEPTHSORT, st);
-            if (vcr_depth_sort_and_scan(N, depth_key, ids, key_sorted, ids_sorted, g.tiles, offsets, temp1, tmp1, st)) return 1;
+            if (vcr_depth_sort_and_scan(N, depth_key, ids, tmp_v, key_sorted, ids_sorted, g.tiles, offsets, totals_depth, temp1, tmp1,
+                                        st))
+                return 1;
         }
-        Readback* rb = pinned_readback();
-        if (!rb) { vcr_set_error("hipHostMalloc for the readback word failed"); return 1; }
-        VCR_HIP_CHECK(hipMemcpyAsync(&rb->R, offsets + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        VCR_HIP_CHECK(hipMemcpyAsync(rb->V, vis_counter, VCR_VIS_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        VCR_HIP_CHECK(hipStreamSynchronize(st));
-        R = rb->R;
+        VCR_HIP_CHECK(hipEventSynchronize(ev));
         uint32_t vsum = 0;
-        for (int k = 0; k < VCR_VIS_SLOTS; ++k) vsum += rb->V[k];
+        for (int k = 0; k < VCR_VIS_SLOTS; ++k) { vsum += rb->V[k]; R += rb->R[k]; }
         out->num_visible = (int32_t)vsum;
+        if (R >= (1ll << 32)) { vcr_set_error("more than 2^32 tile instances"); return 1; }
 
         void* bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(R, T));
         if (!bin_p) { vcr_set_error("allocator returned NULL"); return 1; }
         BinState b = BinState::view(bin_p, R, T);
         out->binning = bin_p;
         const size_t tmp2 = vcr_binning_temp_bytes(N, R, tbits);
-        const size_t rbts = vcr_align(sizeof(uint32_t) * (size_t)(R > 2 * (int64_t)T ? R : 2 * (int64_t)T));
-        char* s2 = (char*)alloc(user, VCR_BUF_SCRATCH, 3 * rbts + tmp2);
+        const size_t rbts = vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1));
+        char* s2 = (char*)alloc(user, VCR_BUF_SCRATCH, 5 * rbts + tmp2);
         if (!s2) { vcr_set_error("allocator returned NULL"); return 1; }
         {
             StageTimer tm(ST_BINNING, st);
             if (vcr_duplicate_and_sort(a, g, out->radii, ids_sorted, offsets, R, tbits, (uint32_t*)s2, (uint32_t*)(s2 + rbts),
-                                       (uint32_t*)(s2 + 2 * rbts), b.point_list, b.ranges, b.tile_order, T, s2 + 3 * rbts, tmp2, st))
+                                       (uint32_t*)(s2 + 2 * rbts), (uint32_t*)(s2 + 3 * rbts), (uint32_t*)(s2 + 4 * rbts),
+                                       b.point_list, b.ranges, b.tile_order, T, totals_tile, s2 + 5 * rbts, tmp2, st))
                 return 1;
         }
         out->num_rendered = R;
         if (a.debug) {                       // diagnostics only: longest per-tile list (one extra sync)
             VCR_HIP_CHECK(hipMemsetAsync(vis_counter, 0, sizeof(uint32_t), st));
             hipLaunchKernelGGL(max_tile_len_kernel, dim3(32), dim3(256), 0, st, T, b.ranges, vis_counter);
-            VCR_HIP_CHECK(hipMemcpyAsync(&rb->R, vis_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            VCR_HIP_CHECK(hipMemcpyAsync(&rb->R[0], vis_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             VCR_HIP_CHECK(hipStreamSynchronize(st));
-            out->max_tile_len = (int32_t)rb->R;
+            out->max_tile_len = (int32_t)rb->R[0];
         }
         {
             StageTimer tm(ST_COMPOSITE_FWD, st);
@@ -204,7 +230,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         BinState b = BinState::view(bin_p, 0, T);
         out->binning = bin_p;
         VCR_HIP_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * (size_t)T, st));
-        if (vcr_launch_tile_len(T, b.ranges, im.n_contrib, b.tile_order, st)) return 1;   // identity order
+        if (vcr_launch_tile_order(T, b.ranges, b.tile_order, false, false, st)) return 1;   // identity order
         VCR_HIP_CHECK(hipMemsetAsync(img_p, 0, ImageState::bytes(P), st));
         if (a.f_count != 3)
             hipLaunchKernelGGL(fill_background_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, a.f_count ? 3 : C, a.bg,

@@ -155,6 +155,12 @@ __device__ __forceinline__ float gauss_exponent(f2 d, f2 sAC, float sB, float lo
     return fmaf(0.5f, hs, lop);
 }
 #define VCR_L2E 1.4426950408889634f
+// Knock-out builds for bottleneck attribution (timing only, results are wrong): -DVCR_KO=1 skips the shading loops
+// (gather + culling + staging remain), =2 keeps the backward's wave reduction but never issues its atomics, =4 issues
+// the atomics without the reduction.  See DESIGN.md section 4.
+#ifndef VCR_KO
+#define VCR_KO 0
+#endif
 #define VCR_LN2 0.6931471805599453f
 
 template <int S, bool ISECT, int FC, int ND>
@@ -283,7 +289,7 @@ _Pragma("unroll")                                                               
             R##0 = srec[(B)]; R##1 = srec[64 + (B)]; R##2 = srec[128 + (B)]; R##3 = srec[192 + (B)];          \
             asm volatile("" ::: "memory");                                                                    \
         } while (0)
-        if (m) {
+        if (m && !(VCR_KO & 1)) {
             float4 A0, A1, A2, A3, B0, B1, B2, B3;
             int b = __builtin_ctzll(m);
             m &= m - 1;
@@ -485,12 +491,13 @@ _Pragma("unroll")                                                               
                 for (int k = 0; k < S; ++k) vs[k] = w * g[8 + k];                                                        \
             }                                                                                                            \
             float r4[4];                                                                                                 \
-            wave_reduce16(v, r4);                                                                                        \
+            if (VCR_KO & 4) { r4[0] = v[0].x + v[4].x; r4[1] = v[1].y + v[5].y; r4[2] = v[2].x + v[6].y; r4[3] = v[3].y + v[7].x; } \
+            else wave_reduce16(v, r4);                                                                                   \
             if ((lane & 15) < 4) {                                                                                       \
                 const int sub = lane & 15;                                                                               \
                 const float val = sub == 0 ? r4[0] : (sub == 1 ? r4[1] : (sub == 2 ? r4[2] : r4[3]));                    \
                 const int k = 8 * (lane >> 5) + 4 * ((lane >> 4) & 1) + sub;                                             \
-                if (val != 0.f) atomicAdd(reinterpret_cast<float*>(sgrad + gid) + k, val);                               \
+                if ((VCR_KO & 2) ? val == 1.2345e-30f : val != 0.f) atomicAdd(reinterpret_cast<float*>(sgrad + gid) + k, val); \
             }                                                                                                            \
 _Pragma("unroll")                                                                                                        \
             for (int k = 0; k < S; ++k) {                                                                                \
@@ -499,7 +506,7 @@ _Pragma("unroll")                                                               
             }                                                                                                            \
             }                                                                                                            \
         } while (0)
-        if (m) {
+        if (m && !(VCR_KO & 1)) {
             float4 A0, A1, A2, A3, B0, B1, B2, B3;
             int b = 63 - __builtin_clzll(m);
             m &= ~(1ull << b);
@@ -523,15 +530,6 @@ _Pragma("unroll")                                                               
         }
         id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; valid = nvalid; nid = nnid; nvalid = nnvalid;
     }
-}
-
-// per-tile list length as a sort key (descending via bit inversion) for longest-first block scheduling
-__global__ void tile_len_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ keys,
-                                uint32_t* __restrict__ vals) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;
-    keys[t] = ~(ranges[t].y - ranges[t].x);
-    vals[t] = (uint32_t)t;
 }
 
 template <int S, bool ISECT, int ND>
@@ -607,8 +605,3 @@ int vcr_launch_composite_backward(const VcrRasterArgs& a, GeomState g, BinState 
                  : launch_bwd_s<false, 0>(a, g, b, im, dL_dout, sgrad, sgrad_sem, tiles, st);
 }
 
-int vcr_launch_tile_len(int T, const uint2* ranges, uint32_t* keys, uint32_t* vals, hipStream_t st) {
-    hipLaunchKernelGGL(tile_len_kernel, dim3((T + 255) / 256), dim3(256), 0, st, T, ranges, keys, vals);
-    VCR_HIP_CHECK(hipGetLastError());
-    return 0;
-}

@@ -140,14 +140,21 @@ int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const in
                                    const GradRec* sgrad, const float* sgrad_sem, VcrBackwardIO& io,
                                    hipStream_t st);
 size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits);
-int vcr_depth_sort_and_scan(int N, const uint32_t* depth_key, const uint32_t* ids, uint32_t* key_sorted,
-                            uint32_t* ids_sorted, const uint32_t* tiles, uint32_t* offsets, void* temp,
+int vcr_depth_sort_and_scan(int N, const uint32_t* depth_key, uint32_t* tmp_k, uint32_t* tmp_v, uint32_t* key_sorted,
+                            uint32_t* ids_sorted, const uint32_t* tiles, uint32_t* offsets, uint32_t* totals, void* temp,
                             size_t temp_bytes, hipStream_t st);
 int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const uint32_t* ids_sorted,
                            const uint32_t* offsets, int64_t R, int tile_bits, uint32_t* keys_a, uint32_t* vals_a,
-                           uint32_t* keys_b, uint32_t* point_list, uint2* ranges, uint32_t* tile_order, int num_tiles,
-                           void* temp, size_t temp_bytes, hipStream_t st);
-int vcr_launch_tile_len(int T, const uint2* ranges, uint32_t* keys, uint32_t* vals, hipStream_t st);
+                           uint32_t* keys_t, uint32_t* vals_t, uint32_t* keys_b, uint32_t* point_list, uint2* ranges,
+                           uint32_t* tile_order, int num_tiles, uint32_t* totals, void* temp, size_t temp_bytes,
+                           hipStream_t st);
+// radix_sort.hip: hand-written stable radix sort of (u32 key, u32 value) pairs and the block-scheduling order
+#define VCR_SORT_TOTALS_WORDS 1024            // 4 passes x 256 digit totals, zero on entry
+size_t vcr_sort_scratch_bytes(int64_t n);
+int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_tmp, uint32_t* vals_tmp,
+                   uint32_t* keys_out, uint32_t* vals_out, int begin_bit, int end_bit, uint32_t* hist, uint32_t* totals,
+                   hipStream_t st);
+int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, bool lpt, bool snake, hipStream_t st);
 int vcr_launch_composite_forward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o,
                                  hipStream_t st);
 int vcr_launch_composite_backward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
