@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 5
+#define VCR_ABI_VERSION 7
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -59,6 +59,14 @@ typedef struct VcrRasterArgs {
     const float* rotations;     /* [N,4] (w,x,y,z) unit, or NULL */
     const float* cov3D_precomp; /* [N,6] or NULL (exactly one of scales+rotations / cov3D_precomp) */
     const float* dirs;          /* [3,H,W] unit pixel rays -> ray/plane ("intersection") depth; NULL -> centre depth */
+    void* colour_stream;        /* optional second HIP stream: the SH -> RGB evaluation is launched there, behind the
+                                   projection of this call, and joined before compositing, so that it overlaps the
+                                   latency-bound sort chain; NULL -> one stream */
+    void (*colour_stream_hook)(void* user);   /* optional: called once, on the host, after colour_stream has been made to
+                                   wait for the projection and before the SH -> RGB launch: work the caller enqueues on
+                                   colour_stream here (e.g. vcr_sh_adam_from_rgb of the previous iteration) runs beside
+                                   the sort chain and ahead of the colour evaluation */
+    void* colour_stream_hook_user;
 } VcrRasterArgs;
 
 /* Forward outputs.  `out`, `radii`, counters are caller-allocated. */
@@ -93,6 +101,8 @@ typedef struct VcrBackwardIO {
     float* dL_dcolors;       /* [N,3] or NULL */
     float* dL_drgb;          /* optional [N,3]: dL/d(SH-evaluated colour) after the clamp mask, for the factorised
                                 data-parallel exchange (vcr_sh_grad_from_rgb); dL_dshs may then be NULL */
+    float* view_dirs;        /* optional [N,3]: unit view direction (mean - campos) used for the SH basis, written
+                                together with dL_drgb for vcr_sh_adam_from_rgb */
     float* dL_dnormals;      /* [N,3] or NULL */
     float* dL_dsemantics;    /* [N,S] or NULL */
     float* dL_dopacities;    /* [N] */
@@ -130,6 +140,14 @@ int vcr_activate_backward(int N, const float* scaling_raw, const float* rotation
  * into the split storage d_features_dc [N,1,3] / d_features_rest [N,15,3].  (No reference counterpart: DP is new.) */
 int vcr_sh_grad_from_rgb(int N, int sh_degree, int nviews, const float* xyz, const float* campos_all,
                          const float* drgb_all, float* d_features_dc, float* d_features_rest, void* stream);
+/* Single-view training: torch.optim.Adam on _features_dc [N,1,3] / _features_rest [N,15,3] (scene/gaussian_model.py:251-252,
+ * trainer.py:389) with the SH gradient formed on the fly as basis_k(view_dirs) x drgb (both [N,3], written by
+ * vcr_rasterize_backward through dL_drgb / view_dirs), so the 192 B/Gaussian SH gradient is never written or read.
+ * Same update rule as vcr_adam_step (bias correction from `step`, eps added to sqrt(v)/sqrt(bc2)); coefficients above
+ * sh_degree get a zero gradient, exactly as in the dense update.  Meant for a second stream (VcrRasterArgs.colour_stream). */
+int vcr_sh_adam_from_rgb(int N, int sh_degree, const float* view_dirs, const float* drgb, float* features_dc,
+                         float* features_rest, float* m_dc, float* v_dc, float* m_rest, float* v_rest, float lr_dc,
+                         float lr_rest, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
 /* simple_knn._C.distCUDA2 (scene/gaussian_model.py:17-20,211): mean squared distance to the 3 nearest neighbours,
  * points [N,3] -> out [N].  Exact brute force (one-time initialisation from the SfM point cloud). */
 int vcr_knn3_mean_dist2(int N, const float* points, float* out, void* stream);

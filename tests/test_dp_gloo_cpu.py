@@ -137,7 +137,7 @@ def sh_worker(rank, world, port, out):
     m.optimizer.param_groups += [{"params": [m._features_dc], "lr": 0.1, "name": "f_dc"},
                                  {"params": [m._features_rest], "lr": 0.1, "name": "f_rest"}]
     tr = Trainer(cfg, m, [_Cam(i) for i in range(8)], 1.0, torch.device("cpu"), world=world, rank=rank, seed=3)
-    assert tr.factorised_sh and rasterizer.SH_GRAD_MODE == "rgb"
+    assert tr.factorised_sh and rasterizer.SH_GRAD_MODE == "full"      # the mode is scoped to the trainer's own renders
 
     def rebuild(drgb_all, campos_all):
         g = sum(_basis_outer(m._xyz.detach(), campos_all[v], drgb_all[v], 3) for v in range(drgb_all.shape[0]))

@@ -220,7 +220,7 @@ def test_factorised_sh_path_trains_like_the_dense_path(device):
     try:
         for force in (False, True):
             cams = synthetic.make_cameras(3, 128, 96, 110.0, device=device)
-            tr = make_synthetic_trainer(raw, cams, device, preset="tnt", force_factorised=force,
+            tr = make_synthetic_trainer(raw, cams, device, preset="tnt", force_factorised=force, overlap_sh=False,
                                         optim={"densify_from_iter": 10 ** 9})
             for _ in range(12):
                 tr.train_step()
@@ -228,6 +228,42 @@ def test_factorised_sh_path_trains_like_the_dense_path(device):
             rasterizer.SH_GRAD_MODE = "full"
     finally:
         rasterizer.SH_GRAD_MODE = "full"
+    for k in finals[0]:
+        d = float((finals[0][k] - finals[1][k]).abs().max())
+        assert d < 2e-3 * max(1.0, float(finals[0][k].abs().max())), (k, d)
+
+
+def test_two_stream_sh_path_trains_like_the_serial_loop(device):
+    """Single-GPU default: SH Adam (gradient formed on the fly from dL/drgb x basis, vcr_sh_adam_from_rgb) and the next
+    iteration's SH -> RGB evaluation run on a second stream.  Same trajectory as the serial loop with the dense SH
+    gradient + vcr_adam_step, including across a densification (surgery) step and an SH-degree bump."""
+    from vcr_gaus_amd import rasterizer, synthetic
+    from vcr_gaus_amd.trainer import make_synthetic_trainer
+    raw = synthetic.make_gaussians(8000, seed=5)
+    raw["scaling"] = raw["scaling"] + 1.0
+    finals = []
+    try:
+        for overlap in (False, True):
+            cams = synthetic.make_cameras(3, 128, 96, 110.0, device=device)
+            tr = make_synthetic_trainer(raw, cams, device, preset="tnt", overlap_sh=overlap,
+                                        optim={"densify_from_iter": 10 ** 9, "opacity_reset_interval": 9})
+            assert tr.overlap_sh == overlap and rasterizer.COLOUR_STREAM is None and rasterizer.SH_GRAD_MODE == "full"
+            tr.model.active_sh_degree = 2
+            for it in range(14):
+                if it == 6:
+                    tr.model.active_sh_degree = 3
+                tr.train_step()                              # iteration 9 resets the opacities (a surgery step)
+            tr.join_side()
+            torch.cuda.synchronize()
+            finals.append({k: getattr(tr.model, k).detach().clone()
+                           for k in ["_features_dc", "_features_rest", "_xyz", "_opacity", "_scaling", "_rotation"]})
+            st = tr.model.optimizer.state
+            finals[-1]["m_rest"] = st["f_rest"]["exp_avg"].clone()
+            finals[-1]["v_dc"] = st["f_dc"]["exp_avg_sq"].clone()
+            assert st["f_rest"]["step"] == 14 and st["xyz"]["step"] == 14
+    finally:
+        rasterizer.SH_GRAD_MODE = "full"
+        rasterizer.COLOUR_STREAM = None
     for k in finals[0]:
         d = float((finals[0][k] - finals[1][k]).abs().max())
         assert d < 2e-3 * max(1.0, float(finals[0][k].abs().max())), (k, d)
@@ -250,7 +286,7 @@ def test_rccl_exchange_path_single_rank_group(device):
         finals = []
         for coll in (False, True):
             cams = synthetic.make_cameras(3, 128, 96, 110.0, device=device)
-            tr = make_synthetic_trainer(raw, cams, device, preset="tnt", force_factorised=True,
+            tr = make_synthetic_trainer(raw, cams, device, preset="tnt", force_factorised=True, overlap_sh=False,
                                         optim={"densify_from_iter": 10 ** 9, "densify_until_iter": 100})
             tr.force_collectives = coll
             for _ in range(8):

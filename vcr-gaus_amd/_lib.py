@@ -14,6 +14,7 @@ c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int32)
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
+HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 BUF_GEOM, BUF_BINNING, BUF_IMAGE, BUF_SCRATCH = 0, 1, 2, 3
 
 
@@ -26,6 +27,7 @@ class VcrRasterArgs(C.Structure):
         ("means3D", C.c_void_p), ("shs", C.c_void_p), ("shs_rest", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("normals_precomp", C.c_void_p), ("semantics_precomp", C.c_void_p), ("opacities", C.c_void_p),
         ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("dirs", C.c_void_p),
+        ("colour_stream", C.c_void_p), ("colour_stream_hook", C.c_void_p), ("colour_stream_hook_user", C.c_void_p),
     ]
 
 
@@ -42,7 +44,7 @@ class VcrBackwardIO(C.Structure):
         ("dL_dout", C.c_void_p), ("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p),
         ("radii", C.c_void_p), ("num_rendered", C.c_int64),
         ("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dmeans2D_densify", C.c_void_p),
-        ("dL_dshs", C.c_void_p), ("dL_dshs_rest", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_drgb", C.c_void_p), ("dL_dnormals", C.c_void_p),
+        ("dL_dshs", C.c_void_p), ("dL_dshs_rest", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_drgb", C.c_void_p), ("view_dirs", C.c_void_p), ("dL_dnormals", C.c_void_p),
         ("dL_dsemantics", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
         ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
     ]
@@ -57,6 +59,7 @@ SYMBOLS = {
     "vcr_activate_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 12),
     "vcr_activate_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 13),
     "vcr_sh_grad_from_rgb": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
+    "vcr_sh_adam_from_rgb": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_float] * 5 + [C.c_int, C.c_float, C.c_void_p]),
     "vcr_knn3_mean_dist2": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vcr_adam_step": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_int64), c_float_p, C.c_float, C.c_float,
@@ -100,7 +103,7 @@ def load():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.vcr_abi_version() != 5:
+    if lib.vcr_abi_version() != 7:
         raise ImportError("libvcr_raster.so ABI version mismatch")
     _lib = lib
     return lib

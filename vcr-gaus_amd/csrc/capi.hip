@@ -54,6 +54,13 @@ Readback* pinned_readback() {
     return p;
 }
 
+// events of the optional colour stream (VcrRasterArgs.colour_stream): geometry ready -> colours ready
+hipEvent_t colour_event(int k) {
+    static thread_local hipEvent_t e[2] = {nullptr, nullptr};
+    if (!e[k] && hipEventCreateWithFlags(&e[k], hipEventDisableTiming) != hipSuccess) e[k] = nullptr;
+    return e[k];
+}
+
 hipEvent_t readback_event() {
     static thread_local hipEvent_t e = nullptr;
     if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
@@ -173,9 +180,21 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         uint32_t* totals_tile = totals_depth + VCR_SORT_TOTALS_WORDS;
         void* temp1 = s1 + 6 * nb + ctr_bytes;
         VCR_HIP_CHECK(hipMemsetAsync(ctr, 0, sizeof(uint32_t) * VCR_CTR_WORDS, st));
+        // two-stream form: geometry here, SH -> RGB on the colour stream behind whatever the caller queued there
+        const bool split_colour = a.colour_stream && a.colour_stream != stream && a.shs && !a.colors_precomp;
         {
             StageTimer tm(ST_PREPROCESS, st);
-            if (vcr_launch_preprocess(a, g, out->radii, depth_key, ids, st)) return 1;
+            if (vcr_launch_preprocess(a, g, out->radii, depth_key, ids, !split_colour, st)) return 1;
+        }
+        if (split_colour) {
+            hipEvent_t e_geo = colour_event(0), e_col = colour_event(1);
+            if (!e_geo || !e_col) { vcr_set_error("hipEventCreate for the colour stream failed"); return 1; }
+            hipStream_t cs = (hipStream_t)a.colour_stream;
+            VCR_HIP_CHECK(hipEventRecord(e_geo, st));
+            VCR_HIP_CHECK(hipStreamWaitEvent(cs, e_geo, 0));
+            if (a.colour_stream_hook) a.colour_stream_hook(a.colour_stream_hook_user);
+            if (vcr_launch_colour(a, g, cs)) return 1;
+            VCR_HIP_CHECK(hipEventRecord(e_col, cs));
         }
         hipLaunchKernelGGL(count_visible_kernel, dim3(min((N + 255) / 256, 512)), dim3(256), 0, st, N, g.tiles, vis_counter);
         // R and V go back to the host now; the depth sort and the offsets scan do not need them and keep the GPU busy
@@ -220,6 +239,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             VCR_HIP_CHECK(hipStreamSynchronize(st));
             out->max_tile_len = (int32_t)rb->R[0];
         }
+        if (split_colour) VCR_HIP_CHECK(hipStreamWaitEvent(st, colour_event(1), 0));
         {
             StageTimer tm(ST_COMPOSITE_FWD, st);
             if (vcr_launch_composite_forward(a, g, b, im, *out, st)) return 1;

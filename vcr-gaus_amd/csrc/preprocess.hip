@@ -4,6 +4,7 @@
 // Reference call sites: gaussian_renderer/__init__.py:61-120 (inputs), :83-87 (colour rule),
 // tools/general_utils.py:98-130 (covariance from scale/rotation), scene/cameras.py:68-70 (matrices).
 #include "vcr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -145,13 +146,20 @@ __device__ __forceinline__ void coop_copy_in(const float* __restrict__ src, int 
     // src: `total` contiguous floats = rows of `per` floats; row g goes to s[g*SH_ROW + off ...]
     const int n4 = (reinterpret_cast<uintptr_t>(src) & 15) ? 0 : (total >> 2);      // unaligned views: scalar path
     const float4* s4 = reinterpret_cast<const float4*>(src);
-    for (int e4 = threadIdx.x; e4 < n4; e4 += 256) {
-        const float4 v = s4[e4];
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+    for (int e0 = threadIdx.x; e0 < n4; e0 += 4 * 256) {                             // four 16-byte loads in flight per lane
+        float4 v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int e = e4 * 4 + j, g = e / per;
-            s[g * SH_ROW + off + (e - g * per)] = vv[j];
+        for (int u = 0; u < 4; ++u) if (e0 + u * 256 < n4) v[u] = s4[e0 + u * 256];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e4 = e0 + u * 256;
+            if (e4 >= n4) continue;
+            const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = e4 * 4 + j, g = e / per;
+                s[g * SH_ROW + off + (e - g * per)] = vv[j];
+            }
         }
     }
     for (int e = (n4 << 2) + threadIdx.x; e < total; e += 256) {
@@ -187,7 +195,8 @@ __device__ __forceinline__ void stage_sh_in(const VcrRasterArgs& a, int base, in
     }
 }
 
-template <bool STAGE>
+// COLOUR = false: geometry only (the SH -> RGB evaluation runs as colour_fwd_kernel on VcrRasterArgs.colour_stream)
+template <bool STAGE, bool COLOUR>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, GeomState g, int32_t* __restrict__ radii,
                                                              uint32_t* __restrict__ depth_key,
                                                              uint32_t* __restrict__ ids) {
@@ -244,7 +253,9 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
 
     GeomRec rec;
     uint8_t clampbits = 0;
-    if (a.colors_precomp) {
+    if (!COLOUR) {
+        rec.r = rec.g = rec.b = 0.f;
+    } else if (a.colors_precomp) {
         rec.r = a.colors_precomp[3 * (size_t)i]; rec.g = a.colors_precomp[3 * (size_t)i + 1];
         rec.b = a.colors_precomp[3 * (size_t)i + 2];
     } else {
@@ -281,10 +292,51 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
     const float4* src = reinterpret_cast<const float4*>(&rec);
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
     for (int k = 0; k < a.S; ++k) g.sem[(size_t)i * a.S + k] = a.semantics_precomp[(size_t)i * a.S + k];
-    g.clamped[i] = clampbits;
+    if (COLOUR) g.clamped[i] = clampbits;
     g.tiles[i] = (uint32_t)ntiles;
     radii[i] = (int32_t)rad;
     depth_key[i] = __float_as_uint(pr.t[2]);
+}
+
+// SH -> RGB of the visible Gaussians (tiles > 0) into the colour slot of their GeomRec + the clamp bits; the second half
+// of preprocess_fwd_kernel<.., false>.
+// Launched with a small persistent grid (vcr_side_grid()): a kernel of the side stream must leave wave slots and LDS for
+// the main stream's sort workgroups (1024 threads + 82 KB LDS each), which a full grid of it starves for its whole duration.
+template <bool STAGE>
+__global__ void __launch_bounds__(256) colour_fwd_kernel(VcrRasterArgs a, GeomState g) {
+    extern __shared__ __attribute__((aligned(16))) float s_sh[];
+    const int nblk = (a.N + 255) / 256;
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int i = blk * 256 + threadIdx.x;
+        if (STAGE) {
+            __syncthreads();                                  // rows of the previous tile are consumed
+            const int base = blk * 256;
+            stage_sh_in(a, base, min(256, a.N - base), s_sh);
+            __syncthreads();
+        }
+        if (i >= a.N || g.tiles[i] == 0) continue;
+        const float* c = a.campos;
+        float dx = a.means3D[3 * (size_t)i] - c[0], dy = a.means3D[3 * (size_t)i + 1] - c[1], dz = a.means3D[3 * (size_t)i + 2] - c[2];
+        const float il = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+        dx *= il; dy *= il; dz *= il;
+        float b[16];
+        sh_basis<false>(a.sh_degree, dx, dy, dz, b, nullptr, nullptr, nullptr);
+        const float* sh = STAGE ? (s_sh + threadIdx.x * SH_ROW) : (a.shs + (size_t)i * a.K * 3);
+        const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
+        float c0 = 0.5f, c1 = 0.5f, c2 = 0.5f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k < nb) {
+                c0 += b[k] * sh[3 * k]; c1 += b[k] * sh[3 * k + 1]; c2 += b[k] * sh[3 * k + 2];
+            }
+        }
+        uint8_t clampbits = 0;
+        if (c0 < 0.f) { c0 = 0.f; clampbits |= 1; }
+        if (c1 < 0.f) { c1 = 0.f; clampbits |= 2; }
+        if (c2 < 0.f) { c2 = 0.f; clampbits |= 4; }
+        reinterpret_cast<float4*>(g.rec + i)[2] = make_float4(c0, c1, c2, 0.f);
+        g.clamped[i] = clampbits;
+    }
 }
 
 template <bool STAGE>
@@ -412,6 +464,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
                 }
             }
             if (dsh) for (int k = nb; k < a.K; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+            if (io.view_dirs) { io.view_dirs[i3] = dx; io.view_dirs[i3 + 1] = dy; io.view_dirs[i3 + 2] = dz; }
             const float dot = dx * ddx + dy * ddy + dz * ddz;       // through normalize()
             dp[0] += (ddx - dx * dot) * il; dp[1] += (ddy - dy * dot) * il; dp[2] += (ddz - dz * dot) * il;
         }
@@ -512,7 +565,103 @@ __global__ void __launch_bounds__(256) sh_grad_from_rgb_kernel(int N, int deg, i
     coop_copy_out(d_rest + (size_t)blk_base * 45, blk_cnt * 45, 45, 3, s_sh);
 }
 
+
+// ---- SH Adam with the gradient formed on the fly (single-view training) ------------------------------------------------
+// grad[g][k][c] = basis_k(view_dirs[g]) * drgb[g][c]; every lane builds its Gaussian's 48-value row in LDS, then the
+// block streams params / moments with coalesced 16-byte accesses (same row mapping as coop_copy_*) and applies Adam.
+__device__ __forceinline__ void coop_adam(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, int total, int per,
+                                          int off, const float* s, float lr_bc1, float b1, float b2, float eps, float bc2_sqrt) {
+    const int n4 = total >> 2;                              // rows start 16-byte aligned: 256*3 and 256*45 floats per block
+    float4* p4 = reinterpret_cast<float4*>(p); float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
+    // software-pipelined by hand: all 12 loads of four 16-byte groups are issued before the first use, so that a small
+    // persistent grid (few waves per CU, see colour_fwd_kernel) still keeps enough bytes in flight for HBM
+    for (int e0 = threadIdx.x; e0 < n4; e0 += 4 * 256) {
+        float4 pp[4], mm[4], vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e4 = e0 + u * 256;
+            if (e4 < n4) { pp[u] = p4[e4]; mm[u] = m4[e4]; vv[u] = v4[e4]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e4 = e0 + u * 256;
+            if (e4 >= n4) continue;
+            float P[4] = {pp[u].x, pp[u].y, pp[u].z, pp[u].w}, M[4] = {mm[u].x, mm[u].y, mm[u].z, mm[u].w};
+            float V[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = e4 * 4 + j, g = e / per;
+                const float gr = s[g * SH_ROW + off + (e - g * per)];
+                M[j] = b1 * M[j] + (1.f - b1) * gr;
+                V[j] = b2 * V[j] + (1.f - b2) * gr * gr;
+                P[j] -= lr_bc1 * (M[j] / (sqrtf(V[j]) / bc2_sqrt + eps));
+            }
+            p4[e4] = make_float4(P[0], P[1], P[2], P[3]); m4[e4] = make_float4(M[0], M[1], M[2], M[3]);
+            v4[e4] = make_float4(V[0], V[1], V[2], V[3]);
+        }
+    }
+    for (int e = (n4 << 2) + threadIdx.x; e < total; e += 256) {
+        const int g = e / per;
+        const float gr = s[g * SH_ROW + off + (e - g * per)];
+        const float M = b1 * m[e] + (1.f - b1) * gr, V = b2 * v[e] + (1.f - b2) * gr * gr;
+        m[e] = M; v[e] = V;
+        p[e] -= lr_bc1 * (M / (sqrtf(V) / bc2_sqrt + eps));
+    }
+}
+
+__global__ void __launch_bounds__(256) sh_adam_from_rgb_kernel(int N, int deg, const float* __restrict__ dirs,
+                                                               const float* __restrict__ drgb, float* p_dc, float* p_rest,
+                                                               float* m_dc, float* v_dc, float* m_rest, float* v_rest,
+                                                               float lr_dc_bc1, float lr_rest_bc1, float b1, float b2, float eps,
+                                                               float bc2_sqrt, float gscale) {
+    extern __shared__ __attribute__((aligned(16))) float s_sh[];
+    const int nblk = (N + 255) / 256;
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {      // small persistent grid, see colour_fwd_kernel
+        const int i = blk * 256 + threadIdx.x;
+        const int blk_base = blk * 256, blk_cnt = min(256, N - blk_base);
+        float* row = s_sh + threadIdx.x * SH_ROW;
+        __syncthreads();
+        if (i < N) {
+            const float g0 = drgb[3 * (size_t)i] * gscale, g1 = drgb[3 * (size_t)i + 1] * gscale, g2 = drgb[3 * (size_t)i + 2] * gscale;
+            float b[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) b[k] = 0.f;
+            if (g0 != 0.f || g1 != 0.f || g2 != 0.f)
+                sh_basis<false>(deg, dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2], b, nullptr, nullptr, nullptr);
+            const int nb = (deg + 1) * (deg + 1);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float bk = k < nb ? b[k] : 0.f;
+                row[3 * k] = bk * g0; row[3 * k + 1] = bk * g1; row[3 * k + 2] = bk * g2;
+            }
+        }
+        __syncthreads();
+        coop_adam(p_dc + (size_t)blk_base * 3, m_dc + (size_t)blk_base * 3, v_dc + (size_t)blk_base * 3, blk_cnt * 3, 3, 0, s_sh,
+                  lr_dc_bc1, b1, b2, eps, bc2_sqrt);
+        coop_adam(p_rest + (size_t)blk_base * 45, m_rest + (size_t)blk_base * 45, v_rest + (size_t)blk_base * 45, blk_cnt * 45, 45,
+                  3, s_sh, lr_rest_bc1, b1, b2, eps, bc2_sqrt);
+    }
+}
+
 }  // namespace
+
+extern "C" int vcr_sh_adam_from_rgb(int N, int sh_degree, const float* view_dirs, const float* drgb, float* features_dc,
+                                    float* features_rest, float* m_dc, float* v_dc, float* m_rest, float* v_rest, float lr_dc,
+                                    float lr_rest, float beta1, float beta2, float eps, int step, float grad_scale,
+                                    void* stream) {
+    if (N <= 0) return 0;
+    if (sh_degree < 0 || sh_degree > 3 || step < 1) { vcr_set_error("vcr_sh_adam_from_rgb: bad degree/step"); return 1; }
+    if ((((uintptr_t)features_dc) | ((uintptr_t)features_rest) | ((uintptr_t)m_dc) | ((uintptr_t)v_dc) | ((uintptr_t)m_rest) |
+         ((uintptr_t)v_rest)) & 15) { vcr_set_error("vcr_sh_adam_from_rgb: tensors must be 16-byte aligned"); return 1; }
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const int nblk = (N + 255) / 256, grid = nblk < vcr_side_grid() ? nblk : vcr_side_grid();
+    hipLaunchKernelGGL(sh_adam_from_rgb_kernel, dim3(grid), dim3(256), 256 * SH_ROW * sizeof(float), (hipStream_t)stream,
+                       N, sh_degree, view_dirs, drgb, features_dc, features_rest, m_dc, v_dc, m_rest, v_rest,
+                       (float)(lr_dc / bc1), (float)(lr_rest / bc1), beta1, beta2, eps, (float)sqrt(bc2), grad_scale);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 
 extern "C" int vcr_sh_grad_from_rgb(int N, int sh_degree, int nviews, const float* xyz, const float* campos_all,
                                     const float* drgb_all, float* d_features_dc, float* d_features_rest, void* stream) {
@@ -525,14 +674,32 @@ extern "C" int vcr_sh_grad_from_rgb(int N, int sh_degree, int nviews, const floa
 }
 
 int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key, uint32_t* ids,
-                          hipStream_t st) {
+                          bool colour, hipStream_t st) {
     if (a.N == 0) return 0;
     const int blocks = (a.N + 255) / 256;
-    if (a.shs && a.K == SH_K)
-        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(blocks), dim3(256), 256 * SH_ROW * sizeof(float), st, a, g, radii,
-                           depth_key, ids);
+    if (!colour)
+        hipLaunchKernelGGL((preprocess_fwd_kernel<false, false>), dim3(blocks), dim3(256), 0, st, a, g, radii, depth_key, ids);
+    else if (a.shs && a.K == SH_K)
+        hipLaunchKernelGGL((preprocess_fwd_kernel<true, true>), dim3(blocks), dim3(256), 256 * SH_ROW * sizeof(float), st, a, g,
+                           radii, depth_key, ids);
     else
-        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(blocks), dim3(256), 0, st, a, g, radii, depth_key, ids);
+        hipLaunchKernelGGL((preprocess_fwd_kernel<false, true>), dim3(blocks), dim3(256), 0, st, a, g, radii, depth_key, ids);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int vcr_side_grid() {
+    static const int g = [] { const char* e = getenv("VCR_SIDE_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    return g;
+}
+
+int vcr_launch_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st) {
+    if (a.N == 0) return 0;
+    const int nblk = (a.N + 255) / 256, blocks = nblk < vcr_side_grid() ? nblk : vcr_side_grid();
+    if (a.K == SH_K)
+        hipLaunchKernelGGL(colour_fwd_kernel<true>, dim3(blocks), dim3(256), 256 * SH_ROW * sizeof(float), st, a, g);
+    else
+        hipLaunchKernelGGL(colour_fwd_kernel<false>, dim3(blocks), dim3(256), 0, st, a, g);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }

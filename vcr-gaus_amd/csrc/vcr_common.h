@@ -135,7 +135,9 @@ void vcr_set_error(const char* fmt, ...);
 
 // ---- stage launchers (defined in the .hip files) ----------------------------------------------
 int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key,
-                          uint32_t* ids, hipStream_t st);
+                          uint32_t* ids, bool colour, hipStream_t st);
+int vcr_launch_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st);
+int vcr_side_grid();     // workgroups of a side-stream kernel (VCR_SIDE_GRID, default 512 = two per CU)
 int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const int32_t* radii,
                                    const GradRec* sgrad, const float* sgrad_sem, VcrBackwardIO& io,
                                    hipStream_t st);

@@ -118,6 +118,28 @@ class FusedAdam:
             for g in live:
                 g["params"][0].grad = None
 
+    @torch.no_grad()
+    def step_sh_from_rgb(self, drgb, dirs, sh_degree, stream=None):
+        """Adam on the f_dc / f_rest groups with the SH gradient formed on the fly as basis(dirs) x drgb (single-view
+        training, HIP kernel vcr_sh_adam_from_rgb), launched on `stream` (a torch.cuda.Stream; default: current)."""
+        lib = _lib.load()
+        groups = {g["name"]: g for g in self.param_groups}
+        dc, rest = groups["f_dc"], groups["f_rest"]
+        sd, sr = self._state(dc), self._state(rest)
+        sd["step"] += 1
+        sr["step"] += 1
+        if sd["step"] != sr["step"]:
+            raise RuntimeError("f_dc / f_rest Adam steps diverged")
+        pd, pr = dc["params"][0], rest["params"][0]
+        if pd.numel() == 0:
+            return
+        st = (stream.cuda_stream if stream is not None else torch.cuda.current_stream(pd.device).cuda_stream)
+        _lib.check(lib.vcr_sh_adam_from_rgb(pd.shape[0], int(sh_degree), dirs.data_ptr(), drgb.data_ptr(), pd.data_ptr(),
+                                            pr.data_ptr(), sd["exp_avg"].data_ptr(), sd["exp_avg_sq"].data_ptr(),
+                                            sr["exp_avg"].data_ptr(), sr["exp_avg_sq"].data_ptr(), float(dc["lr"]),
+                                            float(rest["lr"]), self.betas[0], self.betas[1], self.eps, int(sd["step"]),
+                                            float(self.grad_scale), st))
+
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
             for p in g["params"]:

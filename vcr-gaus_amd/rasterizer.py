@@ -6,6 +6,8 @@ the arithmetic is in libvcr_raster.so (HIP, gfx950) reached through ctypes.
 """
 from typing import NamedTuple, Optional
 
+import ctypes as _ct
+
 import torch
 import torch.nn as nn
 
@@ -37,7 +39,13 @@ class _Allocator:
         self.scratch = []
 
         def _cb(_user, tag, nbytes):
-            t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
+            # instance-count dependent sizes change from camera to camera: rounding up to 1/8-octave steps makes the
+            # requests repeat, so the caching allocator reuses its blocks instead of growing (hipMalloc stalls)
+            n = max(int(nbytes), 1)
+            if n > (1 << 20):
+                q = 1 << (n.bit_length() - 4)
+                n = (n + q - 1) // q * q
+            t = torch.empty(n, dtype=torch.uint8, device=self.device)
             if tag == _lib.BUF_SCRATCH:
                 self.scratch.append(t)
             else:
@@ -61,7 +69,27 @@ def _check(rc):
 
 
 SH_GRAD_MODE = "full"   # "rgb": backward skips the SH gradients and leaves dL/drgb [N,3] in `last_drgb` (DP exchange)
-last_drgb = {}
+last_drgb = {}          # "drgb" [N,3] and "dirs" [N,3] (unit view directions) of the most recent "rgb"-mode backward
+COLOUR_STREAM = None    # torch.cuda.Stream: f_count = 0 forwards evaluate SH -> RGB there (VcrRasterArgs.colour_stream)
+COLOUR_HOOK = None      # callable(): enqueue caller work on COLOUR_STREAM ahead of the colour evaluation (colour_stream_hook)
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def modes(sh_grad="full", colour_stream=None, colour_hook=None):
+    """Scoped setting of SH_GRAD_MODE / COLOUR_STREAM / COLOUR_HOOK for the forwards issued inside the block (the backward
+    of such a forward keeps the mode it was recorded with)."""
+    global SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK
+    old = (SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK)
+    SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK = sh_grad, colour_stream, colour_hook
+    try:
+        yield
+    finally:
+        SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK = old
+
+
 NUM_DIST = 0      # trailing channels, the fork's compile-time `NUM_DIST` (README.md:155): 0, 1 = distortion, 2 = sum w d, sum w d^2
 last_stats = {}   # R / V of the most recent forward (for benchmarks; not part of the reference API)
 
@@ -91,6 +119,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                                semantics_precomp=_ptr(t["sem"]), opacities=_ptr(t["opac"]), scales=_ptr(t["scales"]),
                                rotations=_ptr(t["rots"]), cov3D_precomp=_ptr(t["cov"]), dirs=_ptr(t["dirs"]))
         fc = int(rs.f_count)
+        hook = None
+        if COLOUR_STREAM is not None and fc == 0 and t["shs"] is not None:
+            a.colour_stream = COLOUR_STREAM.cuda_stream
+            if COLOUR_HOOK is not None:
+                fn = COLOUR_HOOK
+                hook = _lib.HOOK_FN(lambda _user: fn())            # kept alive until the forward call returns
+                a.colour_stream_hook = _ct.cast(hook, _ct.c_void_p)
         C = 8 + S + int(num_dist)
         out = torch.empty((C if fc == 0 else 3, H, W), dtype=torch.float32, device=dev) if fc != 3 else None
         radii = torch.empty(N, dtype=torch.int32, device=dev)      # fully written by the preprocess kernel
@@ -111,6 +146,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             ctx.num_rendered = int(fo.num_rendered)
             ctx.has = (means2D_densify is not None)
             ctx.num_dist = int(num_dist)
+            ctx.rgb_mode = SH_GRAD_MODE == "rgb" and t["shs"] is not None
             ctx.save_for_backward(radii)
             ctx.mark_non_differentiable(radii)
             return out, radii
@@ -142,10 +178,11 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         d_means3D, d_means2D, d_opac = new(N, 3), new(N, 3), new(N, 1)
         d_dens = new(N, 3) if ctx.has else None
-        rgb_mode = SH_GRAD_MODE == "rgb" and t["shs"] is not None
+        rgb_mode = ctx.rgb_mode
         d_shs = new(*t["shs"].shape) if (t["shs"] is not None and not rgb_mode) else None
         d_shr = new(*t["shs_rest"].shape) if (t["shs_rest"] is not None and not rgb_mode) else None
         d_rgb = new(N, 3) if rgb_mode else None
+        v_dirs = new(N, 3) if rgb_mode else None
         d_col = new(N, 3) if t["colors"] is not None else None
         d_nrm = new(N, 3) if t["normals"] is not None else None
         d_sem = new(N, S) if t["sem"] is not None else None
@@ -156,7 +193,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                 binning=_ptr(ctx.state[_lib.BUF_BINNING]), image=_ptr(ctx.state[_lib.BUF_IMAGE]),
                                 radii=_ptr(radii), num_rendered=ctx.num_rendered, dL_dmeans3D=_ptr(d_means3D),
                                 dL_dmeans2D=_ptr(d_means2D), dL_dmeans2D_densify=_ptr(d_dens), dL_dshs=_ptr(d_shs),
-                                dL_dshs_rest=_ptr(d_shr), dL_drgb=_ptr(d_rgb), dL_dcolors=_ptr(d_col), dL_dnormals=_ptr(d_nrm), dL_dsemantics=_ptr(d_sem),
+                                dL_dshs_rest=_ptr(d_shr), dL_drgb=_ptr(d_rgb), view_dirs=_ptr(v_dirs), dL_dcolors=_ptr(d_col), dL_dnormals=_ptr(d_nrm), dL_dsemantics=_ptr(d_sem),
                                 dL_dopacities=_ptr(d_opac), dL_dscales=_ptr(d_sc), dL_drotations=_ptr(d_rot),
                                 dL_dcov3D=_ptr(d_cov))
         al = _Allocator(dev)
@@ -165,6 +202,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _check(lib.vcr_rasterize_backward(a, io, al.cb, None, stream))
         if rgb_mode:
             last_drgb["drgb"] = d_rgb
+            last_drgb["dirs"] = v_dirs
         return (d_means3D, d_means2D, d_dens, d_shs, d_col, d_nrm, d_sem, d_opac, d_sc, d_rot, d_cov, None, None, d_shr, None)
 
 

@@ -11,6 +11,7 @@ densification statistics), renders ITS OWN camera of the step's batch of `world`
 gradients are summed across ranks and scaled by 1/world inside the fused Adam kernel.  All schedule
 decisions depend only on all-reduced quantities, so replicas stay in lock-step without broadcasts.
 """
+import os
 import random
 
 import torch
@@ -23,7 +24,8 @@ from .normal_utils import get_edge_aware_distortion_map
 
 
 class Trainer:
-    def __init__(self, cfg, model, cameras, extent, device, world=1, rank=0, dirs=None, seed=0, force_factorised=False):
+    def __init__(self, cfg, model, cameras, extent, device, world=1, rank=0, dirs=None, seed=0, force_factorised=False,
+                 overlap_sh=None):
         self.cfg, self.model, self.cameras = cfg, model, cameras
         self.device, self.world, self.rank = device, world, rank
         self.extent = extent
@@ -44,9 +46,41 @@ class Trainer:
         self._picked = []
         # DP: exchange dL/drgb (12 B/Gaussian/view, all-gather) instead of all-reducing the 192 B/Gaussian SH gradients
         self.factorised_sh = world > 1 or force_factorised       # (forcing it at world 1 exercises the path in tests)
-        if self.factorised_sh:
-            from . import rasterizer
-            rasterizer.SH_GRAD_MODE = "rgb"
+        # Single GPU: the SH colour path runs on a second stream.  The backward leaves dL/drgb + view directions
+        # (24 B/Gaussian) instead of the 192 B/Gaussian SH gradient; `vcr_sh_adam_from_rgb` applies Adam to the SH
+        # coefficients on the side stream while the main stream already runs the next iteration's geometry Adam,
+        # activation, projection and the latency-bound sort chain; that iteration's SH -> RGB evaluation follows on the
+        # side stream and is joined before compositing.  Same arithmetic and ordering of updates as the serial loop.
+        if overlap_sh is None:
+            overlap_sh = world == 1 and not force_factorised and str(device).startswith("cuda") \
+                and not os.environ.get("VCR_NO_OVERLAP")
+        self.overlap_sh = bool(overlap_sh) and world == 1
+        self.side = None
+        self._pending_sh = None          # (drgb, view_dirs, sh_degree) of the last backward, not yet applied
+        if self.overlap_sh:
+            self.side = torch.cuda.Stream(device=device)
+            self.factorised_sh = True
+
+    def _launch_pending_sh(self):
+        """Enqueue the deferred SH Adam update on the side stream.  Called from the rasterizer's colour-stream hook, i.e.
+        after the side stream was made to wait for this iteration's projection (hence for the backward that produced
+        the gradients) and before the SH -> RGB evaluation: the update runs beside the latency-bound sort chain."""
+        if self._pending_sh is None:
+            return
+        drgb, vdirs, deg = self._pending_sh
+        self._pending_sh = None
+        drgb.record_stream(self.side)
+        vdirs.record_stream(self.side)
+        self.model.optimizer.step_sh_from_rgb(drgb, vdirs, deg, stream=self.side)
+
+    def join_side(self):
+        """Apply a still-pending SH update and make the current stream wait for the side stream: call before anything
+        that reads or replaces the SH coefficients outside `train_step`'s render (evaluation renders, saving, surgery)."""
+        if self.side is not None:
+            if self._pending_sh is not None:
+                self.side.wait_stream(torch.cuda.current_stream(self.device))
+                self._launch_pending_sh()
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
 
     # ---- camera batch: `world` cameras per step, rank r takes the r-th (`trainer.py:326-328`) -------
     def _next_cameras(self):
@@ -233,7 +267,12 @@ class Trainer:
         bg = self.bg_table[it % self.bg_table.shape[0]] if cfg.optim.random_background else self.background
         fused = getattr(self, "use_fused_losses", True) and not any(
             k in self.weights for k in ("distortion", "depth_var", "semantic", "entropy", "mono_depth"))
-        data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True, geometry=not fused)
+        from . import rasterizer
+        with rasterizer.modes("rgb" if self.factorised_sh else "full", self.side if self.overlap_sh else None,
+                              self._launch_pending_sh if self.overlap_sh else None):
+            data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True, geometry=not fused)
+        if self._pending_sh is not None:         # the render did not go through the two-stream path (e.g. no Gaussians)
+            self.join_side()
         loss = self._compute_loss(data, cam)
         loss.backward()
         with torch.no_grad():
@@ -241,7 +280,16 @@ class Trainer:
                        and it % cfg.optim.densification_interval == 0) \
                 or it % cfg.optim.opacity_reset_interval == 0 or it in cfg.optim.prune.iterations \
                 or (cfg.model.white_background and it == cfg.optim.densify_from_iter)
-            self._allreduce_grads(early_feature_step=not surgery)
+            if self.overlap_sh and not surgery:
+                from . import rasterizer
+                for g in m.optimizer.param_groups:         # moments are created (zero-filled) on THIS stream, ahead of
+                    if g["name"] in ("f_dc", "f_rest"):    # the projection the side stream will wait for
+                        m.optimizer._state(g)
+                m.optimizer.grad_scale = 1.0
+                self._pending_sh = (rasterizer.last_drgb.pop("drgb"), rasterizer.last_drgb.pop("dirs"), int(m.active_sh_degree))
+            else:
+                self.join_side()
+                self._allreduce_grads(early_feature_step=not surgery)
             if it < cfg.optim.densify_until_iter:
                 self._densify_stats(data)
                 if it > cfg.optim.densify_from_iter and it % cfg.optim.densification_interval == 0:
@@ -264,7 +312,7 @@ class Trainer:
 
 
 def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_jitter=0.02, seed=0,
-                           force_factorised=False, **overrides):
+                           force_factorised=False, overlap_sh=None, **overrides):
     """Model + GT (renders of a perturbed copy of the scene, so every loss is non-trivial) + Trainer."""
     from . import synthetic
     from .config import make_config
@@ -283,7 +331,7 @@ def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_
     dirs = get_all_px_dir(cams[0].intr, cams[0].image_height, cams[0].image_width) \
         if cfg.model.depth_type == "intersection" else None
     tr = Trainer(cfg, model, cams, extent, device, world=world, rank=rank, dirs=dirs, seed=seed,
-                 force_factorised=force_factorised)
+                 force_factorised=force_factorised, overlap_sh=overlap_sh)
     # ground truth from a jittered copy
     g = torch.Generator().manual_seed(seed + 1)
     raw2 = {k: v.clone() for k, v in raw.items()}
@@ -322,7 +370,6 @@ class BenchTrainer:
                 raise
             print(f"[bench] factorised SH exchange failed ({e!r}); falling back to dense all-reduce", flush=True)
             self.tr.factorised_sh = False
-            rasterizer.SH_GRAD_MODE = "full"
             rasterizer.last_drgb.clear()
             self.tr.model.optimizer.zero_grad(set_to_none=True)
             self.tr.train_step()
