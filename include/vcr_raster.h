@@ -170,6 +170,9 @@ int vcr_depth_to_normal_backward(int H, int W, float fx, float fy, float cx, flo
 /* rendered normal [3,H,W] -> F.normalize -> [H,W,3] (gaussian_renderer/__init__.py:133-134) */
 int vcr_normalize_chw_forward(int P, const float* in_chw, float* out_hwc, void* stream);
 int vcr_normalize_chw_backward(int P, const float* in_chw, const float* dout_hwc, float* din_chw, void* stream);
+/* total = sum_k res[k] * w[k] - (sub_index >= 0 ? w[sub_index] : 0): the weighted sum of the loss dictionary
+ * (trainer.py:310-321) in one launch; sub_index marks the entry that enters as (1 - value), i.e. SSIM. */
+int vcr_weighted_total(int K, const float* res, const float* w, int sub_index, float* total, void* stream);
 /* monosdf_normal_loss with the cos_weight confidence and boolean mask fused in
  * (tools/loss_utils.py:122-143, trainer.py:261-293).  sums3 (device, fp64, vcr_sums_elems(3) doubles: results
  * first, reduction slots behind) = {sum w|p-g|_1, sum w(1-p.g), count}; loss = (sums[0]+sums[1])/sums[2].

@@ -503,4 +503,18 @@ extern "C" int vcr_scale_reg_backward(int N, const float* scaling_raw, const flo
     return 0;
 }
 
+__global__ void weighted_total_kernel(int K, const float* __restrict__ res, const float* __restrict__ w, int sub_index,
+                                      float* __restrict__ total) {
+    float t = sub_index >= 0 ? -w[sub_index] : 0.f;
+    for (int k = 0; k < K; ++k) t += res[k] * w[k];
+    *total = t;
+}
+
+extern "C" int vcr_weighted_total(int K, const float* res, const float* w, int sub_index, float* total, void* stream) {
+    if (K <= 0 || !res || !w || !total) { vcr_set_error("vcr_weighted_total: bad arguments"); return 1; }
+    hipLaunchKernelGGL(weighted_total_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, K, res, w, sub_index, total);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int vcr_sums_elems(int k) { return k * (1 + VCR_NSLOT); }

@@ -9,6 +9,16 @@ import torch
 from . import _lib
 
 NAMES = ["l1", "ssim", "l1_scale", "mono_normal", "depth_normal", "consistent_normal"]
+_ONES = {}
+
+
+def unit_seed(device):
+    """A cached scalar 1.0 to pass to `loss.backward(...)`: spares autograd's ones_like fill, and the loss node skips
+    the multiplication of its weight vector by it."""
+    k = str(device)
+    if k not in _ONES:
+        _ONES[k] = torch.ones((), device=device)
+    return _ONES[k]
 
 
 class _FusedLosses(torch.autograd.Function):
@@ -25,9 +35,11 @@ class _FusedLosses(torch.autograd.Function):
         est = torch.empty(P * 3, device=dev)
         lib.vcr_normalize_chw_forward(P, base + 4 * P * 4, normal.data_ptr(), st)
         lib.vcr_depth_to_normal_forward(H, W, *intr, base + 3 * P * 4, est.data_ptr(), st)
-        res = torch.zeros(6, device=dev)
         n2, n3 = lib.vcr_sums_elems(2), lib.vcr_sums_elems(3)
-        sums = torch.zeros(n2 + 4 * n3, dtype=torch.float64, device=dev)       # ONE memset for all five reductions
+        # ONE memset for all five reductions and the six results (+ the weighted total), which live in the buffer's tail
+        sums = torch.zeros(n2 + 4 * n3 + 4, dtype=torch.float64, device=dev)
+        res8 = sums[n2 + 4 * n3:].view(torch.float32)
+        res, total = res8[:6], res8[6]
         sp = lambda k: sums.data_ptr() + 8 * (n2 + (k - 1) * n3) if k else sums.data_ptr()
         rp = lambda k: res.data_ptr() + 4 * k
         gi = gt_image.detach().contiguous()
@@ -49,8 +61,8 @@ class _FusedLosses(torch.autograd.Function):
             _lib.check(lib.vcr_normal_loss_forward(P, est.data_ptr(), normal.data_ptr(), None, 0.0, None, None, 0.0, sp(4), rp(5), 1, st))
         ctx.save_for_backward(o, normal, est, gi, part, sums, sr, xz, gn, m, wvec, trans, scale)
         ctx.meta = (H, W, C, tuple(intr), tuple(active), float(exp_t), float(depth_max), n2, n3)
-        # total = sum_k w_k L_k with the ssim entry meaning (1 - ssim): wvec[1] = -w_ssim, constant +w_ssim added here
-        total = torch.dot(res, wvec) - wvec[1]
+        # total = sum_k w_k L_k with the ssim entry meaning (1 - ssim): wvec[1] = -w_ssim, constant +w_ssim added in-kernel
+        _lib.check(lib.vcr_weighted_total(6, res.data_ptr(), wvec.data_ptr(), 1, total.data_ptr(), st))
         ctx.mark_non_differentiable(res)
         return total, res
 
@@ -62,7 +74,8 @@ class _FusedLosses(torch.autograd.Function):
         P = H * W
         dev = o.device
         st = _lib.stream_of(o)
-        seeds = (g_total * wvec).contiguous()
+        one = _ONES.get(str(dev))
+        seeds = wvec if (one is not None and g_total.data_ptr() == one.data_ptr()) else (g_total * wvec).contiguous()
         gp = lambda k: seeds.data_ptr() + 4 * k
         sp = lambda k: sums.data_ptr() + 8 * (n2 + (k - 1) * n3) if k else sums.data_ptr()
         dout = torch.empty_like(o)
@@ -108,6 +121,33 @@ class _FusedLosses(torch.autograd.Function):
         return (dout, d_sc) + (None,) * 11
 
 
+class _LossVals(dict):
+    """Loss dictionary whose "ssim" entry (1 - SSIM index, `trainer.py:238`) is formed when it is read."""
+    ssim_index = None
+
+    def __missing__(self, key):
+        if key == "ssim" and self.ssim_index is not None:
+            v = 1.0 - self.ssim_index
+            self[key] = v
+            return v
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return (key == "ssim" and self.ssim_index is not None) or dict.__contains__(self, key)
+
+    def items(self):
+        self["ssim"]
+        return dict.items(self)
+
+    def keys(self):
+        self["ssim"]
+        return dict.keys(self)
+
+    def __iter__(self):
+        self["ssim"]
+        return dict.__iter__(self)
+
+
 def fused_losses(out, model, cam, weights, it, optim_cfg, extent, mask=None):
     """-> (total, {name: value}) for the losses of `weights` that this node covers (`NAMES`)."""
     w = [float(weights.get(n, 0.0)) for n in NAMES]
@@ -125,7 +165,8 @@ def fused_losses(out, model, cam, weights, it, optim_cfg, extent, mask=None):
     total, res = _FusedLosses.apply(out, model._scaling, model._xyz, cam.original_image, getattr(cam, "normal", None), mask,
                                     cam.intr_scalars, cache[key], tuple(active), optim_cfg.exp_t, depth_max, model.trans,
                                     model.scale)
-    vals = {"l1": res[0], "ssim": 1.0 - res[1]}
+    vals = _LossVals({"l1": res[0]})
+    vals.ssim_index = res[1]
     for k in range(2, 6):
         if active[k]:
             vals[NAMES[k]] = res[k]

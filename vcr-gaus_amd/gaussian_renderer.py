@@ -40,6 +40,21 @@ def _cam_rotation(cam, device):
     return R.to(device)
 
 
+class _RenderOut(dict):
+    """The reference's return dictionary; with `lazy_mask` the [N] `visibility_filter` (radii > 0) is only materialised
+    when somebody reads it (the fused trainer hands `radii` to the densification-statistics kernel instead)."""
+
+    def __missing__(self, key):
+        if key == "visibility_filter":
+            v = self["radii"] > 0
+            self[key] = v
+            return v
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return key == "visibility_filter" or dict.__contains__(self, key)
+
+
 def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_color=None, return_normal=True,
            is_all=True, dirs=None, mask_depth_thr=0.8, lazy_mask=False, geometry=True):
     """Background tensor (bg_color) must be on the GPU.  Returns the reference's dict:
@@ -93,10 +108,12 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
         normal = normalize_rendered_normal(rendered_normal)
         est_normal = compute_normals(rendered_depth, viewpoint_camera.intr,
                                      getattr(viewpoint_camera, "intr_scalars", None))
-    out = {"render": rendered_image, "depth": rendered_depth, "normal": normal, "est_normal": est_normal,
-           "alpha": rendered_alpha, "viewspace_points": screenspace_points,
-           "viewspace_points_densify": screenspace_points_densify, "visibility_filter": radii > 0, "mask": mask,
-           "mask_static": cam_mask, "radii": radii, "render_out": rendered_out}
+    out = _RenderOut({"render": rendered_image, "depth": rendered_depth, "normal": normal, "est_normal": est_normal,
+                      "alpha": rendered_alpha, "viewspace_points": screenspace_points,
+                      "viewspace_points_densify": screenspace_points_densify, "mask": mask,
+                      "mask_static": cam_mask, "radii": radii, "render_out": rendered_out})
+    if not lazy_mask:
+        out["visibility_filter"] = radii > 0
     if cfg.optim.loss_weight.semantic > 0:
         sem = rendered_out[8:8 + cfg.model.ch_sem_feat]
         out["render_sem"] = pc.classifier(sem[None])[0].permute(1, 2, 0)

@@ -199,13 +199,13 @@ class Trainer:
         m = self.model
         vp = data["viewspace_points_densify"]
         if self.world == 1 and not getattr(self, "force_collectives", False):
-            m.add_densification_stats(vp, data["visibility_filter"], radii=data["radii"])
+            m.add_densification_stats(vp, None, radii=data["radii"])
             return
         N = m._xyz.shape[0]
         acc, den, mr = torch.zeros(N, 1, device=self.device), torch.zeros(N, 1, device=self.device), torch.zeros(N, device=self.device)
         keep = (m.xyz_gradient_accum, m.denom, m.max_radii2D)
         m.xyz_gradient_accum, m.denom, m.max_radii2D = acc, den, mr
-        m.add_densification_stats(vp, data["visibility_filter"], radii=data["radii"])
+        m.add_densification_stats(vp, None, radii=data["radii"])
         m.xyz_gradient_accum, m.denom, m.max_radii2D = keep
         pair = torch.cat([acc, den], 1)
         w1 = dist.all_reduce(pair, op=dist.ReduceOp.SUM, async_op=True)
@@ -274,7 +274,8 @@ class Trainer:
         if self._pending_sh is not None:         # the render did not go through the two-stream path (e.g. no Gaussians)
             self.join_side()
         loss = self._compute_loss(data, cam)
-        loss.backward()
+        from .fused_losses import unit_seed
+        loss.backward(unit_seed(loss.device))
         with torch.no_grad():
             surgery = (it < cfg.optim.densify_until_iter and it > cfg.optim.densify_from_iter
                        and it % cfg.optim.densification_interval == 0) \
