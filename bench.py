@@ -136,6 +136,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trainer.prime()              # set-up (allocator sizes of every camera), then the W warm-up steps of the contract
     for i in range(args.warmup):
         trainer.step(i)
     sync()

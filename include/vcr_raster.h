@@ -148,6 +148,12 @@ int vcr_sh_grad_from_rgb(int N, int sh_degree, int nviews, const float* xyz, con
 int vcr_sh_adam_from_rgb(int N, int sh_degree, const float* view_dirs, const float* drgb, float* features_dc,
                          float* features_rest, float* m_dc, float* v_dc, float* m_rest, float* v_rest, float lr_dc,
                          float lr_rest, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+/* The rasterizer's own stable LSD radix sort of (u32 key, u32 value) pairs on key bits [begin_bit, end_bit) (at most
+ * 32 bits = 4 passes), exposed for testing and reuse; replaces cub/rocPRIM DeviceRadixSort::SortPairs in the public
+ * rasterizer's binning.  vals_in == NULL sorts the identity permutation.  scratch: vcr_sort_pairs_u32_scratch_bytes(n). */
+size_t vcr_sort_pairs_u32_scratch_bytes(int64_t n);
+int vcr_sort_pairs_u32(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                       int begin_bit, int end_bit, void* scratch, size_t scratch_bytes, void* stream);
 /* simple_knn._C.distCUDA2 (scene/gaussian_model.py:17-20,211): mean squared distance to the 3 nearest neighbours,
  * points [N,3] -> out [N].  Exact brute force (one-time initialisation from the SfM point cloud). */
 int vcr_knn3_mean_dist2(int N, const float* points, float* out, void* stream);

@@ -322,3 +322,108 @@ def test_fused_loss_node_matches_modular_losses(device):
     for k in finals[0]:
         d = float((finals[0][k] - finals[1][k]).abs().max())
         assert d < 2e-3 * max(1.0, float(finals[0][k].abs().max())), (k, d)
+
+
+@pytest.mark.parametrize("n,bits,iota", [(1, 32, True), (777, 32, True), (8193, 9, False), (300001, 32, True),
+                                         (1000000, 13, False), (70000, 17, False)])
+def test_radix_sort_pairs_is_stable_and_matches_torch(device, n, bits, iota):
+    """vcr_sort_pairs_u32 (the rasterizer's depth / tile sort): stable, exact, ragged sizes, partial last pass."""
+    import ctypes as C
+    from vcr_gaus_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + bits)
+    if bits == 32:         # positive float bit patterns, like the depth keys (many ties in the high bytes)
+        keys = (0.2 + 20.0 * torch.rand(n, generator=g)).float().view(torch.int32)
+    else:
+        keys = torch.randint(0, 1 << bits, (n,), generator=g, dtype=torch.int32)
+    keys = keys.to(device)
+    vals = None if iota else torch.randint(0, 2 ** 31 - 1, (n,), generator=g, dtype=torch.int32).to(device)
+    ko, vo = torch.empty_like(keys), torch.empty_like(keys)
+    nb = lib.vcr_sort_pairs_u32_scratch_bytes(n)
+    scratch = torch.empty(nb, dtype=torch.uint8, device=device)
+    _lib.check(lib.vcr_sort_pairs_u32(n, keys.data_ptr(), None if iota else vals.data_ptr(), ko.data_ptr(), vo.data_ptr(), 0, bits,
+                                      scratch.data_ptr(), nb, _lib.stream_of(keys)))
+    order = torch.sort(keys.cpu().long(), stable=True).indices
+    assert torch.equal(ko.cpu(), keys.cpu()[order])
+    ref_v = order.int() if iota else vals.cpu()[order]
+    assert torch.equal(vo.cpu(), ref_v)
+
+
+def test_sh_adam_from_rgb_equals_dense_gradient_plus_adam(device):
+    """vcr_sh_adam_from_rgb == (vcr_sh_grad_from_rgb -> vcr_adam_step) on the SH groups, for an inactive top degree too."""
+    import ctypes as C
+    from vcr_gaus_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    n = 5000
+    xyz = torch.randn(n, 3, generator=g).to(device)
+    campos = torch.tensor([[0.3, -2.0, 4.0]], device=device)
+    dirs = torch.nn.functional.normalize(xyz - campos, dim=1).contiguous()
+    drgb = torch.randn(n, 3, generator=g).to(device) * (torch.rand(n, 1, generator=g).to(device) > 0.3)   # some zero rows
+    for deg, step in ((3, 1), (2, 7)):
+        dc0, rest0 = torch.randn(n, 1, 3, generator=g).to(device), torch.randn(n, 15, 3, generator=g).to(device)
+        m0 = [0.01 * torch.randn(n, 1, 3, generator=g).to(device), 0.01 * torch.randn(n, 15, 3, generator=g).to(device)]
+        v0 = [1e-4 * torch.rand(n, 1, 3, generator=g).to(device), 1e-4 * torch.rand(n, 15, 3, generator=g).to(device)]
+        st = _lib.stream_of(xyz)
+        # reference: dense gradient, then the multi-tensor Adam kernel
+        gd, gr = torch.empty(n, 1, 3, device=device), torch.empty(n, 15, 3, device=device)
+        _lib.check(lib.vcr_sh_grad_from_rgb(n, deg, 1, xyz.data_ptr(), campos.data_ptr(), drgb.contiguous().data_ptr(),
+                                            gd.data_ptr(), gr.data_ptr(), st))
+        p = [dc0.clone(), rest0.clone()]
+        m, v = [t.clone() for t in m0], [t.clone() for t in v0]
+        arr = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])
+        _lib.check(lib.vcr_adam_step(2, arr(p), arr([gd, gr]), arr(m), arr(v), (C.c_int64 * 2)(3 * n, 45 * n),
+                                     (C.c_float * 2)(0.0025, 0.000125), 0.9, 0.999, 1e-15, step, 1.0, st))
+        # fused
+        q = [dc0.clone(), rest0.clone()]
+        mq, vq = [t.clone() for t in m0], [t.clone() for t in v0]
+        _lib.check(lib.vcr_sh_adam_from_rgb(n, deg, dirs.data_ptr(), drgb.contiguous().data_ptr(), q[0].data_ptr(), q[1].data_ptr(),
+                                            mq[0].data_ptr(), vq[0].data_ptr(), mq[1].data_ptr(), vq[1].data_ptr(), 0.0025, 0.000125,
+                                            0.9, 0.999, 1e-15, step, 1.0, st))
+        for a, b in zip(p + m + v, q + mq + vq):
+            assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), float((a - b).abs().max())
+
+
+def test_weighted_total(device):
+    from vcr_gaus_amd import _lib
+    lib = _lib.load()
+    res = torch.tensor([0.1, 0.8, 0.3, 0.0, 2.0, 0.5], device=device)
+    w = torch.tensor([0.8, -0.2, 100.0, 0.0, 0.015, 0.05], device=device)
+    out = torch.zeros(1, device=device)
+    _lib.check(lib.vcr_weighted_total(6, res.data_ptr(), w.data_ptr(), 1, out.data_ptr(), _lib.stream_of(res)))
+    ref = float((res.double() * w.double()).sum() - w[1].double())
+    assert abs(float(out) - ref) < 1e-5 * abs(ref)
+
+
+def test_colour_stream_render_is_identical(device):
+    """SH -> RGB on a second stream (VcrRasterArgs.colour_stream, with a hook that enqueues foreign work first) gives the
+    same image and gradients as the single-stream call."""
+    from vcr_gaus_amd import rasterizer, synthetic
+    from vcr_gaus_amd.config import make_config
+    from vcr_gaus_amd.gaussian_model import GaussianModel
+    from vcr_gaus_amd.gaussian_renderer import render
+    from vcr_gaus_amd.graphics_utils import get_all_px_dir
+    raw = synthetic.make_gaussians(20000, seed=9)
+    cams = synthetic.make_cameras(2, 160, 120, 140.0, device=device)
+    cfg = make_config("tnt")
+    m = GaussianModel(cfg.model)
+    m.create_from_params(raw, spatial_lr_scale=1.0, device=device)
+    m.active_sh_degree = 3
+    dirs = get_all_px_dir(cams[0].intr, 120, 160)
+    bg = torch.zeros(3, device=device)
+    outs = []
+    side = torch.cuda.Stream(device=device)
+    called = []
+    for two in (False, True):
+        for p in (m._features_dc, m._features_rest, m._xyz):
+            p.grad = None
+        hook = (lambda: called.append(torch.zeros(1 << 20, device=device).add_(1.0))) if two else None
+        with rasterizer.modes("full", side if two else None, hook):
+            pkg = render(cams[1], m, cfg, bg, dirs=dirs)
+        (pkg["render"].sum() + pkg["depth"].sum()).backward()
+        torch.cuda.synchronize()
+        outs.append((pkg["render_out"].detach().clone(), m._features_rest.grad.clone(), m._xyz.grad.clone()))
+    assert called, "the colour-stream hook was not invoked"
+    for a, b in zip(*outs):
+        assert torch.equal(a, b) or torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+    assert torch.equal(outs[0][0], outs[1][0])          # the image is bit-identical

@@ -245,3 +245,26 @@ def test_virtual_visibility_cameras_look_at_box_floor():
     cams = sample_cameras(3, trans, scale, device="cpu", generator=torch.Generator().manual_seed(1))
     assert cams[0].image_width == 1500 and abs(cams[0].FoVx - 2.5) < 1e-9
     assert torch.allclose(cams[0].camera_center, -(cams[0].world_view_transform[:3, :3] @ cams[0].world_view_transform[3, :3]), atol=1e-4)
+
+
+def test_lazy_dictionaries_and_scoped_modes():
+    """Host logic of the trimmed step: render / loss dictionaries materialise derived entries on read, rasterizer modes
+    are scoped, scratch sizes are rounded to 1/8-octave steps."""
+    from vcr_gaus_amd import rasterizer
+    from vcr_gaus_amd.fused_losses import _LossVals
+    from vcr_gaus_amd.gaussian_renderer import _RenderOut
+    r = _RenderOut({"radii": torch.tensor([0, 3, 0, 1])})
+    assert "visibility_filter" in r and not dict.__contains__(r, "visibility_filter")
+    assert r["visibility_filter"].tolist() == [False, True, False, True] and dict.__contains__(r, "visibility_filter")
+    with pytest.raises(KeyError):
+        r["nope"]
+    v = _LossVals({"l1": torch.tensor(0.25)})
+    v.ssim_index = torch.tensor(0.9)
+    assert "ssim" in v and abs(float(v["ssim"]) - 0.1) < 1e-6 and set(v.keys()) == {"l1", "ssim"}
+    assert rasterizer.SH_GRAD_MODE == "full" and rasterizer.COLOUR_STREAM is None
+    with rasterizer.modes("rgb", colour_stream="S", colour_hook=len):
+        assert (rasterizer.SH_GRAD_MODE, rasterizer.COLOUR_STREAM, rasterizer.COLOUR_HOOK) == ("rgb", "S", len)
+        with rasterizer.modes():
+            assert rasterizer.SH_GRAD_MODE == "full" and rasterizer.COLOUR_STREAM is None
+        assert rasterizer.SH_GRAD_MODE == "rgb"
+    assert (rasterizer.SH_GRAD_MODE, rasterizer.COLOUR_STREAM, rasterizer.COLOUR_HOOK) == ("full", None, None)

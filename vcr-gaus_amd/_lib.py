@@ -58,6 +58,8 @@ SYMBOLS = {
     "vcr_rasterize_backward": (C.c_int, [C.POINTER(VcrRasterArgs), C.POINTER(VcrBackwardIO), ALLOC_FN, C.c_void_p, C.c_void_p]),
     "vcr_activate_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 12),
     "vcr_activate_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 13),
+    "vcr_sort_pairs_u32_scratch_bytes": (C.c_size_t, [C.c_int64]),
+    "vcr_sort_pairs_u32": (C.c_int, [C.c_int64] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "vcr_weighted_total": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "vcr_sh_grad_from_rgb": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "vcr_sh_adam_from_rgb": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_float] * 5 + [C.c_int, C.c_float, C.c_void_p]),

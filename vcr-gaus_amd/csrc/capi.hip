@@ -136,6 +136,28 @@ int tile_bits_for(int T) {
 extern "C" int vcr_abi_version(void) { return VCR_ABI_VERSION; }
 extern "C" const char* vcr_last_error(void) { return g_err; }
 
+extern "C" int vcr_sort_pairs_u32(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
+                                  uint32_t* vals_out, int begin_bit, int end_bit, void* scratch, size_t scratch_bytes,
+                                  void* stream) {
+    if (n <= 0) return 0;
+    if (!keys_in || !keys_out || !vals_out || begin_bit < 0 || end_bit > 32 || begin_bit >= end_bit) {
+        vcr_set_error("vcr_sort_pairs_u32: bad arguments"); return 1;
+    }
+    const size_t nb = vcr_align(sizeof(uint32_t) * (size_t)n), tot = vcr_align(sizeof(uint32_t) * VCR_SORT_TOTALS_WORDS);
+    const size_t need = 2 * nb + tot + vcr_sort_scratch_bytes(n);
+    if (!scratch || scratch_bytes < need) { vcr_set_error("vcr_sort_pairs_u32: scratch too small (%zu < %zu)", scratch_bytes, need); return 1; }
+    char* s = (char*)scratch;
+    hipStream_t st = (hipStream_t)stream;
+    VCR_HIP_CHECK(hipMemsetAsync(s + 2 * nb, 0, tot, st));
+    return vcr_sort_pairs(n, keys_in, vals_in, (uint32_t*)s, (uint32_t*)(s + nb), keys_out, vals_out, begin_bit, end_bit,
+                          (uint32_t*)(s + 2 * nb + tot), (uint32_t*)(s + 2 * nb), st);
+}
+
+extern "C" size_t vcr_sort_pairs_u32_scratch_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    return 2 * vcr_align(sizeof(uint32_t) * (size_t)n) + vcr_align(sizeof(uint32_t) * VCR_SORT_TOTALS_WORDS) + vcr_sort_scratch_bytes(n);
+}
+
 extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* out, vcr_alloc_fn alloc, void* user,
                                      void* stream) {
     if (validate(args)) return 1;
