@@ -199,6 +199,20 @@ int vcr_scale_reg_forward(int N, const float* scaling_raw, const float* xyz, con
                           double* sums3, float* loss, int sums_prezeroed, void* stream);
 int vcr_scale_reg_backward(int N, const float* scaling_raw, const float* xyz, const float* trans, const float* scale,
                            const double* sums3, const float* gout, float* dscaling, void* stream);
+/* All three normal losses of trainer.py:261-293 in one pass each way on the rasterizer output: mono_normal (bit 0 of
+ * `active`) = monosdf_normal_loss(n, gt), depth_normal (bit 1) = the same on est with the cos_weight confidence, the
+ * camera mask and the depth threshold (depth_max <= 0: none), consistent_normal (bit 2) = monosdf_normal_loss(est, n),
+ * where n = F.normalize(normal_planes [3,H,W]) and est = compute_normals(depth [H,W]).  sums9: vcr_sums_elems(9) doubles;
+ * res3 / seeds3: the three loss values / their upstream gradients.  The backward writes d(depth) [H,W] and
+ * d(normal_planes) [3,H,W]; scratch6 is [H*W*6] floats. */
+int vcr_normal_losses_forward(int H, int W, float fx, float fy, float cx, float cy, const float* depth,
+                              const float* normal_planes, const float* gt /* [H*W,3] or NULL */,
+                              const uint8_t* mask /* [H*W] or NULL */, float depth_max, float exp_t, int active,
+                              double* sums9, float* res3, int sums_prezeroed, void* stream);
+int vcr_normal_losses_backward(int H, int W, float fx, float fy, float cx, float cy, const float* depth,
+                               const float* normal_planes, const float* gt, const uint8_t* mask, float depth_max,
+                               float exp_t, int active, const double* sums9, const float* seeds3, float* scratch6,
+                               float* d_depth, float* d_normal_planes, void* stream);
 /* l1_loss + ssim (tools/loss_utils.py:36,49-92) in one pass over [3,H,W] images.  sums2 (device, fp64) =
  * {sum|a-b|, sum ssim_map}; partials9: [9,H,W] scratch kept for backward (NULL for inference). */
 int vcr_l1_ssim_forward(int H, int W, const float* img1, const float* img2, double* sums2, float* means2 /* {l1, ssim} */,

@@ -427,3 +427,58 @@ def test_colour_stream_render_is_identical(device):
     for a, b in zip(*outs):
         assert torch.equal(a, b) or torch.allclose(a, b, rtol=1e-4, atol=1e-6)
     assert torch.equal(outs[0][0], outs[1][0])          # the image is bit-identical
+
+
+@pytest.mark.parametrize("active", [1, 2, 3, 4, 7, 6])
+def test_fused_normal_losses_match_the_modular_operators(device, active):
+    """vcr_normal_losses_forward/backward == normalize + compute_normals + normal_loss x3 (values and gradients w.r.t. the
+    depth and normal planes), with the camera mask and the depth threshold, on a ragged image."""
+    from vcr_gaus_amd import _lib
+    from vcr_gaus_amd.loss_utils import normal_loss
+    from vcr_gaus_amd.normal_utils import compute_normals, normalize_rendered_normal
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(100 + active)
+    H, W = 70, 93
+    P = H * W
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    depth = (2.0 + 0.01 * xx + 0.02 * yy + 0.05 * torch.rand(H, W, generator=g)).to(device)
+    nrm = torch.randn(3, H, W, generator=g).to(device)
+    gt = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=1).to(device).contiguous()
+    mask = (torch.rand(H, W, generator=g) > 0.2).to(device)
+    K = torch.tensor([[80.0, 0, 46.0], [0, 82.0, 35.5], [0, 0, 1.0]])
+    intr = (80.0, 82.0, 46.0, 35.5)
+    depth_max, exp_t = 3.6, 0.01
+    seeds = torch.tensor([0.7, 1.3, 0.4], device=device)
+    # reference through the modular autograd operators
+    d_ref = depth.clone().requires_grad_(True)
+    n_ref = nrm.clone().requires_grad_(True)
+    n = normalize_rendered_normal(n_ref)
+    est = compute_normals(d_ref[None], K, intr)
+    vals = [torch.zeros((), device=device)] * 3
+    if active & 1:
+        vals[0] = normal_loss(n, gt.view(H, W, 3))
+    if active & 2:
+        vals[1] = normal_loss(est, gt.view(H, W, 3), weight_src=n.detach(), exp_t=exp_t, mask=mask, depth=d_ref.detach()[None],
+                              depth_max=depth_max)
+    if active & 4:
+        vals[2] = normal_loss(est, n)
+    (seeds[0] * vals[0] + seeds[1] * vals[1] + seeds[2] * vals[2]).backward()
+    # fused
+    n9 = lib.vcr_sums_elems(9)
+    sums = torch.zeros(n9, dtype=torch.float64, device=device)
+    res = torch.zeros(3, device=device)
+    st = _lib.stream_of(depth)
+    m8 = mask.view(-1).to(torch.uint8).contiguous()
+    _lib.check(lib.vcr_normal_losses_forward(H, W, *intr, depth.data_ptr(), nrm.data_ptr(), gt.data_ptr(), m8.data_ptr(), depth_max,
+                                             exp_t, active, sums.data_ptr(), res.data_ptr(), 1, st))
+    for k in range(3):
+        assert abs(float(res[k]) - float(vals[k])) < 2e-5 * max(1.0, abs(float(vals[k]))), (k, float(res[k]), float(vals[k]))
+    dd, dn = torch.empty(H, W, device=device), torch.empty(3, H, W, device=device)
+    scratch = torch.empty(P * 6, device=device)
+    _lib.check(lib.vcr_normal_losses_backward(H, W, *intr, depth.data_ptr(), nrm.data_ptr(), gt.data_ptr(), m8.data_ptr(), depth_max,
+                                              exp_t, active, sums.data_ptr(), seeds.data_ptr(), scratch.data_ptr(), dd.data_ptr(),
+                                              dn.data_ptr(), st))
+    ref_dd = d_ref.grad if d_ref.grad is not None else torch.zeros_like(dd)
+    ref_dn = n_ref.grad if n_ref.grad is not None else torch.zeros_like(dn)
+    assert float((dd - ref_dd).abs().max()) <= 1e-4 * float(ref_dd.abs().max()) + 1e-9
+    assert float((dn - ref_dn).abs().max()) <= 1e-4 * float(ref_dn.abs().max()) + 1e-9

@@ -60,6 +60,10 @@ SYMBOLS = {
     "vcr_activate_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 13),
     "vcr_sort_pairs_u32_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "vcr_sort_pairs_u32": (C.c_int, [C.c_int64] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vcr_normal_losses_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vcr_normal_losses_backward": (C.c_int, [C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int]
+                                   + [C.c_void_p] * 6),
     "vcr_weighted_total": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "vcr_sh_grad_from_rgb": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "vcr_sh_adam_from_rgb": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_float] * 5 + [C.c_int, C.c_float, C.c_void_p]),

@@ -240,6 +240,137 @@ __global__ void __launch_bounds__(256) normal_loss_bwd_kernel(int P, const float
     }
 }
 
+// ---------------- all three normal losses in one pass each way ---------------------------------------
+// mono_normal L3 = normal_loss(n, gt); depth_normal L4 = normal_loss(est, gt, weight exp((n.gt - 1)/exp_t), mask, depth
+// threshold); consistent_normal L5 = normal_loss(est, n), with n = normalize(rendered normal), est = depth -> normal
+// (trainer.py:261-293).  One forward kernel replaces normalize + depth_to_normal + up to three loss kernels; one backward
+// kernel replaces the loss backwards, the normalisation backward and stage 1 of the depth-to-normal adjoint.  n and est
+// are recomputed in the backward instead of being stored (the depth stencil is L2-resident).
+// sums9: [9 totals][VCR_NSLOT x 9]: triple (sum w|p-g|_1, sum w(1-p.g), count) per loss.
+struct PixNormals { float n[3], nlen, raw[3], e[3], elen, dx[3], dy[3], c[3]; };
+
+__device__ __forceinline__ void pixel_normals(int H, int W, Intr k, const float* __restrict__ depth,
+                                              const float* __restrict__ nrm, int x, int y, PixNormals& q) {
+    const size_t P = (size_t)H * W, i = (size_t)y * W + x;
+    q.raw[0] = nrm[i]; q.raw[1] = nrm[P + i]; q.raw[2] = nrm[2 * P + i];
+    q.nlen = sqrtf(q.raw[0] * q.raw[0] + q.raw[1] * q.raw[1] + q.raw[2] * q.raw[2]);
+    const float ni = 1.f / fmaxf(q.nlen, 1e-12f);
+    q.n[0] = q.raw[0] * ni; q.n[1] = q.raw[1] * ni; q.n[2] = q.raw[2] * ni;
+    grad_cols(depth, W, H, x, y, k, q.dx);
+    grad_rows(depth, W, H, x, y, k, q.dy);
+    q.c[0] = q.dx[1] * q.dy[2] - q.dx[2] * q.dy[1]; q.c[1] = q.dx[2] * q.dy[0] - q.dx[0] * q.dy[2];
+    q.c[2] = q.dx[0] * q.dy[1] - q.dx[1] * q.dy[0];
+    q.elen = sqrtf(q.c[0] * q.c[0] + q.c[1] * q.c[1] + q.c[2] * q.c[2]);
+    const float ei = 1.f / fmaxf(q.elen, 1e-12f);
+    q.e[0] = q.c[0] * ei; q.e[1] = q.c[1] * ei; q.e[2] = q.c[2] * ei;
+}
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ void __launch_bounds__(256) normal_losses_fwd_kernel(int H, int W, Intr k, const float* __restrict__ depth,
+                                                                const float* __restrict__ nrm, const float* __restrict__ gt,
+                                                                const uint8_t* __restrict__ mask, float depth_max, float exp_t,
+                                                                int active, double* __restrict__ sums9) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    float v[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (x < W && y < H) {
+        PixNormals q;
+        pixel_normals(H, W, k, depth, nrm, x, y, q);
+        const size_t i = (size_t)y * W + x;
+        float g[3] = {0.f, 0.f, 0.f};
+        if (active & 3) { g[0] = gt[3 * i]; g[1] = gt[3 * i + 1]; g[2] = gt[3 * i + 2]; }
+        if (active & 1) {
+            v[0] = fabsf(q.n[0] - g[0]) + fabsf(q.n[1] - g[1]) + fabsf(q.n[2] - g[2]);
+            v[1] = 1.f - (q.n[0] * g[0] + q.n[1] * g[1] + q.n[2] * g[2]);
+            v[2] = 1.f;
+        }
+        if ((active & 2) && (!mask || mask[i]) && !(depth_max > 0.f && !(depth[i] < depth_max))) {
+            float w = 1.f;
+            if (exp_t > 0.f) w = __expf((q.n[0] * g[0] + q.n[1] * g[1] + q.n[2] * g[2] - 1.f) / exp_t);
+            v[3] = w * (fabsf(q.e[0] - g[0]) + fabsf(q.e[1] - g[1]) + fabsf(q.e[2] - g[2]));
+            v[4] = w * (1.f - (q.e[0] * g[0] + q.e[1] * g[1] + q.e[2] * g[2]));
+            v[5] = 1.f;
+        }
+        if (active & 4) {
+            v[6] = fabsf(q.e[0] - q.n[0]) + fabsf(q.e[1] - q.n[1]) + fabsf(q.e[2] - q.n[2]);
+            v[7] = 1.f - (q.e[0] * q.n[0] + q.e[1] * q.n[1] + q.e[2] * q.n[2]);
+            v[8] = 1.f;
+        }
+    }
+    block_accumulate<9>(sums9 + 9, v);
+}
+
+// totals + the three losses (0 when a loss has no selected pixel / is inactive)
+__global__ void finalize_normal_losses_kernel(double* __restrict__ sums9, float* __restrict__ res3) {
+    __shared__ double s_t[9];
+    for (int k = 0; k < 9; ++k) {
+        double t = 0.0;
+        for (int s = threadIdx.x; s < VCR_NSLOT; s += 64) t += sums9[9 + (size_t)s * 9 + k];
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (threadIdx.x == 0) { s_t[k] = t; sums9[k] = t; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int l = threadIdx.x;
+        res3[l] = s_t[3 * l + 2] > 0.0 ? (float)((s_t[3 * l] + s_t[3 * l + 1]) / s_t[3 * l + 2]) : 0.f;
+    }
+}
+
+// seeds3: dL/dL3, dL/dL4, dL/dL5 (device).  Writes d(out) for the three normal planes and the [P,6] stage-1 scratch of the
+// depth-to-normal adjoint (consumed by depth_normal_bwd2_kernel).
+__global__ void __launch_bounds__(256) normal_losses_bwd_kernel(int H, int W, Intr k, const float* __restrict__ depth,
+                                                                const float* __restrict__ nrm, const float* __restrict__ gt,
+                                                                const uint8_t* __restrict__ mask, float depth_max, float exp_t,
+                                                                int active, const double* __restrict__ sums9,
+                                                                const float* __restrict__ seeds3, float* __restrict__ dnrm,
+                                                                float* __restrict__ dgrad) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    PixNormals q;
+    pixel_normals(H, W, k, depth, nrm, x, y, q);
+    const size_t P = (size_t)H * W, i = (size_t)y * W + x;
+    float g[3] = {0.f, 0.f, 0.f};
+    if (active & 3) { g[0] = gt[3 * i]; g[1] = gt[3 * i + 1]; g[2] = gt[3 * i + 2]; }
+    float dn[3] = {0.f, 0.f, 0.f}, de[3] = {0.f, 0.f, 0.f};
+    if ((active & 1) && sums9[2] > 0.0) {
+        const float sc = seeds3[0] / (float)sums9[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dn[j] += sc * (sgn(q.n[j] - g[j]) - g[j]);
+    }
+    if ((active & 2) && sums9[5] > 0.0 && (!mask || mask[i]) && !(depth_max > 0.f && !(depth[i] < depth_max))) {
+        float w = 1.f;
+        if (exp_t > 0.f) w = __expf((q.n[0] * g[0] + q.n[1] * g[1] + q.n[2] * g[2] - 1.f) / exp_t);
+        const float sc = seeds3[1] / (float)sums9[5] * w;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) de[j] += sc * (sgn(q.e[j] - g[j]) - g[j]);
+    }
+    if ((active & 4) && sums9[8] > 0.0) {
+        const float sc = seeds3[2] / (float)sums9[8];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float sg = sgn(q.e[j] - q.n[j]);
+            de[j] += sc * (sg - q.n[j]);
+            dn[j] += sc * (-sg - q.e[j]);
+        }
+    }
+    // through n = raw / |raw|
+    float d0, d1, d2;
+    if (q.nlen > 1e-12f) {
+        const float inv = 1.f / q.nlen, dot = q.n[0] * dn[0] + q.n[1] * dn[1] + q.n[2] * dn[2];
+        d0 = (dn[0] - q.n[0] * dot) * inv; d1 = (dn[1] - q.n[1] * dot) * inv; d2 = (dn[2] - q.n[2] * dot) * inv;
+    } else { d0 = dn[0] * 1e12f; d1 = dn[1] * 1e12f; d2 = dn[2] * 1e12f; }
+    dnrm[i] = d0; dnrm[P + i] = d1; dnrm[2 * P + i] = d2;
+    // through est = c / |c|, c = dx x dy   (stage 1 of the depth-to-normal adjoint)
+    float dc[3];
+    if (q.elen > 1e-12f) {
+        const float inv = 1.f / q.elen, dot = q.e[0] * de[0] + q.e[1] * de[1] + q.e[2] * de[2];
+        dc[0] = (de[0] - q.e[0] * dot) * inv; dc[1] = (de[1] - q.e[1] * dot) * inv; dc[2] = (de[2] - q.e[2] * dot) * inv;
+    } else { dc[0] = de[0] * 1e12f; dc[1] = de[1] * 1e12f; dc[2] = de[2] * 1e12f; }
+    float* o = dgrad + 6 * i;
+    o[0] = q.dy[1] * dc[2] - q.dy[2] * dc[1]; o[1] = q.dy[2] * dc[0] - q.dy[0] * dc[2]; o[2] = q.dy[0] * dc[1] - q.dy[1] * dc[0];
+    o[3] = dc[1] * q.dx[2] - dc[2] * q.dx[1]; o[4] = dc[2] * q.dx[0] - dc[0] * q.dx[2]; o[5] = dc[0] * q.dx[1] - dc[1] * q.dx[0];
+}
+
 // ---------------- fused L1 + SSIM ------------------------------------------------------------------
 #define SSIM_R 5
 #define SSIM_TX 32
@@ -475,6 +606,33 @@ static GaussWin make_window() {
     for (int i = 0; i < 11; ++i) { v[i] = exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); s += v[i]; }
     for (int i = 0; i < 11; ++i) g.w[i] = (float)(v[i] / s);
     return g;
+}
+
+extern "C" int vcr_normal_losses_forward(int H, int W, float fx, float fy, float cx, float cy, const float* depth,
+                                         const float* normal_planes, const float* gt, const uint8_t* mask, float depth_max,
+                                         float exp_t, int active, double* sums9, float* res3, int sums_prezeroed, void* stream) {
+    if ((active & 3) && !gt) { vcr_set_error("vcr_normal_losses_forward: gt is NULL"); return 1; }
+    if (!sums_prezeroed) VCR_HIP_CHECK(hipMemsetAsync(sums9, 0, 9 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
+    const float k4[4] = {fx, fy, cx, cy};
+    hipLaunchKernelGGL(normal_losses_fwd_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, (hipStream_t)stream, H, W,
+                       make_intr(k4), depth, normal_planes, gt, mask, depth_max, exp_t, active, sums9);
+    hipLaunchKernelGGL(finalize_normal_losses_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums9, res3);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_normal_losses_backward(int H, int W, float fx, float fy, float cx, float cy, const float* depth,
+                                          const float* normal_planes, const float* gt, const uint8_t* mask, float depth_max,
+                                          float exp_t, int active, const double* sums9, const float* seeds3, float* scratch6,
+                                          float* d_depth, float* d_normal_planes, void* stream) {
+    if ((active & 3) && !gt) { vcr_set_error("vcr_normal_losses_backward: gt is NULL"); return 1; }
+    const float k4[4] = {fx, fy, cx, cy};
+    const dim3 grid((W + 63) / 64, (H + 3) / 4);
+    hipLaunchKernelGGL(normal_losses_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, make_intr(k4), depth,
+                       normal_planes, gt, mask, depth_max, exp_t, active, sums9, seeds3, d_normal_planes, scratch6);
+    hipLaunchKernelGGL(depth_normal_bwd2_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, make_intr(k4), scratch6, d_depth);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 extern "C" int vcr_l1_ssim_forward(int H, int W, const float* img1, const float* img2, double* sums2, float* means2,

@@ -31,36 +31,29 @@ class _FusedLosses(torch.autograd.Function):
         dev = o.device
         st = _lib.stream_of(o)
         base = o.data_ptr()
-        normal = torch.empty(P * 3, device=dev)
-        est = torch.empty(P * 3, device=dev)
-        lib.vcr_normalize_chw_forward(P, base + 4 * P * 4, normal.data_ptr(), st)
-        lib.vcr_depth_to_normal_forward(H, W, *intr, base + 3 * P * 4, est.data_ptr(), st)
-        n2, n3 = lib.vcr_sums_elems(2), lib.vcr_sums_elems(3)
-        # ONE memset for all five reductions and the six results (+ the weighted total), which live in the buffer's tail
-        sums = torch.zeros(n2 + 4 * n3 + 4, dtype=torch.float64, device=dev)
-        res8 = sums[n2 + 4 * n3:].view(torch.float32)
+        n2, n3, n9 = lib.vcr_sums_elems(2), lib.vcr_sums_elems(3), lib.vcr_sums_elems(9)
+        # ONE memset for all reductions and the six results (+ the weighted total), which live in the buffer's tail
+        sums = torch.zeros(n2 + n3 + n9 + 4, dtype=torch.float64, device=dev)
+        res8 = sums[n2 + n3 + n9:].view(torch.float32)
         res, total = res8[:6], res8[6]
-        sp = lambda k: sums.data_ptr() + 8 * (n2 + (k - 1) * n3) if k else sums.data_ptr()
+        s_ssim, s_scale, s_nrm = sums.data_ptr(), sums.data_ptr() + 8 * n2, sums.data_ptr() + 8 * (n2 + n3)
         rp = lambda k: res.data_ptr() + 4 * k
         gi = gt_image.detach().contiguous()
         part = torch.empty(9, H, W, device=dev)
-        _lib.check(lib.vcr_l1_ssim_forward(H, W, base, gi.data_ptr(), sp(0), rp(0), part.data_ptr(), 1, st))
+        _lib.check(lib.vcr_l1_ssim_forward(H, W, base, gi.data_ptr(), s_ssim, rp(0), part.data_ptr(), 1, st))
         sr, xz = scaling_raw.detach().contiguous(), xyz.detach().contiguous()
         if active[2]:
             _lib.check(lib.vcr_scale_reg_forward(sr.shape[0], sr.data_ptr(), xz.data_ptr(), trans.data_ptr(), scale.data_ptr(),
-                                                 sp(1), rp(2), 1, st))
+                                                 s_scale, rp(2), 1, st))
         gn = None if gt_normal is None else gt_normal.detach().contiguous()
         m = None if mask is None else mask.detach().contiguous().view(-1).to(torch.uint8)
-        dptr = base + 3 * P * 4 if depth_max > 0 else None
-        if active[3]:
-            _lib.check(lib.vcr_normal_loss_forward(P, normal.data_ptr(), gn.data_ptr(), None, 0.0, None, None, 0.0, sp(2), rp(3), 1, st))
-        if active[4]:
-            _lib.check(lib.vcr_normal_loss_forward(P, est.data_ptr(), gn.data_ptr(), normal.data_ptr(), float(exp_t),
-                                                   None if m is None else m.data_ptr(), dptr, float(depth_max), sp(3), rp(4), 1, st))
-        if active[5]:
-            _lib.check(lib.vcr_normal_loss_forward(P, est.data_ptr(), normal.data_ptr(), None, 0.0, None, None, 0.0, sp(4), rp(5), 1, st))
-        ctx.save_for_backward(o, normal, est, gi, part, sums, sr, xz, gn, m, wvec, trans, scale)
-        ctx.meta = (H, W, C, tuple(intr), tuple(active), float(exp_t), float(depth_max), n2, n3)
+        nbits = (1 if active[3] else 0) | (2 if active[4] else 0) | (4 if active[5] else 0)
+        if nbits:      # mono_normal, depth_normal, consistent_normal: one kernel (+ one finalize) for all three
+            _lib.check(lib.vcr_normal_losses_forward(H, W, *intr, base + 3 * P * 4, base + 4 * P * 4,
+                                                     None if gn is None else gn.data_ptr(), None if m is None else m.data_ptr(),
+                                                     float(depth_max), float(exp_t), nbits, s_nrm, rp(3), 1, st))
+        ctx.save_for_backward(o, gi, part, sums, sr, xz, gn, m, wvec, trans, scale)
+        ctx.meta = (H, W, C, tuple(intr), tuple(active), float(exp_t), float(depth_max), n2, n3, nbits)
         # total = sum_k w_k L_k with the ssim entry meaning (1 - ssim): wvec[1] = -w_ssim, constant +w_ssim added in-kernel
         _lib.check(lib.vcr_weighted_total(6, res.data_ptr(), wvec.data_ptr(), 1, total.data_ptr(), st))
         ctx.mark_non_differentiable(res)
@@ -69,55 +62,34 @@ class _FusedLosses(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_res):
         lib = _lib.load()
-        o, normal, est, gi, part, sums, sr, xz, gn, m, wvec, trans, scale = ctx.saved_tensors
-        H, W, C, intr, active, exp_t, depth_max, n2, n3 = ctx.meta
+        o, gi, part, sums, sr, xz, gn, m, wvec, trans, scale = ctx.saved_tensors
+        H, W, C, intr, active, exp_t, depth_max, n2, n3, nbits = ctx.meta
         P = H * W
         dev = o.device
         st = _lib.stream_of(o)
         one = _ONES.get(str(dev))
         seeds = wvec if (one is not None and g_total.data_ptr() == one.data_ptr()) else (g_total * wvec).contiguous()
         gp = lambda k: seeds.data_ptr() + 4 * k
-        sp = lambda k: sums.data_ptr() + 8 * (n2 + (k - 1) * n3) if k else sums.data_ptr()
+        s_scale, s_nrm = sums.data_ptr() + 8 * n2, sums.data_ptr() + 8 * (n2 + n3)
         dout = torch.empty_like(o)
         dbase = dout.data_ptr()
         if C > 7:
             dout[7:].zero_()
         _lib.check(lib.vcr_l1_ssim_backward(H, W, o.data_ptr(), gi.data_ptr(), part.data_ptr(), gp(0), gp(1), dbase, st))
-        d_nrm = torch.empty(P * 3, device=dev)
-        d_est = torch.empty(P * 3, device=dev)
-        nrm_w = est_w = False
         base = o.data_ptr()
-        dptr = base + 3 * P * 4 if depth_max > 0 else None
-        if active[3]:
-            _lib.check(lib.vcr_normal_loss_backward(P, normal.data_ptr(), gn.data_ptr(), None, 0.0, None, None, 0.0, sp(2), gp(3),
-                                                    d_nrm.data_ptr(), None, 0, st))
-            nrm_w = True
-        if active[4]:
-            _lib.check(lib.vcr_normal_loss_backward(P, est.data_ptr(), gn.data_ptr(), normal.data_ptr(), exp_t,
-                                                    None if m is None else m.data_ptr(), dptr, depth_max, sp(3), gp(4),
-                                                    d_est.data_ptr(), None, 0, st))
-            est_w = True
-        if active[5]:
-            if not nrm_w:
-                d_nrm.zero_()
-            _lib.check(lib.vcr_normal_loss_backward(P, est.data_ptr(), normal.data_ptr(), None, 0.0, None, None, 0.0, sp(4), gp(5),
-                                                    d_est.data_ptr(), d_nrm.data_ptr(), (1 if est_w else 0) | 2, st))
-            nrm_w = est_w = True
-        if est_w:
+        if nbits:
             scratch = torch.empty(P * 6, device=dev)
-            _lib.check(lib.vcr_depth_to_normal_backward(H, W, *intr, base + 3 * P * 4, d_est.data_ptr(), scratch.data_ptr(),
-                                                        dbase + 3 * P * 4, st))
+            _lib.check(lib.vcr_normal_losses_backward(H, W, *intr, base + 3 * P * 4, base + 4 * P * 4,
+                                                      None if gn is None else gn.data_ptr(), None if m is None else m.data_ptr(),
+                                                      float(depth_max), float(exp_t), nbits, s_nrm, gp(3), scratch.data_ptr(),
+                                                      dbase + 3 * P * 4, dbase + 4 * P * 4, st))
         else:
-            dout[3].zero_()
-        if nrm_w:
-            _lib.check(lib.vcr_normalize_chw_backward(P, base + 4 * P * 4, d_nrm.data_ptr(), dbase + 4 * P * 4, st))
-        else:
-            dout[4:7].zero_()
+            dout[3:7].zero_()
         d_sc = None
         if active[2]:
             d_sc = torch.empty_like(sr)
             _lib.check(lib.vcr_scale_reg_backward(sr.shape[0], sr.data_ptr(), xz.data_ptr(), trans.data_ptr(), scale.data_ptr(),
-                                                  sp(1), gp(2), d_sc.data_ptr(), st))
+                                                  s_scale, gp(2), d_sc.data_ptr(), st))
         return (dout, d_sc) + (None,) * 11
 
 
