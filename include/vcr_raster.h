@@ -176,6 +176,12 @@ int vcr_depth_to_normal_backward(int H, int W, float fx, float fy, float cx, flo
 /* rendered normal [3,H,W] -> F.normalize -> [H,W,3] (gaussian_renderer/__init__.py:133-134) */
 int vcr_normalize_chw_forward(int P, const float* in_chw, float* out_hwc, void* stream);
 int vcr_normalize_chw_backward(int P, const float* in_chw, const float* dout_hwc, float* din_chw, void* stream);
+/* The *_forward functions of the loss kernels take `sums_prezeroed`: bit 0 = the sums buffer is already zero, bit 1 = do
+ * not launch the per-loss finalize.  vcr_finalize_losses then finishes the L1+SSIM sums (sums2), the scale regulariser
+ * (sums3 or NULL) and the three normal losses (sums9 or NULL) in ONE launch: res6 = {l1, ssim index, l1_scale,
+ * mono_normal, depth_normal, consistent_normal}, total = sum res6[k] w[k] - (sub_index >= 0 ? w[sub_index] : 0). */
+int vcr_finalize_losses(int H, int W, double* sums2, double* sums3, double* sums9, float* res6, const float* w, int sub_index,
+                        float* total, void* stream);
 /* total = sum_k res[k] * w[k] - (sub_index >= 0 ? w[sub_index] : 0): the weighted sum of the loss dictionary
  * (trainer.py:310-321) in one launch; sub_index marks the entry that enters as (1 - value), i.e. SSIM. */
 int vcr_weighted_total(int K, const float* res, const float* w, int sub_index, float* total, void* stream);

@@ -75,7 +75,7 @@ int main() {
     hipMemcpy(ord.data(), dord, T * 4, hipMemcpyDeviceToHost);
     std::vector<int> seen(T, 0); int badp = 0, inv = 0;
     for (int i = 0; i < T; ++i) { if (ord[i] >= (uint32_t)T || seen[ord[i]]++) ++badp; }
-    for (int i = 1; i < T && !badp; ++i) inv += ((rg[ord[i]].y >> 1) > (rg[ord[i - 1]].y >> 1));
+    for (int i = 1; i < T && !badp; ++i) inv += ((rg[ord[i]].y >> 2) > (rg[ord[i - 1]].y >> 2));
     vcr_launch_tile_order(T, drg, dord, true, true, 0);
     hipMemcpy(ord.data(), dord, T * 4, hipMemcpyDeviceToHost);
     std::fill(seen.begin(), seen.end(), 0); int badp2 = 0;

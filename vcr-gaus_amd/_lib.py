@@ -64,6 +64,7 @@ SYMBOLS = {
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vcr_normal_losses_backward": (C.c_int, [C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int]
                                    + [C.c_void_p] * 6),
+    "vcr_finalize_losses": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p]),
     "vcr_weighted_total": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "vcr_sh_grad_from_rgb": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "vcr_sh_adam_from_rgb": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_float] * 5 + [C.c_int, C.c_float, C.c_void_p]),

@@ -31,12 +31,14 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
                                                         const int32_t* __restrict__ radii,
                                                         const uint32_t* __restrict__ tiles,
                                                         uint32_t* __restrict__ keys_out,
-                                                        uint32_t* __restrict__ vals_out) {
+                                                        uint32_t* __restrict__ vals_out, uint2* __restrict__ ranges,
+                                                        int num_tiles) {
     __shared__ uint32_t s_end[4][64], s_start[4][64], s_id[4][64];
     __shared__ int s_xmin[4][64], s_ymin[4][64], s_w[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int gi = blockIdx.x * 256 + threadIdx.x;
     const int gx = (W + VCR_TILE - 1) / VCR_TILE, gy = (H + VCR_TILE - 1) / VCR_TILE;
+    for (int t = gi; t < num_tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);   // empty tiles (tile_ranges fills the rest)
     uint32_t id = 0, cnt = 0, end;
     int xmin = 0, ymin = 0, w = 1;
     if (gi < N) {
@@ -138,11 +140,13 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
                            hipStream_t st) {
     static const bool no_lpt = getenv("VCR_NO_LPT") != nullptr;          // experiment switches
     static const bool no_snake = getenv("VCR_NO_SNAKE") != nullptr;
-    VCR_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, st));
-    if (R <= 0) return vcr_launch_tile_order(num_tiles, ranges, tile_order, false, false, st);   // identity order
+    if (R <= 0) {
+        VCR_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, st));
+        return vcr_launch_tile_order(num_tiles, ranges, tile_order, false, false, st);   // identity order
+    }
     const int blocks = (a.N + 255) / 256;
     hipLaunchKernelGGL(duplicate_kernel, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, offsets, g.rec, radii,
-                       g.tiles, keys_a, vals_a);
+                       g.tiles, keys_a, vals_a, ranges, num_tiles);
     VCR_HIP_CHECK(hipGetLastError());
     if (R > VCR_SORT_HAND_MAX) {
         size_t tb = temp_bytes;

@@ -42,7 +42,6 @@ struct StageTimer {
     }
 };
 
-#define VCR_VIS_SLOTS 64
 // device counters of one forward call, zeroed by ONE memset: visible-count slots, tile-instance-count slots and the
 // digit totals of the two radix sorts
 #define VCR_CTR_WORDS (2 * VCR_VIS_SLOTS + 2 * VCR_SORT_TOTALS_WORDS)
@@ -65,23 +64,6 @@ hipEvent_t readback_event() {
     static thread_local hipEvent_t e = nullptr;
     if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
     return e;
-}
-
-// visible Gaussians and tile instances (R = sum of tiles touched), spread over slots to keep the atomics apart
-__global__ void __launch_bounds__(256) count_visible_kernel(int N, const uint32_t* __restrict__ tiles,
-                                                            uint32_t* __restrict__ slots) {
-    uint32_t c = 0, r = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
-        const uint32_t t = tiles[i];
-        c += t != 0 ? 1u : 0u;
-        r += t;
-    }
-    for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); r += __shfl_xor(r, o); }
-    if ((threadIdx.x & 63) == 0 && c) {
-        const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) % VCR_VIS_SLOTS;
-        atomicAdd(slots + slot, c);
-        atomicAdd(slots + VCR_VIS_SLOTS + slot, r);
-    }
 }
 
 __global__ void fill_background_kernel(int P, int C, const float* __restrict__ bg, float* __restrict__ out) {
@@ -206,7 +188,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         const bool split_colour = a.colour_stream && a.colour_stream != stream && a.shs && !a.colors_precomp;
         {
             StageTimer tm(ST_PREPROCESS, st);
-            if (vcr_launch_preprocess(a, g, out->radii, depth_key, ids, !split_colour, st)) return 1;
+            if (vcr_launch_preprocess(a, g, out->radii, depth_key, ids, vis_counter, !split_colour, st)) return 1;
         }
         if (split_colour) {
             hipEvent_t e_geo = colour_event(0), e_col = colour_event(1);
@@ -218,7 +200,6 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             if (vcr_launch_colour(a, g, cs)) return 1;
             VCR_HIP_CHECK(hipEventRecord(e_col, cs));
         }
-        hipLaunchKernelGGL(count_visible_kernel, dim3(min((N + 255) / 256, 512)), dim3(256), 0, st, N, g.tiles, vis_counter);
         // R and V go back to the host now; the depth sort and the offsets scan do not need them and keep the GPU busy
         // while the host wakes up, sizes the instance buffers and enqueues the rest
         Readback* rb = pinned_readback();

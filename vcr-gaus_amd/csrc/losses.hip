@@ -582,7 +582,7 @@ extern "C" int vcr_normalize_chw_backward(int P, const float* in_chw, const floa
 extern "C" int vcr_normal_loss_forward(int P, const float* pred, const float* gt, const float* wsrc, float exp_t,
                                        const uint8_t* mask, const float* depth, float depth_max, double* sums3,
                                        float* loss, int sums_prezeroed, void* stream) {
-    if (!sums_prezeroed) VCR_HIP_CHECK(hipMemsetAsync(sums3, 0, 3 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
+    if (!(sums_prezeroed & 1)) VCR_HIP_CHECK(hipMemsetAsync(sums3, 0, 3 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
     const int blocks = min((P + 255) / 256, 2048);
     hipLaunchKernelGGL(normal_loss_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, pred, gt, wsrc, exp_t, mask,
                        depth, depth_max, sums3);
@@ -612,11 +612,12 @@ extern "C" int vcr_normal_losses_forward(int H, int W, float fx, float fy, float
                                          const float* normal_planes, const float* gt, const uint8_t* mask, float depth_max,
                                          float exp_t, int active, double* sums9, float* res3, int sums_prezeroed, void* stream) {
     if ((active & 3) && !gt) { vcr_set_error("vcr_normal_losses_forward: gt is NULL"); return 1; }
-    if (!sums_prezeroed) VCR_HIP_CHECK(hipMemsetAsync(sums9, 0, 9 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
+    if (!(sums_prezeroed & 1)) VCR_HIP_CHECK(hipMemsetAsync(sums9, 0, 9 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
     const float k4[4] = {fx, fy, cx, cy};
     hipLaunchKernelGGL(normal_losses_fwd_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, (hipStream_t)stream, H, W,
                        make_intr(k4), depth, normal_planes, gt, mask, depth_max, exp_t, active, sums9);
-    hipLaunchKernelGGL(finalize_normal_losses_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums9, res3);
+    if (!(sums_prezeroed & 2))
+        hipLaunchKernelGGL(finalize_normal_losses_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums9, res3);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -637,12 +638,13 @@ extern "C" int vcr_normal_losses_backward(int H, int W, float fx, float fy, floa
 
 extern "C" int vcr_l1_ssim_forward(int H, int W, const float* img1, const float* img2, double* sums2, float* means2,
                                    float* partials9, int sums_prezeroed, void* stream) {
-    if (!sums_prezeroed) VCR_HIP_CHECK(hipMemsetAsync(sums2, 0, 2 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
+    if (!(sums_prezeroed & 1)) VCR_HIP_CHECK(hipMemsetAsync(sums2, 0, 2 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
     const dim3 grid((W + SSIM_TX - 1) / SSIM_TX, (H + SSIM_TY - 1) / SSIM_TY, 3);
     hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, make_window(), img1, img2, sums2,
                        partials9);
-    hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, 2, sums2, 0,
-                       1.0 / (3.0 * (double)H * (double)W), means2);
+    if (!(sums_prezeroed & 2))
+        hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, 2, sums2, 0,
+                           1.0 / (3.0 * (double)H * (double)W), means2);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -696,11 +698,11 @@ __global__ void __launch_bounds__(256) scale_reg_bwd_kernel(int N, const float* 
 
 extern "C" int vcr_scale_reg_forward(int N, const float* scaling_raw, const float* xyz, const float* trans, const float* scale,
                                      double* sums3, float* loss, int sums_prezeroed, void* stream) {
-    if (!sums_prezeroed) VCR_HIP_CHECK(hipMemsetAsync(sums3, 0, 3 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
+    if (!(sums_prezeroed & 1)) VCR_HIP_CHECK(hipMemsetAsync(sums3, 0, 3 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
     if (N > 0)
         hipLaunchKernelGGL(scale_reg_fwd_kernel, dim3(min((N + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, N,
                            scaling_raw, xyz, trans, scale, sums3);
-    hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, 3, sums3, 1, 1.0, loss);
+    if (!(sums_prezeroed & 2)) hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, 3, sums3, 1, 1.0, loss);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -719,6 +721,50 @@ __global__ void weighted_total_kernel(int K, const float* __restrict__ res, cons
     float t = sub_index >= 0 ? -w[sub_index] : 0.f;
     for (int k = 0; k < K; ++k) t += res[k] * w[k];
     *total = t;
+}
+
+// One launch for what the loss node needs at the end of its forward: fold the slots of the L1+SSIM sums (2), the
+// scale-regulariser sums (3, optional) and the normal-loss sums (9, optional) in the fixed order of the individual
+// finalize kernels, write the six loss values and their weighted total.
+__global__ void finalize_losses_kernel(double* __restrict__ sums2, double inv_count, double* __restrict__ sums3,
+                                       double* __restrict__ sums9, float* __restrict__ res6, const float* __restrict__ w,
+                                       int sub_index, float* __restrict__ total) {
+    __shared__ double s_t[14];
+    double* bases[3] = {sums2, sums3, sums9};
+    const int Ks[3] = {2, 3, 9};
+    int off = 0;
+    for (int b = 0; b < 3; ++b) {
+        const int K = Ks[b];
+        for (int k = 0; k < K; ++k) {
+            double t = 0.0;
+            if (bases[b]) {
+                for (int s = threadIdx.x; s < VCR_NSLOT; s += 64) t += bases[b][K + (size_t)s * K + k];
+                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+                if (threadIdx.x == 0) bases[b][k] = t;
+            }
+            if (threadIdx.x == 0) s_t[off + k] = t;
+        }
+        off += K;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r[6];
+        r[0] = (float)(s_t[0] * inv_count); r[1] = (float)(s_t[1] * inv_count);
+        r[2] = s_t[4] > 0.0 ? (float)((s_t[2] + s_t[3]) / s_t[4]) : 0.f;
+        for (int l = 0; l < 3; ++l) r[3 + l] = s_t[5 + 3 * l + 2] > 0.0 ? (float)((s_t[5 + 3 * l] + s_t[5 + 3 * l + 1]) / s_t[5 + 3 * l + 2]) : 0.f;
+        float t = sub_index >= 0 ? -w[sub_index] : 0.f;
+        for (int k = 0; k < 6; ++k) { res6[k] = r[k]; t += r[k] * w[k]; }
+        *total = t;
+    }
+}
+
+extern "C" int vcr_finalize_losses(int H, int W, double* sums2, double* sums3, double* sums9, float* res6, const float* w,
+                                   int sub_index, float* total, void* stream) {
+    if (!sums2 || !res6 || !w || !total) { vcr_set_error("vcr_finalize_losses: bad arguments"); return 1; }
+    hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums2, 1.0 / (3.0 * (double)H * (double)W),
+                       sums3, sums9, res6, w, sub_index, total);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 extern "C" int vcr_weighted_total(int K, const float* res, const float* w, int sub_index, float* total, void* stream) {

@@ -196,18 +196,12 @@ __device__ __forceinline__ void stage_sh_in(const VcrRasterArgs& a, int base, in
 }
 
 // COLOUR = false: geometry only (the SH -> RGB evaluation runs as colour_fwd_kernel on VcrRasterArgs.colour_stream)
+// Returns the number of tiles the Gaussian touches (0 = culled).
 template <bool STAGE, bool COLOUR>
-__global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, GeomState g, int32_t* __restrict__ radii,
-                                                             uint32_t* __restrict__ depth_key,
-                                                             uint32_t* __restrict__ ids) {
-    extern __shared__ __attribute__((aligned(16))) float s_sh[];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (STAGE) {
-        const int base = blockIdx.x * 256;
-        stage_sh_in(a, base, min(256, a.N - base), s_sh);
-        __syncthreads();
-    }
-    if (i >= a.N) return;
+__device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const GeomState& g, int32_t* __restrict__ radii,
+                                                   uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
+                                                   const float* s_sh, int i) {
+    if (i >= a.N) return 0;
     ids[i] = i;
     radii[i] = 0;
     g.tiles[i] = 0;
@@ -217,7 +211,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
     const float p[3] = {a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2]};
     Proj pr;
     project(a, cam, p, pr);
-    if (pr.t[2] <= VCR_NEAR) return;
+    if (pr.t[2] <= VCR_NEAR) return 0;
 
     const float* P = cam.P;
     const float hx = p[0] * P[0] + p[1] * P[4] + p[2] * P[8] + P[12];
@@ -235,7 +229,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
     const float cb = pr.M0[0] * SM1[0] + pr.M0[1] * SM1[1] + pr.M0[2] * SM1[2];
     const float cc = pr.M1[0] * SM1[0] + pr.M1[1] * SM1[1] + pr.M1[2] * SM1[2] + VCR_LOWPASS;
     const float det = ca * cc - cb * cb;
-    if (det == 0.f) return;
+    if (det == 0.f) return 0;
     const float idet = 1.f / det;
     const float mid = 0.5f * (ca + cc);
     const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
@@ -249,7 +243,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
     const int ymin = min(gy, max(0, (int)floorf((py - rad) / VCR_TILE)));
     const int ymax = min(gy, max(0, (int)floorf((py + rad + VCR_TILE - 1) / VCR_TILE)));
     const int ntiles = (xmax - xmin) * (ymax - ymin);
-    if (ntiles <= 0) return;
+    if (ntiles <= 0) return 0;
 
     GeomRec rec;
     uint8_t clampbits = 0;
@@ -296,6 +290,33 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
     g.tiles[i] = (uint32_t)ntiles;
     radii[i] = (int32_t)rad;
     depth_key[i] = __float_as_uint(pr.t[2]);
+    return (uint32_t)ntiles;
+}
+
+// vis_slots (optional): 2 x VCR_VIS_SLOTS counters, [visible Gaussians | tile instances], one pair of atomics per block
+// spread over many addresses (same-address L2 atomics serialise at ~200 ns each)
+template <bool STAGE, bool COLOUR>
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, GeomState g, int32_t* __restrict__ radii,
+                                                             uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
+                                                             uint32_t* __restrict__ vis_slots) {
+    extern __shared__ __attribute__((aligned(16))) float s_sh[];
+    if (STAGE) {
+        const int base = blockIdx.x * 256;
+        stage_sh_in(a, base, min(256, a.N - base), s_sh);
+        __syncthreads();
+    }
+    const uint32_t nt = preprocess_one<STAGE, COLOUR>(a, g, radii, depth_key, ids, s_sh, blockIdx.x * 256 + threadIdx.x);
+    if (vis_slots) {
+        __shared__ uint32_t s_cnt[2][4];
+        uint32_t c = nt != 0 ? 1u : 0u, r = nt;
+        for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); r += __shfl_xor(r, o); }
+        if ((threadIdx.x & 63) == 0) { s_cnt[0][threadIdx.x >> 6] = c; s_cnt[1][threadIdx.x >> 6] = r; }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const uint32_t t = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+            if (t) atomicAdd(vis_slots + threadIdx.x * VCR_VIS_SLOTS + blockIdx.x % VCR_VIS_SLOTS, t);
+        }
+    }
 }
 
 // SH -> RGB of the visible Gaussians (tiles > 0) into the colour slot of their GeomRec + the clamp bits; the second half
@@ -674,16 +695,18 @@ extern "C" int vcr_sh_grad_from_rgb(int N, int sh_degree, int nviews, const floa
 }
 
 int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key, uint32_t* ids,
-                          bool colour, hipStream_t st) {
+                          uint32_t* vis_slots, bool colour, hipStream_t st) {
     if (a.N == 0) return 0;
     const int blocks = (a.N + 255) / 256;
     if (!colour)
-        hipLaunchKernelGGL((preprocess_fwd_kernel<false, false>), dim3(blocks), dim3(256), 0, st, a, g, radii, depth_key, ids);
+        hipLaunchKernelGGL((preprocess_fwd_kernel<false, false>), dim3(blocks), dim3(256), 0, st, a, g, radii, depth_key, ids,
+                           vis_slots);
     else if (a.shs && a.K == SH_K)
         hipLaunchKernelGGL((preprocess_fwd_kernel<true, true>), dim3(blocks), dim3(256), 256 * SH_ROW * sizeof(float), st, a, g,
-                           radii, depth_key, ids);
+                           radii, depth_key, ids, vis_slots);
     else
-        hipLaunchKernelGGL((preprocess_fwd_kernel<false, true>), dim3(blocks), dim3(256), 0, st, a, g, radii, depth_key, ids);
+        hipLaunchKernelGGL((preprocess_fwd_kernel<false, true>), dim3(blocks), dim3(256), 0, st, a, g, radii, depth_key, ids,
+                           vis_slots);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -156,42 +156,36 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_downsweep_kernel(int64_t n, const
 
 // Block-scheduling order of the compositing kernels: tiles by list length, longest first, folded boustrophedon-wise
 // with the period of the chip.  The order is a placement policy, so lengths are quantised
-// (<= 2048 classes) and ties land in arbitrary order: ONE single-workgroup counting sort instead of a device-wide sort.
+// (2048 classes of 4 entries) and ties land in arbitrary order: ONE single-workgroup counting sort instead of a device-wide sort.
 __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order,
                                                         int lpt, int snake) {
-    constexpr int BINS = 2048;
+    constexpr int BINS = 2048, SH = 2;                 // classes of 4 list entries; lists >= 8188 share the first class
     __shared__ uint32_t hist[BINS];
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t s_max;
-    const int t = threadIdx.x;
+    __shared__ uint32_t wsum[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (!lpt) { for (int i = t; i < T; i += 1024) order[i] = (uint32_t)i; return; }
     hist[t] = 0; hist[t + 1024] = 0;
-    if (t == 0) s_max = 0;
     __syncthreads();
-    uint32_t m = 0;
-    for (int i = t; i < T; i += 1024) m = max(m, ranges[i].y - ranges[i].x);
-    atomicMax(&s_max, m);
+    for (int i = t; i < T; i += 1024)
+        atomicAdd(&hist[BINS - 1 - min((ranges[i].y - ranges[i].x) >> SH, (uint32_t)(BINS - 1))], 1u);   // bin 0 = longest
     __syncthreads();
-    int sh = 0;
-    while ((s_max >> sh) >= (uint32_t)BINS) ++sh;
-    for (int i = t; i < T; i += 1024) atomicAdd(&hist[BINS - 1 - ((ranges[i].y - ranges[i].x) >> sh)], 1u);   // bin 0 = longest
-    __syncthreads();
+    // exclusive scan of the 2048 classes: 2 per lane, wave scan, 16 wave totals
     const uint32_t h0 = hist[2 * t], h1 = hist[2 * t + 1];
-    part[t] = h0 + h1;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const uint32_t v = t >= o ? part[t - o] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    uint32_t inc = h0 + h1;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, o);
+        if (lane >= o) inc += v;
     }
-    const uint32_t ex = part[t] - (h0 + h1);
+    if (lane == 63) wsum[w] = inc;
     __syncthreads();
+    uint32_t base = 0;
+    for (int k = 0; k < w; ++k) base += wsum[k];
+    const uint32_t ex = base + inc - (h0 + h1);
     hist[2 * t] = ex; hist[2 * t + 1] = ex + h0;           // exclusive start of every class
     __syncthreads();
     for (int i = t; i < T; i += 1024) {
-        const uint32_t r = atomicAdd(&hist[BINS - 1 - ((ranges[i].y - ranges[i].x) >> sh)], 1u);    // rank in launch order
-        uint32_t pos = r;
+        const uint32_t r = atomicAdd(&hist[BINS - 1 - min((ranges[i].y - ranges[i].x) >> SH, (uint32_t)(BINS - 1))], 1u);
+        uint32_t pos = r;                                   // rank in launch order
         if (snake) {
             const int band = (int)(r >> 8), j = (int)(r & 255);
             const int band_len = min(256, T - (band << 8));

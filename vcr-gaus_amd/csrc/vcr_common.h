@@ -134,8 +134,9 @@ void vcr_set_error(const char* fmt, ...);
     } while (0)
 
 // ---- stage launchers (defined in the .hip files) ----------------------------------------------
+#define VCR_VIS_SLOTS 1024                    // counter slots for visible Gaussians / tile instances
 int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key,
-                          uint32_t* ids, bool colour, hipStream_t st);
+                          uint32_t* ids, uint32_t* vis_slots, bool colour, hipStream_t st);
 int vcr_launch_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st);
 int vcr_side_grid();     // workgroups of a side-stream kernel (VCR_SIDE_GRID, default 512 = two per CU)
 int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const int32_t* radii,
