@@ -363,14 +363,21 @@ class BenchTrainer:
         self.last_R = self.last_V = 0
         self._primed = False
 
-    def prime(self):
+    def prime(self, min_seconds=1.0):
         """Untimed set-up: one ordinary training step per camera, so that every instance-count-dependent buffer size has
         been seen by the caching allocator (a first-seen size inside the timed window is a hipMalloc stall of several
         ms, i.e. allocator noise rather than step time)."""
         if not self._primed:
             self._primed = True
-            for i in range(len(self.tr.cameras)):
+            import time
+            t0, i = time.perf_counter(), 0
+            # every camera once, and at least `min_seconds` of ordinary steps: on a fresh box the first second of a
+            # process is slowed by code / library page-in on the host, which starves the GPU and is not step time
+            # (multi-GPU: a FIXED count, identical on every rank -- a time-based count would desynchronise the collectives)
+            fixed = len(self.tr.cameras) if self.tr.world == 1 else max(len(self.tr.cameras), 64)
+            while i < fixed or (self.tr.world == 1 and time.perf_counter() - t0 < min_seconds):
                 self.step(-1 - i)
+                i += 1
             torch.cuda.synchronize()
 
     def step(self, i):
