@@ -210,7 +210,8 @@ int vcr_scale_reg_backward(int N, const float* scaling_raw, const float* xyz, co
  * camera mask and the depth threshold (depth_max <= 0: none), consistent_normal (bit 2) = monosdf_normal_loss(est, n),
  * where n = F.normalize(normal_planes [3,H,W]) and est = compute_normals(depth [H,W]).  sums9: vcr_sums_elems(9) doubles;
  * res3 / seeds3: the three loss values / their upstream gradients.  The backward writes d(depth) [H,W] and
- * d(normal_planes) [3,H,W]; scratch6 is [H*W*6] floats. */
+ * d(normal_planes) [3,H,W] followed by a zeroed fourth plane (the alpha plane of the rasterizer output: d_normal_planes
+ * must have room for [4,H,W]); scratch6 is [H*W*6] floats. */
 int vcr_normal_losses_forward(int H, int W, float fx, float fy, float cx, float cy, const float* depth,
                               const float* normal_planes, const float* gt /* [H*W,3] or NULL */,
                               const uint8_t* mask /* [H*W] or NULL */, float depth_max, float exp_t, int active,

@@ -473,7 +473,8 @@ def test_fused_normal_losses_match_the_modular_operators(device, active):
                                              exp_t, active, sums.data_ptr(), res.data_ptr(), 1, st))
     for k in range(3):
         assert abs(float(res[k]) - float(vals[k])) < 2e-5 * max(1.0, abs(float(vals[k]))), (k, float(res[k]), float(vals[k]))
-    dd, dn = torch.empty(H, W, device=device), torch.empty(3, H, W, device=device)
+    dd, dn4 = torch.empty(H, W, device=device), torch.full((4, H, W), 7.0, device=device)
+    dn = dn4[:3]
     scratch = torch.empty(P * 6, device=device)
     _lib.check(lib.vcr_normal_losses_backward(H, W, *intr, depth.data_ptr(), nrm.data_ptr(), gt.data_ptr(), m8.data_ptr(), depth_max,
                                               exp_t, active, sums.data_ptr(), seeds.data_ptr(), scratch.data_ptr(), dd.data_ptr(),
@@ -482,3 +483,4 @@ def test_fused_normal_losses_match_the_modular_operators(device, active):
     ref_dn = n_ref.grad if n_ref.grad is not None else torch.zeros_like(dn)
     assert float((dd - ref_dd).abs().max()) <= 1e-4 * float(ref_dd.abs().max()) + 1e-9
     assert float((dn - ref_dn).abs().max()) <= 1e-4 * float(ref_dn.abs().max()) + 1e-9
+    assert float(dn4[3].abs().max()) == 0.0          # the alpha plane behind the normal planes is zeroed

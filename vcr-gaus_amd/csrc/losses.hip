@@ -360,6 +360,7 @@ __global__ void __launch_bounds__(256) normal_losses_bwd_kernel(int H, int W, In
         d0 = (dn[0] - q.n[0] * dot) * inv; d1 = (dn[1] - q.n[1] * dot) * inv; d2 = (dn[2] - q.n[2] * dot) * inv;
     } else { d0 = dn[0] * 1e12f; d1 = dn[1] * 1e12f; d2 = dn[2] * 1e12f; }
     dnrm[i] = d0; dnrm[P + i] = d1; dnrm[2 * P + i] = d2;
+    dnrm[3 * P + i] = 0.f;                    // the alpha plane behind the normal planes carries no loss
     // through est = c / |c|, c = dx x dy   (stage 1 of the depth-to-normal adjoint)
     float dc[3];
     if (q.elen > 1e-12f) {

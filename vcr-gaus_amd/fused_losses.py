@@ -35,7 +35,7 @@ class _FusedLosses(torch.autograd.Function):
         # ONE memset for all reductions and the six results (+ the weighted total), which live in the buffer's tail
         sums = torch.zeros(n2 + n3 + n9 + 4, dtype=torch.float64, device=dev)
         res8 = sums[n2 + n3 + n9:].view(torch.float32)
-        res, total = res8[:6], res8[6]
+        res, total = res8[:6], torch.empty((), device=dev)       # (not a view: a view output costs a select_backward)
         s_ssim, s_scale, s_nrm = sums.data_ptr(), sums.data_ptr() + 8 * n2, sums.data_ptr() + 8 * (n2 + n3)
         rp = lambda k: res.data_ptr() + 4 * k
         gi = gt_image.detach().contiguous()
@@ -75,8 +75,8 @@ class _FusedLosses(torch.autograd.Function):
         s_scale, s_nrm = sums.data_ptr() + 8 * n2, sums.data_ptr() + 8 * (n2 + n3)
         dout = torch.empty_like(o)
         dbase = dout.data_ptr()
-        if C > 7:
-            dout[7:].zero_()
+        if C > 8 or (C > 7 and not nbits):
+            dout[7:].zero_()                                       # (the alpha plane is zeroed by the normal-loss backward)
         _lib.check(lib.vcr_l1_ssim_backward(H, W, o.data_ptr(), gi.data_ptr(), part.data_ptr(), gp(0), gp(1), dbase, st))
         base = o.data_ptr()
         if nbits:

@@ -364,21 +364,40 @@ class BenchTrainer:
         self._primed = False
 
     def prime(self, min_seconds=1.0):
-        """Untimed set-up: one ordinary training step per camera, so that every instance-count-dependent buffer size has
-        been seen by the caching allocator (a first-seen size inside the timed window is a hipMalloc stall of several
-        ms, i.e. allocator noise rather than step time)."""
-        if not self._primed:
-            self._primed = True
-            import time
-            t0, i = time.perf_counter(), 0
-            # every camera once, and at least `min_seconds` of ordinary steps: on a fresh box the first second of a
-            # process is slowed by code / library page-in on the host, which starves the GPU and is not step time
-            # (multi-GPU: a FIXED count, identical on every rank -- a time-based count would desynchronise the collectives)
-            fixed = len(self.tr.cameras) if self.tr.world == 1 else max(len(self.tr.cameras), 64)
-            while i < fixed or (self.tr.world == 1 and time.perf_counter() - t0 < min_seconds):
-                self.step(-1 - i)
-                i += 1
-            torch.cuda.synchronize()
+        """Untimed set-up.  Runs ordinary training steps -- every camera at least once, so that every instance-count-
+        dependent buffer size has been seen by the caching allocator (a first-seen size inside the timed window is a
+        hipMalloc stall of several ms), and for at least `min_seconds`, because on a fresh box the first second of a
+        process is slowed by code / library page-in on the host, which starves the GPU -- and then puts the model, the
+        optimizer and the trainer back into their initial state, so the timed steps run on the workload as specified."""
+        if self._primed:
+            return
+        self._primed = True
+        import copy
+        import time
+        tr, m = self.tr, self.tr.model
+        names = ["_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity", "_objects_dc",
+                 "xyz_gradient_accum", "denom", "max_radii2D"]
+        saved = {k: getattr(m, k).detach().clone() for k in names if isinstance(getattr(m, k, None), torch.Tensor)}
+        host = (tr.current_iteration, tr.rng.getstate(), list(tr.view_order), copy.deepcopy(
+            [(g["name"], g["lr"]) for g in m.optimizer.param_groups]), m.active_sh_degree)
+        t0, i = time.perf_counter(), 0
+        # (multi-GPU: a FIXED count, identical on every rank -- a time-based count would desynchronise the collectives)
+        fixed = len(tr.cameras) if tr.world == 1 else max(len(tr.cameras), 64)
+        while i < fixed or (tr.world == 1 and time.perf_counter() - t0 < min_seconds):
+            self.step(-1 - i)
+            i += 1
+        tr.join_side()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for k, v in saved.items():
+                getattr(m, k).data.copy_(v)
+        m.optimizer.state = {}
+        m.optimizer.zero_grad(set_to_none=True)
+        tr.current_iteration, rng_state, tr.view_order, lrs, m.active_sh_degree = host
+        tr.rng.setstate(rng_state)
+        for g, (name, lr) in zip(m.optimizer.param_groups, lrs):
+            g["lr"] = lr
+        torch.cuda.synchronize()
 
     def step(self, i):
         from . import rasterizer
