@@ -36,6 +36,7 @@ def main():
                                        "consistent_normal_from_iter": 500})
 
     def eval_psnr():
+        tr.join_side()          # the last SH update may still be pending on / running on the trainer's second stream
         with torch.no_grad():
             vals = [float(psnr(render(c, tr.model, tr.cfg, tr.background, dirs=tr.dirs)["render"].clamp(0, 1),
                                c.original_image).mean()) for c in cams[:8]]

@@ -245,13 +245,15 @@ def test_two_stream_sh_path_trains_like_the_serial_loop(device):
     try:
         for overlap in (False, True):
             cams = synthetic.make_cameras(3, 128, 96, 110.0, device=device)
-            tr = make_synthetic_trainer(raw, cams, device, preset="tnt", overlap_sh=overlap,
+            tr = make_synthetic_trainer(raw, cams, device, preset="tnt", overlap_sh=overlap, overlap_min_gaussians=0,
                                         optim={"densify_from_iter": 10 ** 9, "opacity_reset_interval": 9})
             assert tr.overlap_sh == overlap and rasterizer.COLOUR_STREAM is None and rasterizer.SH_GRAD_MODE == "full"
             tr.model.active_sh_degree = 2
             for it in range(14):
                 if it == 6:
                     tr.model.active_sh_degree = 3
+                if it == 11:
+                    tr.overlap_min_gaussians = 10 ** 9       # model "shrank" below the threshold: back to one stream
                 tr.train_step()                              # iteration 9 resets the opacities (a surgery step)
             tr.join_side()
             torch.cuda.synchronize()

@@ -25,7 +25,7 @@ from .normal_utils import get_edge_aware_distortion_map
 
 class Trainer:
     def __init__(self, cfg, model, cameras, extent, device, world=1, rank=0, dirs=None, seed=0, force_factorised=False,
-                 overlap_sh=None):
+                 overlap_sh=None, overlap_min_gaussians=400_000):
         self.cfg, self.model, self.cameras = cfg, model, cameras
         self.device, self.world, self.rank = device, world, rank
         self.extent = extent
@@ -55,11 +55,14 @@ class Trainer:
             overlap_sh = world == 1 and not force_factorised and str(device).startswith("cuda") \
                 and not os.environ.get("VCR_NO_OVERLAP")
         self.overlap_sh = bool(overlap_sh) and world == 1
+        # below ~400 k Gaussians the step is launch-bound and the second stream's events / extra launches cost more than
+        # the overlap returns (100 k Gaussians at 400x300: 580 vs 810 it/s): the two-stream form is used per step, by size
+        self.overlap_min_gaussians = int(overlap_min_gaussians)
+        self._factorised_base = self.factorised_sh
         self.side = None
         self._pending_sh = None          # (drgb, view_dirs, sh_degree) of the last backward, not yet applied
         if self.overlap_sh:
             self.side = torch.cuda.Stream(device=device)
-            self.factorised_sh = True
 
     def _launch_pending_sh(self):
         """Enqueue the deferred SH Adam update on the side stream.  Called from the rasterizer's colour-stream hook, i.e.
@@ -268,8 +271,12 @@ class Trainer:
         fused = getattr(self, "use_fused_losses", True) and not any(
             k in self.weights for k in ("distortion", "depth_var", "semantic", "entropy", "mono_depth"))
         from . import rasterizer
-        with rasterizer.modes("rgb" if self.factorised_sh else "full", self.side if self.overlap_sh else None,
-                              self._launch_pending_sh if self.overlap_sh else None):
+        overlap = self.overlap_sh and m._xyz.shape[0] >= self.overlap_min_gaussians
+        self.factorised_sh = self._factorised_base or overlap
+        if not overlap and self._pending_sh is not None:
+            self.join_side()
+        with rasterizer.modes("rgb" if self.factorised_sh else "full", self.side if overlap else None,
+                              self._launch_pending_sh if overlap else None):
             data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True, geometry=not fused)
         if self._pending_sh is not None:         # the render did not go through the two-stream path (e.g. no Gaussians)
             self.join_side()
@@ -281,7 +288,7 @@ class Trainer:
                        and it % cfg.optim.densification_interval == 0) \
                 or it % cfg.optim.opacity_reset_interval == 0 or it in cfg.optim.prune.iterations \
                 or (cfg.model.white_background and it == cfg.optim.densify_from_iter)
-            if self.overlap_sh and not surgery:
+            if overlap and not surgery:
                 from . import rasterizer
                 for g in m.optimizer.param_groups:         # moments are created (zero-filled) on THIS stream, ahead of
                     if g["name"] in ("f_dc", "f_rest"):    # the projection the side stream will wait for
@@ -313,7 +320,7 @@ class Trainer:
 
 
 def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_jitter=0.02, seed=0,
-                           force_factorised=False, overlap_sh=None, **overrides):
+                           force_factorised=False, overlap_sh=None, overlap_min_gaussians=400_000, **overrides):
     """Model + GT (renders of a perturbed copy of the scene, so every loss is non-trivial) + Trainer."""
     from . import synthetic
     from .config import make_config
@@ -332,7 +339,7 @@ def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_
     dirs = get_all_px_dir(cams[0].intr, cams[0].image_height, cams[0].image_width) \
         if cfg.model.depth_type == "intersection" else None
     tr = Trainer(cfg, model, cams, extent, device, world=world, rank=rank, dirs=dirs, seed=seed,
-                 force_factorised=force_factorised, overlap_sh=overlap_sh)
+                 force_factorised=force_factorised, overlap_sh=overlap_sh, overlap_min_gaussians=overlap_min_gaussians)
     # ground truth from a jittered copy
     g = torch.Generator().manual_seed(seed + 1)
     raw2 = {k: v.clone() for k, v in raw.items()}
@@ -408,7 +415,7 @@ class BenchTrainer:
                 raise
             self._fell_back = True
             print(f"[bench] factorised SH exchange failed ({e!r}); falling back to dense all-reduce", flush=True)
-            self.tr.factorised_sh = False
+            self.tr.factorised_sh = self.tr._factorised_base = False
             rasterizer.last_drgb.clear()
             self.tr.model.optimizer.zero_grad(set_to_none=True)
             self.tr.train_step()
@@ -420,4 +427,4 @@ class BenchTrainer:
             (("RCCL exchange (all-gather dL/drgb + all-reduce 44 B/Gaussian) + " if self.tr.factorised_sh
               else "RCCL grad all-reduce + ") if self.tr.world > 1 else "") + \
             ("fused Adam, SH coefficients updated on a second stream beside the next step's sort chain"
-             if self.tr.overlap_sh else "fused Adam") + " (densify/prune off in the timed window)"
+             if (self.tr.overlap_sh and self.tr.model._xyz.shape[0] >= self.tr.overlap_min_gaussians) else "fused Adam") + " (densify/prune off in the timed window)"
