@@ -148,6 +148,13 @@ int vcr_sh_grad_from_rgb(int N, int sh_degree, int nviews, const float* xyz, con
 int vcr_sh_adam_from_rgb(int N, int sh_degree, const float* view_dirs, const float* drgb, float* features_dc,
                          float* features_rest, float* m_dc, float* v_dc, float* m_rest, float* v_rest, float lr_dc,
                          float lr_rest, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+/* Data-parallel form of vcr_sh_adam_from_rgb: gradient = sum_v basis_k(normalize(xyz - campos_all[v])) x drgb_all[v]
+ * (drgb_all [nviews,N,3] from the all-gather of dL_drgb, xyz = the means the views were rendered with), scaled by
+ * grad_scale (1/world), never materialised. */
+int vcr_sh_adam_from_rgb_views(int N, int sh_degree, int nviews, const float* xyz, const float* campos_all,
+                               const float* drgb_all, float* features_dc, float* features_rest, float* m_dc, float* v_dc,
+                               float* m_rest, float* v_rest, float lr_dc, float lr_rest, float beta1, float beta2, float eps,
+                               int step, float grad_scale, void* stream);
 /* The rasterizer's own stable LSD radix sort of (u32 key, u32 value) pairs on key bits [begin_bit, end_bit) (at most
  * 32 bits = 4 passes), exposed for testing and reuse; replaces cub/rocPRIM DeviceRadixSort::SortPairs in the public
  * rasterizer's binning.  vals_in == NULL sorts the identity permutation.  scratch: vcr_sort_pairs_u32_scratch_bytes(n). */

@@ -286,18 +286,24 @@ def test_rccl_exchange_path_single_rank_group(device):
         raw = synthetic.make_gaussians(6000, seed=4)
         raw["scaling"] = raw["scaling"] + 1.0
         finals = []
-        for coll in (False, True):
+        for coll, overlap in ((False, False), (True, False), (True, True)):
+            # (True, True): the data-parallel two-stream form -- the all-gather is awaited by the second stream only and the
+            # SH update (vcr_sh_adam_from_rgb_views) is issued from the next forward's colour-stream hook
             cams = synthetic.make_cameras(3, 128, 96, 110.0, device=device)
-            tr = make_synthetic_trainer(raw, cams, device, preset="tnt", force_factorised=True, overlap_sh=False,
+            tr = make_synthetic_trainer(raw, cams, device, preset="tnt", force_factorised=not overlap, overlap_sh=overlap,
+                                        overlap_min_gaussians=0,
                                         optim={"densify_from_iter": 10 ** 9, "densify_until_iter": 100})
             tr.force_collectives = coll
             for _ in range(8):
                 tr.train_step()
+            tr.join_side()
+            torch.cuda.synchronize()
             finals.append({k: getattr(tr.model, k).detach().clone() for k in ["_features_rest", "_xyz", "_scaling"]})
             stats = (tr.model.xyz_gradient_accum.clone(), tr.model.denom.clone(), tr.model.max_radii2D.clone())
             finals[-1]["stats"] = torch.cat([stats[0].flatten(), stats[1].flatten(), stats[2].flatten()])
         for k in finals[0]:
             assert torch.allclose(finals[0][k], finals[1][k], rtol=5e-3, atol=1e-5), k      # fp32 atomics: run-to-run noise
+            assert torch.allclose(finals[0][k], finals[2][k], rtol=5e-3, atol=1e-5), k
     finally:
         rasterizer.SH_GRAD_MODE = "full"
         dist.destroy_process_group()
@@ -384,6 +390,37 @@ def test_sh_adam_from_rgb_equals_dense_gradient_plus_adam(device):
                                             0.9, 0.999, 1e-15, step, 1.0, st))
         for a, b in zip(p + m + v, q + mq + vq):
             assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), float((a - b).abs().max())
+
+
+def test_sh_adam_from_rgb_views_equals_dense_gradient_plus_adam(device):
+    """Data-parallel form: vcr_sh_adam_from_rgb_views == (vcr_sh_grad_from_rgb over 3 views -> vcr_adam_step with the
+    1/world gradient scale)."""
+    import ctypes as C
+    from vcr_gaus_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(12)
+    n, V = 4097, 3
+    xyz = torch.randn(n, 3, generator=g).to(device)
+    campos = torch.tensor([[0.3, -2.0, 4.0], [3.0, 0.5, -2.0], [-4.0, 1.0, 0.2]], device=device)
+    drgb = (torch.randn(V, n, 3, generator=g) * (torch.rand(V, n, 1, generator=g) > 0.4)).to(device).contiguous()
+    dc0, rest0 = torch.randn(n, 1, 3, generator=g).to(device), torch.randn(n, 15, 3, generator=g).to(device)
+    m0 = [0.01 * torch.randn(n, 1, 3, generator=g).to(device), 0.01 * torch.randn(n, 15, 3, generator=g).to(device)]
+    v0 = [1e-4 * torch.rand(n, 1, 3, generator=g).to(device), 1e-4 * torch.rand(n, 15, 3, generator=g).to(device)]
+    st = _lib.stream_of(xyz)
+    gd, gr = torch.empty(n, 1, 3, device=device), torch.empty(n, 15, 3, device=device)
+    _lib.check(lib.vcr_sh_grad_from_rgb(n, 3, V, xyz.data_ptr(), campos.data_ptr(), drgb.data_ptr(), gd.data_ptr(), gr.data_ptr(), st))
+    p = [dc0.clone(), rest0.clone()]
+    m, v = [t.clone() for t in m0], [t.clone() for t in v0]
+    arr = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])
+    _lib.check(lib.vcr_adam_step(2, arr(p), arr([gd, gr]), arr(m), arr(v), (C.c_int64 * 2)(3 * n, 45 * n),
+                                 (C.c_float * 2)(0.0025, 0.000125), 0.9, 0.999, 1e-15, 5, 1.0 / V, st))
+    q = [dc0.clone(), rest0.clone()]
+    mq, vq = [t.clone() for t in m0], [t.clone() for t in v0]
+    _lib.check(lib.vcr_sh_adam_from_rgb_views(n, 3, V, xyz.data_ptr(), campos.data_ptr(), drgb.data_ptr(), q[0].data_ptr(),
+                                              q[1].data_ptr(), mq[0].data_ptr(), vq[0].data_ptr(), mq[1].data_ptr(), vq[1].data_ptr(),
+                                              0.0025, 0.000125, 0.9, 0.999, 1e-15, 5, 1.0 / V, st))
+    for a, b in zip(p + m + v, q + mq + vq):
+        assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), float((a - b).abs().max())
 
 
 def test_weighted_total(device):

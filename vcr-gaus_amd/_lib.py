@@ -67,6 +67,8 @@ SYMBOLS = {
     "vcr_finalize_losses": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p]),
     "vcr_weighted_total": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "vcr_sh_grad_from_rgb": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
+    "vcr_sh_adam_from_rgb_views": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_float] * 5
+                                   + [C.c_int, C.c_float, C.c_void_p]),
     "vcr_sh_adam_from_rgb": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_float] * 5 + [C.c_int, C.c_float, C.c_void_p]),
     "vcr_knn3_mean_dist2": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vcr_adam_step": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),

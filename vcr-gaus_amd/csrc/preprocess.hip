@@ -664,6 +664,52 @@ __global__ void __launch_bounds__(256) sh_adam_from_rgb_kernel(int N, int deg, c
     }
 }
 
+// Data-parallel form: gradient = sum over the step's views of basis_k(normalize(xyz - campos_v)) x dL/drgb_v (drgb_all
+// [nviews,N,3] from the all-gather), formed on the fly like sh_grad_from_rgb_kernel, then the same Adam as above.
+__global__ void __launch_bounds__(256) sh_adam_from_views_kernel(int N, int deg, int nviews, const float* __restrict__ xyz,
+                                                                 const float* __restrict__ campos,
+                                                                 const float* __restrict__ drgb, float* p_dc, float* p_rest,
+                                                                 float* m_dc, float* v_dc, float* m_rest, float* v_rest,
+                                                                 float lr_dc_bc1, float lr_rest_bc1, float b1, float b2, float eps,
+                                                                 float bc2_sqrt, float gscale) {
+    extern __shared__ __attribute__((aligned(16))) float s_sh[];
+    const int nblk = (N + 255) / 256;
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int i = blk * 256 + threadIdx.x;
+        const int blk_base = blk * 256, blk_cnt = min(256, N - blk_base);
+        float* row = s_sh + threadIdx.x * SH_ROW;
+        __syncthreads();
+        if (i < N) {
+            float acc[48];
+#pragma unroll
+            for (int k = 0; k < 48; ++k) acc[k] = 0.f;
+            const float p0 = xyz[3 * (size_t)i], p1 = xyz[3 * (size_t)i + 1], p2 = xyz[3 * (size_t)i + 2];
+            for (int v = 0; v < nviews; ++v) {
+                const float* g = drgb + ((size_t)v * N + i) * 3;
+                const float g0 = g[0] * gscale, g1 = g[1] * gscale, g2 = g[2] * gscale;
+                if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;
+                float dx = p0 - campos[3 * v], dy = p1 - campos[3 * v + 1], dz = p2 - campos[3 * v + 2];
+                const float il = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+                float b[16];
+                sh_basis<false>(deg, dx * il, dy * il, dz * il, b, nullptr, nullptr, nullptr);
+                const int nb = (deg + 1) * (deg + 1);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float bk = k < nb ? b[k] : 0.f;
+                    acc[3 * k] += bk * g0; acc[3 * k + 1] += bk * g1; acc[3 * k + 2] += bk * g2;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 48; ++k) row[k] = acc[k];
+        }
+        __syncthreads();
+        coop_adam(p_dc + (size_t)blk_base * 3, m_dc + (size_t)blk_base * 3, v_dc + (size_t)blk_base * 3, blk_cnt * 3, 3, 0, s_sh,
+                  lr_dc_bc1, b1, b2, eps, bc2_sqrt);
+        coop_adam(p_rest + (size_t)blk_base * 45, m_rest + (size_t)blk_base * 45, v_rest + (size_t)blk_base * 45, blk_cnt * 45, 45,
+                  3, s_sh, lr_rest_bc1, b1, b2, eps, bc2_sqrt);
+    }
+}
+
 }  // namespace
 
 extern "C" int vcr_sh_adam_from_rgb(int N, int sh_degree, const float* view_dirs, const float* drgb, float* features_dc,
@@ -678,6 +724,23 @@ extern "C" int vcr_sh_adam_from_rgb(int N, int sh_degree, const float* view_dirs
     const int nblk = (N + 255) / 256, grid = nblk < vcr_side_grid() ? nblk : vcr_side_grid();
     hipLaunchKernelGGL(sh_adam_from_rgb_kernel, dim3(grid), dim3(256), 256 * SH_ROW * sizeof(float), (hipStream_t)stream,
                        N, sh_degree, view_dirs, drgb, features_dc, features_rest, m_dc, v_dc, m_rest, v_rest,
+                       (float)(lr_dc / bc1), (float)(lr_rest / bc1), beta1, beta2, eps, (float)sqrt(bc2), grad_scale);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_sh_adam_from_rgb_views(int N, int sh_degree, int nviews, const float* xyz, const float* campos_all,
+                                          const float* drgb_all, float* features_dc, float* features_rest, float* m_dc,
+                                          float* v_dc, float* m_rest, float* v_rest, float lr_dc, float lr_rest, float beta1,
+                                          float beta2, float eps, int step, float grad_scale, void* stream) {
+    if (N <= 0) return 0;
+    if (sh_degree < 0 || sh_degree > 3 || step < 1 || nviews <= 0) { vcr_set_error("vcr_sh_adam_from_rgb_views: bad degree/step/views"); return 1; }
+    if ((((uintptr_t)features_dc) | ((uintptr_t)features_rest) | ((uintptr_t)m_dc) | ((uintptr_t)v_dc) | ((uintptr_t)m_rest) |
+         ((uintptr_t)v_rest)) & 15) { vcr_set_error("vcr_sh_adam_from_rgb_views: tensors must be 16-byte aligned"); return 1; }
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const int nblk = (N + 255) / 256, grid = nblk < vcr_side_grid() ? nblk : vcr_side_grid();
+    hipLaunchKernelGGL(sh_adam_from_views_kernel, dim3(grid), dim3(256), 256 * SH_ROW * sizeof(float), (hipStream_t)stream, N,
+                       sh_degree, nviews, xyz, campos_all, drgb_all, features_dc, features_rest, m_dc, v_dc, m_rest, v_rest,
                        (float)(lr_dc / bc1), (float)(lr_rest / bc1), beta1, beta2, eps, (float)sqrt(bc2), grad_scale);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;

@@ -140,6 +140,29 @@ class FusedAdam:
                                             float(rest["lr"]), self.betas[0], self.betas[1], self.eps, int(sd["step"]),
                                             float(self.grad_scale), st))
 
+    @torch.no_grad()
+    def step_sh_from_rgb_views(self, drgb_all, xyz, campos_all, sh_degree, stream=None):
+        """Data-parallel form of `step_sh_from_rgb`: gradient = sum over views of basis(normalize(xyz - campos_v)) x
+        drgb_all[v], times `grad_scale` (HIP kernel vcr_sh_adam_from_rgb_views); `xyz` are the means the views were
+        rendered with (a snapshot when the geometry update is already queued)."""
+        lib = _lib.load()
+        groups = {g["name"]: g for g in self.param_groups}
+        dc, rest = groups["f_dc"], groups["f_rest"]
+        sd, sr = self._state(dc), self._state(rest)
+        sd["step"] += 1
+        sr["step"] += 1
+        if sd["step"] != sr["step"]:
+            raise RuntimeError("f_dc / f_rest Adam steps diverged")
+        pd, pr = dc["params"][0], rest["params"][0]
+        if pd.numel() == 0:
+            return
+        st = (stream.cuda_stream if stream is not None else torch.cuda.current_stream(pd.device).cuda_stream)
+        _lib.check(lib.vcr_sh_adam_from_rgb_views(pd.shape[0], int(sh_degree), int(drgb_all.shape[0]), xyz.data_ptr(),
+                                                  campos_all.data_ptr(), drgb_all.data_ptr(), pd.data_ptr(), pr.data_ptr(),
+                                                  sd["exp_avg"].data_ptr(), sd["exp_avg_sq"].data_ptr(), sr["exp_avg"].data_ptr(),
+                                                  sr["exp_avg_sq"].data_ptr(), float(dc["lr"]), float(rest["lr"]), self.betas[0],
+                                                  self.betas[1], self.eps, int(sd["step"]), float(self.grad_scale), st))
+
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
             for p in g["params"]:

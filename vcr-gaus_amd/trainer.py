@@ -51,10 +51,12 @@ class Trainer:
         # coefficients on the side stream while the main stream already runs the next iteration's geometry Adam,
         # activation, projection and the latency-bound sort chain; that iteration's SH -> RGB evaluation follows on the
         # side stream and is joined before compositing.  Same arithmetic and ordering of updates as the serial loop.
+        # Data parallel: the same second stream additionally waits for the all-gather of dL/drgb, so that exchange (the
+        # larger of the two: 12 B/Gaussian/view) and the SH update run beside the next iteration's geometry all-reduce
+        # wait, geometry Adam, projection and sort chain instead of in front of them.
         if overlap_sh is None:
-            overlap_sh = world == 1 and not force_factorised and str(device).startswith("cuda") \
-                and not os.environ.get("VCR_NO_OVERLAP")
-        self.overlap_sh = bool(overlap_sh) and world == 1
+            overlap_sh = not force_factorised and str(device).startswith("cuda") and not os.environ.get("VCR_NO_OVERLAP")
+        self.overlap_sh = bool(overlap_sh)
         # below ~400 k Gaussians the step is launch-bound and the second stream's events / extra launches cost more than
         # the overlap returns (100 k Gaussians at 400x300: 580 vs 810 it/s): the two-stream form is used per step, by size
         self.overlap_min_gaussians = int(overlap_min_gaussians)
@@ -70,8 +72,16 @@ class Trainer:
         the gradients) and before the SH -> RGB evaluation: the update runs beside the latency-bound sort chain."""
         if self._pending_sh is None:
             return
-        drgb, vdirs, deg = self._pending_sh
-        self._pending_sh = None
+        pend, self._pending_sh = self._pending_sh, None
+        if pend[0] == "views":           # data parallel: (tag, all-gather work, drgb_all, xyz snapshot, campos_all, degree)
+            _, gather, drgb_all, xyz0, campos_all, deg = pend
+            with torch.cuda.stream(self.side):
+                gather.wait()            # the SIDE stream waits for the collective
+            for t in (drgb_all, xyz0, campos_all):
+                t.record_stream(self.side)
+            self.model.optimizer.step_sh_from_rgb_views(drgb_all, xyz0, campos_all, deg, stream=self.side)
+            return
+        drgb, vdirs, deg = pend
         drgb.record_stream(self.side)
         vdirs.record_stream(self.side)
         self.model.optimizer.step_sh_from_rgb(drgb, vdirs, deg, stream=self.side)
@@ -144,7 +154,7 @@ class Trainer:
         return self._wvec
 
     # ---- gradient exchange ------------------------------------------------------------------------------------
-    def _allreduce_grads(self, early_feature_step=False):
+    def _allreduce_grads(self, early_feature_step=False, defer_sh=False):
         """Sum the per-Gaussian gradients of all ranks (RCCL over xGMI).  One collective per parameter
         tensor, all in flight together; the 1/world scale is folded into the Adam kernel.  With the factorised SH
         exchange the all-gather of dL/drgb is awaited first, the SH gradients are rebuilt and (on iterations without
@@ -178,11 +188,19 @@ class Trainer:
                 p.grad = torch.zeros_like(p)
             works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
         if gather is not None:
-            gather.wait()
             campos_all = torch.stack([self.cameras[i].camera_center for i in self._picked]).float().contiguous()
-            self.model._features_dc.grad, self.model._features_rest.grad = self._sh_grads_from_rgb(drgb_all, campos_all)
-            if early_feature_step:
-                self.model.optimizer.step(only={"f_dc", "f_rest"})
+            if defer_sh:
+                # nobody on this stream waits for the all-gather: the SH update (gradient formed on the fly from all views)
+                # is applied on the second stream from the next forward's hook, beside its sort chain.  xyz is snapshotted
+                # because the geometry update below runs first.
+                rasterizer.last_drgb.pop("dirs", None)
+                self._pending_sh = ("views", gather, drgb_all, self.model._xyz.detach().clone(), campos_all,
+                                    int(self.model.active_sh_degree))
+            else:
+                gather.wait()
+                self.model._features_dc.grad, self.model._features_rest.grad = self._sh_grads_from_rgb(drgb_all, campos_all)
+                if early_feature_step:
+                    self.model.optimizer.step(only={"f_dc", "f_rest"})
         for w in works:
             w.wait()
 
