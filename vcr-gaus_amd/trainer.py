@@ -180,13 +180,26 @@ class Trainer:
             flat = torch.empty((self.world * drgb.shape[0], 3), dtype=drgb.dtype, device=drgb.device)
             gather = dist.all_gather_into_tensor(flat, drgb, async_op=True)           # concatenated along dim 0
             drgb_all = flat.view(self.world, drgb.shape[0], 3)
-        for g in self.model.optimizer.param_groups:
-            if self.factorised_sh and g["name"] in ("f_dc", "f_rest"):
-                continue
-            p = g["params"][0]
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-            works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
+        # ONE bucket for the remaining gradients (xyz, opacity, scaling, rotation, ...): a ring all-reduce pays 2(n-1) link
+        # latencies per call, so four small collectives cost four times the latency of one (xGMI is point-to-point)
+        params = [g["params"][0] for g in self.model.optimizer.param_groups
+                  if not (self.factorised_sh and g["name"] in ("f_dc", "f_rest"))]
+        sizes = [(p.numel() + 3) // 4 * 4 for p in params]                    # 16-byte aligned segments for the Adam kernel
+        ref = params[0]
+        if all(p.grad is not None and n == p.numel() for p, n in zip(params, sizes)):
+            flat = torch.cat([p.grad.reshape(-1) for p in params])            # one kernel
+        else:
+            flat = torch.zeros(sum(sizes), dtype=ref.dtype, device=ref.device)
+            off = 0
+            for p, n in zip(params, sizes):
+                if p.grad is not None:
+                    flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+                off += n
+        works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+        off = 0
+        for p, n in zip(params, sizes):
+            p.grad = flat[off:off + p.numel()].view_as(p)                       # views of the bucket: no copy back
+            off += n
         if gather is not None:
             campos_all = torch.stack([self.cameras[i].camera_center for i in self._picked]).float().contiguous()
             if defer_sh:
