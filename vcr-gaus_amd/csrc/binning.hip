@@ -27,9 +27,7 @@ struct GatherTiles {
 
 __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, const uint32_t* __restrict__ ids_sorted,
                                                         const uint32_t* __restrict__ offsets,
-                                                        const GeomRec* __restrict__ rec,
-                                                        const int32_t* __restrict__ radii,
-                                                        const uint32_t* __restrict__ tiles,
+                                                        const uint2* __restrict__ rect,
                                                         uint32_t* __restrict__ keys_out,
                                                         uint32_t* __restrict__ vals_out, uint2* __restrict__ ranges,
                                                         int num_tiles) {
@@ -37,21 +35,18 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
     __shared__ int s_xmin[4][64], s_ymin[4][64], s_w[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int gi = blockIdx.x * 256 + threadIdx.x;
-    const int gx = (W + VCR_TILE - 1) / VCR_TILE, gy = (H + VCR_TILE - 1) / VCR_TILE;
+    const int gx = (W + VCR_TILE - 1) / VCR_TILE;
     for (int t = gi; t < num_tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);   // empty tiles (tile_ranges fills the rest)
     uint32_t id = 0, cnt = 0, end;
     int xmin = 0, ymin = 0, w = 1;
     if (gi < N) {
         id = ids_sorted[gi];
-        cnt = tiles[id];
         end = offsets[gi];
-        if (cnt) {
-            const float px = rec[id].px, py = rec[id].py, rad = (float)radii[id];
-            xmin = min(gx, max(0, (int)floorf((px - rad) / VCR_TILE)));
-            const int xmax = min(gx, max(0, (int)floorf((px + rad + VCR_TILE - 1) / VCR_TILE)));
-            ymin = min(gy, max(0, (int)floorf((py - rad) / VCR_TILE)));
-            w = xmax - xmin;
-        }
+        const uint2 rc = rect[id];                      // {0, 0} for culled Gaussians
+        w = (int)(rc.y & 0xFFFFu);
+        cnt = (uint32_t)w * (rc.y >> 16);
+        xmin = (int)(rc.x & 0xFFFFu); ymin = (int)(rc.x >> 16);
+        if (cnt == 0) w = 1;
     } else {
         end = offsets[N - 1];
     }
@@ -145,8 +140,8 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
         return vcr_launch_tile_order(num_tiles, ranges, tile_order, false, false, st);   // identity order
     }
     const int blocks = (a.N + 255) / 256;
-    hipLaunchKernelGGL(duplicate_kernel, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, offsets, g.rec, radii,
-                       g.tiles, keys_a, vals_a, ranges, num_tiles);
+    hipLaunchKernelGGL(duplicate_kernel, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, offsets, g.rect,
+                       keys_a, vals_a, ranges, num_tiles);
     VCR_HIP_CHECK(hipGetLastError());
     if (R > VCR_SORT_HAND_MAX) {
         size_t tb = temp_bytes;

@@ -205,6 +205,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const
     ids[i] = i;
     radii[i] = 0;
     g.tiles[i] = 0;
+    g.rect[i] = make_uint2(0u, 0u);
     depth_key[i] = 0xFFFFFFFFu;
 
     const Cam cam = load_cam(a);
@@ -288,6 +289,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const
     for (int k = 0; k < a.S; ++k) g.sem[(size_t)i * a.S + k] = a.semantics_precomp[(size_t)i * a.S + k];
     if (COLOUR) g.clamped[i] = clampbits;
     g.tiles[i] = (uint32_t)ntiles;
+    g.rect[i] = make_uint2((uint32_t)xmin | ((uint32_t)ymin << 16), (uint32_t)(xmax - xmin) | ((uint32_t)(ymax - ymin) << 16));
     radii[i] = (int32_t)rad;
     depth_key[i] = __float_as_uint(pr.t[2]);
     return (uint32_t)ntiles;

@@ -56,9 +56,11 @@ struct GeomState {
     float* sem;          // [N,S]
     uint32_t* tiles;     // [N] tiles touched (0 = culled)
     uint8_t* clamped;    // [N] bit c set when colour channel c was clamped at 0
+    uint2* rect;         // [N] tile rectangle {xmin | ymin << 16, width | height << 16}: ONE 8-byte gather per Gaussian
+                         //     for the instance emission instead of three (tiles, record, radius)
     static size_t bytes(int N, int S) {
         return vcr_align(sizeof(GeomRec) * (size_t)N) + vcr_align(sizeof(float) * (size_t)N * (S > 0 ? S : 1)) +
-               vcr_align(sizeof(uint32_t) * (size_t)N) + vcr_align((size_t)N);
+               vcr_align(sizeof(uint32_t) * (size_t)N) + vcr_align((size_t)N) + vcr_align(sizeof(uint2) * (size_t)N);
     }
     static GeomState view(void* p, int N, int S) {
         GeomState g;
@@ -66,7 +68,8 @@ struct GeomState {
         g.rec = (GeomRec*)c;      c += vcr_align(sizeof(GeomRec) * (size_t)N);
         g.sem = (float*)c;        c += vcr_align(sizeof(float) * (size_t)N * (S > 0 ? S : 1));
         g.tiles = (uint32_t*)c;   c += vcr_align(sizeof(uint32_t) * (size_t)N);
-        g.clamped = (uint8_t*)c;
+        g.clamped = (uint8_t*)c;  c += vcr_align((size_t)N);
+        g.rect = (uint2*)c;
         return g;
     }
 };
