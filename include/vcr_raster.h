@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 7
+#define VCR_ABI_VERSION 8
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -32,6 +32,22 @@ enum { VCR_BUF_GEOM = 0, VCR_BUF_BINNING = 1, VCR_BUF_IMAGE = 2, VCR_BUF_SCRATCH
 
 /* Mirrors GaussianRasterizationSettings + the forward kwargs
  * (gaussian_renderer/__init__.py:43-57,107-120). */
+/* Optional SH-coefficient update applied on the colour stream right before the SH -> RGB evaluation of a forward call
+ * (VcrRasterArgs.sh_update): the Adam step of vcr_sh_adam_from_rgb (nviews == 0, gradient = basis(view_dirs) x drgb) or of
+ * vcr_sh_adam_from_rgb_views (nviews > 0, gradient summed over the views from xyz / campos_all), fused with the colour
+ * evaluation so that the updated coefficients are not read back from HBM.  Updates shs / shs_rest of the call IN PLACE
+ * (split storage required). */
+typedef struct VcrShUpdate {
+    int32_t nviews, sh_degree, step;
+    float grad_scale;
+    const float* view_dirs;     /* [N,3], nviews == 0 */
+    const float* drgb;          /* [N,3] or [nviews,N,3] */
+    const float* xyz;           /* [N,3] means the views were rendered with, nviews > 0 */
+    const float* campos_all;    /* [nviews,3], nviews > 0 */
+    float* m_dc; float* v_dc; float* m_rest; float* v_rest;     /* Adam moments of features_dc / features_rest */
+    float lr_dc, lr_rest, beta1, beta2, eps;
+} VcrShUpdate;
+
 typedef struct VcrRasterArgs {
     int32_t N;            /* Gaussians */
     int32_t H, W;         /* image_height, image_width */
@@ -67,6 +83,7 @@ typedef struct VcrRasterArgs {
                                    colour_stream here (e.g. vcr_sh_adam_from_rgb of the previous iteration) runs beside
                                    the sort chain and ahead of the colour evaluation */
     void* colour_stream_hook_user;
+    const VcrShUpdate* sh_update;   /* optional, with colour_stream: see VcrShUpdate */
 } VcrRasterArgs;
 
 /* Forward outputs.  `out`, `radii`, counters are caller-allocated. */

@@ -18,6 +18,15 @@ HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 BUF_GEOM, BUF_BINNING, BUF_IMAGE, BUF_SCRATCH = 0, 1, 2, 3
 
 
+class VcrShUpdate(C.Structure):
+    _fields_ = [
+        ("nviews", C.c_int32), ("sh_degree", C.c_int32), ("step", C.c_int32), ("grad_scale", C.c_float),
+        ("view_dirs", C.c_void_p), ("drgb", C.c_void_p), ("xyz", C.c_void_p), ("campos_all", C.c_void_p),
+        ("m_dc", C.c_void_p), ("v_dc", C.c_void_p), ("m_rest", C.c_void_p), ("v_rest", C.c_void_p),
+        ("lr_dc", C.c_float), ("lr_rest", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+    ]
+
+
 class VcrRasterArgs(C.Structure):
     _fields_ = [
         ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("S", C.c_int32), ("K", C.c_int32),
@@ -27,7 +36,7 @@ class VcrRasterArgs(C.Structure):
         ("means3D", C.c_void_p), ("shs", C.c_void_p), ("shs_rest", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("normals_precomp", C.c_void_p), ("semantics_precomp", C.c_void_p), ("opacities", C.c_void_p),
         ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("dirs", C.c_void_p),
-        ("colour_stream", C.c_void_p), ("colour_stream_hook", C.c_void_p), ("colour_stream_hook_user", C.c_void_p),
+        ("colour_stream", C.c_void_p), ("colour_stream_hook", C.c_void_p), ("colour_stream_hook_user", C.c_void_p), ("sh_update", C.c_void_p),
     ]
 
 
@@ -113,7 +122,7 @@ def load():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.vcr_abi_version() != 7:
+    if lib.vcr_abi_version() != 8:
         raise ImportError("libvcr_raster.so ABI version mismatch")
     _lib = lib
     return lib

@@ -186,6 +186,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         VCR_HIP_CHECK(hipMemsetAsync(ctr, 0, sizeof(uint32_t) * VCR_CTR_WORDS, st));
         // two-stream form: geometry here, SH -> RGB on the colour stream behind whatever the caller queued there
         const bool split_colour = a.colour_stream && a.colour_stream != stream && a.shs && !a.colors_precomp;
+        if (a.sh_update && !split_colour) { vcr_set_error("sh_update needs colour_stream and SH colours"); return 1; }
         {
             StageTimer tm(ST_PREPROCESS, st);
             if (vcr_launch_preprocess(a, g, out->radii, depth_key, ids, vis_counter, !split_colour, st)) return 1;
@@ -197,7 +198,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             VCR_HIP_CHECK(hipEventRecord(e_geo, st));
             VCR_HIP_CHECK(hipStreamWaitEvent(cs, e_geo, 0));
             if (a.colour_stream_hook) a.colour_stream_hook(a.colour_stream_hook_user);
-            if (vcr_launch_colour(a, g, cs)) return 1;
+            if (a.sh_update ? vcr_launch_sh_update_colour(a, g, cs) : vcr_launch_colour(a, g, cs)) return 1;
             VCR_HIP_CHECK(hipEventRecord(e_col, cs));
         }
         // R and V go back to the host now; the depth sort and the offsets scan do not need them and keep the GPU busy

@@ -592,8 +592,10 @@ __global__ void __launch_bounds__(256) sh_grad_from_rgb_kernel(int N, int deg, i
 // ---- SH Adam with the gradient formed on the fly (single-view training) ------------------------------------------------
 // grad[g][k][c] = basis_k(view_dirs[g]) * drgb[g][c]; every lane builds its Gaussian's 48-value row in LDS, then the
 // block streams params / moments with coalesced 16-byte accesses (same row mapping as coop_copy_*) and applies Adam.
+// KEEP: the updated parameter replaces the gradient in the LDS row (for the fused colour evaluation)
+template <bool KEEP = false>
 __device__ __forceinline__ void coop_adam(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, int total, int per,
-                                          int off, const float* s, float lr_bc1, float b1, float b2, float eps, float bc2_sqrt) {
+                                          int off, float* s, float lr_bc1, float b1, float b2, float eps, float bc2_sqrt) {
     const int n4 = total >> 2;                              // rows start 16-byte aligned: 256*3 and 256*45 floats per block
     float4* p4 = reinterpret_cast<float4*>(p); float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
     // software-pipelined by hand: all 12 loads of four 16-byte groups are issued before the first use, so that a small
@@ -614,10 +616,12 @@ __device__ __forceinline__ void coop_adam(float* __restrict__ p, float* __restri
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int e = e4 * 4 + j, g = e / per;
-                const float gr = s[g * SH_ROW + off + (e - g * per)];
+                float* slot = s + g * SH_ROW + off + (e - g * per);
+                const float gr = *slot;
                 M[j] = b1 * M[j] + (1.f - b1) * gr;
                 V[j] = b2 * V[j] + (1.f - b2) * gr * gr;
                 P[j] -= lr_bc1 * (M[j] / (sqrtf(V[j]) / bc2_sqrt + eps));
+                if (KEEP) *slot = P[j];
             }
             p4[e4] = make_float4(P[0], P[1], P[2], P[3]); m4[e4] = make_float4(M[0], M[1], M[2], M[3]);
             v4[e4] = make_float4(V[0], V[1], V[2], V[3]);
@@ -625,10 +629,13 @@ __device__ __forceinline__ void coop_adam(float* __restrict__ p, float* __restri
     }
     for (int e = (n4 << 2) + threadIdx.x; e < total; e += 256) {
         const int g = e / per;
-        const float gr = s[g * SH_ROW + off + (e - g * per)];
+        float* slot = s + g * SH_ROW + off + (e - g * per);
+        const float gr = *slot;
         const float M = b1 * m[e] + (1.f - b1) * gr, V = b2 * v[e] + (1.f - b2) * gr * gr;
         m[e] = M; v[e] = V;
-        p[e] -= lr_bc1 * (M / (sqrtf(V) / bc2_sqrt + eps));
+        const float P = p[e] - lr_bc1 * (M / (sqrtf(V) / bc2_sqrt + eps));
+        p[e] = P;
+        if (KEEP) *slot = P;
     }
 }
 
@@ -712,6 +719,77 @@ __global__ void __launch_bounds__(256) sh_adam_from_views_kernel(int N, int deg,
     }
 }
 
+// SH update (VcrShUpdate) + SH -> RGB of the same forward call in one pass over the coefficients: the Adam step leaves the
+// updated coefficients in the LDS rows, from which every lane evaluates its Gaussian's colour for THIS call's camera.
+__global__ void __launch_bounds__(256) sh_update_colour_kernel(VcrRasterArgs a, GeomState g, VcrShUpdate u, float lr_dc_bc1,
+                                                               float lr_rest_bc1, float bc2_sqrt) {
+    extern __shared__ __attribute__((aligned(16))) float s_sh[];
+    const int N = a.N, nblk = (N + 255) / 256;
+    float* p_dc = const_cast<float*>(a.shs);
+    float* p_rest = const_cast<float*>(a.shs_rest);
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int i = blk * 256 + threadIdx.x;
+        const int blk_base = blk * 256, blk_cnt = min(256, N - blk_base);
+        float* row = s_sh + threadIdx.x * SH_ROW;
+        __syncthreads();
+        if (i < N) {
+            float acc[48];
+#pragma unroll
+            for (int k = 0; k < 48; ++k) acc[k] = 0.f;
+            const int nbu = (u.sh_degree + 1) * (u.sh_degree + 1);
+            const int nv = u.nviews > 0 ? u.nviews : 1;
+            for (int v = 0; v < nv; ++v) {
+                const float* gp = u.drgb + ((size_t)v * N + i) * 3;
+                const float g0 = gp[0] * u.grad_scale, g1 = gp[1] * u.grad_scale, g2 = gp[2] * u.grad_scale;
+                if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;
+                float dx, dy, dz;
+                if (u.nviews > 0) {
+                    dx = u.xyz[3 * (size_t)i] - u.campos_all[3 * v]; dy = u.xyz[3 * (size_t)i + 1] - u.campos_all[3 * v + 1];
+                    dz = u.xyz[3 * (size_t)i + 2] - u.campos_all[3 * v + 2];
+                    const float il = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+                    dx *= il; dy *= il; dz *= il;
+                } else {
+                    dx = u.view_dirs[3 * (size_t)i]; dy = u.view_dirs[3 * (size_t)i + 1]; dz = u.view_dirs[3 * (size_t)i + 2];
+                }
+                float b[16];
+                sh_basis<false>(u.sh_degree, dx, dy, dz, b, nullptr, nullptr, nullptr);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float bk = k < nbu ? b[k] : 0.f;
+                    acc[3 * k] += bk * g0; acc[3 * k + 1] += bk * g1; acc[3 * k + 2] += bk * g2;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 48; ++k) row[k] = acc[k];
+        }
+        __syncthreads();
+        coop_adam<true>(p_dc + (size_t)blk_base * 3, u.m_dc + (size_t)blk_base * 3, u.v_dc + (size_t)blk_base * 3, blk_cnt * 3, 3, 0,
+                        s_sh, lr_dc_bc1, u.beta1, u.beta2, u.eps, bc2_sqrt);
+        coop_adam<true>(p_rest + (size_t)blk_base * 45, u.m_rest + (size_t)blk_base * 45, u.v_rest + (size_t)blk_base * 45,
+                        blk_cnt * 45, 45, 3, s_sh, lr_rest_bc1, u.beta1, u.beta2, u.eps, bc2_sqrt);
+        __syncthreads();
+        if (i < N && g.tiles[i] != 0) {            // colour of the visible Gaussians from the freshly updated rows
+            const float* c = a.campos;
+            float dx = a.means3D[3 * (size_t)i] - c[0], dy = a.means3D[3 * (size_t)i + 1] - c[1], dz = a.means3D[3 * (size_t)i + 2] - c[2];
+            const float il = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+            float b[16];
+            sh_basis<false>(a.sh_degree, dx * il, dy * il, dz * il, b, nullptr, nullptr, nullptr);
+            const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
+            float c0 = 0.5f, c1 = 0.5f, c2 = 0.5f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < nb) { c0 += b[k] * row[3 * k]; c1 += b[k] * row[3 * k + 1]; c2 += b[k] * row[3 * k + 2]; }
+            }
+            uint8_t clampbits = 0;
+            if (c0 < 0.f) { c0 = 0.f; clampbits |= 1; }
+            if (c1 < 0.f) { c1 = 0.f; clampbits |= 2; }
+            if (c2 < 0.f) { c2 = 0.f; clampbits |= 4; }
+            reinterpret_cast<float4*>(g.rec + i)[2] = make_float4(c0, c1, c2, 0.f);
+            g.clamped[i] = clampbits;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int vcr_sh_adam_from_rgb(int N, int sh_degree, const float* view_dirs, const float* drgb, float* features_dc,
@@ -779,6 +857,20 @@ int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, u
 int vcr_side_grid() {
     static const int g = [] { const char* e = getenv("VCR_SIDE_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
     return g;
+}
+
+int vcr_launch_sh_update_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st) {
+    const VcrShUpdate& u = *a.sh_update;
+    if (a.N == 0) return 0;
+    if (!a.shs || !a.shs_rest || a.K != SH_K) { vcr_set_error("sh_update needs the split SH storage (shs + shs_rest, K = 16)"); return 1; }
+    if (u.sh_degree < 0 || u.sh_degree > 3 || u.step < 1 || u.nviews < 0 || !u.drgb || !u.m_dc || !u.v_dc || !u.m_rest || !u.v_rest ||
+        (u.nviews == 0 ? !u.view_dirs : (!u.xyz || !u.campos_all))) { vcr_set_error("sh_update: bad arguments"); return 1; }
+    const double bc1 = 1.0 - pow((double)u.beta1, u.step), bc2 = 1.0 - pow((double)u.beta2, u.step);
+    const int nblk = (a.N + 255) / 256, grid = nblk < vcr_side_grid() ? nblk : vcr_side_grid();
+    hipLaunchKernelGGL(sh_update_colour_kernel, dim3(grid), dim3(256), 256 * SH_ROW * sizeof(float), st, a, g, u,
+                       (float)(u.lr_dc / bc1), (float)(u.lr_rest / bc1), (float)sqrt(bc2));
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int vcr_launch_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st) {

@@ -141,6 +141,7 @@ void vcr_set_error(const char* fmt, ...);
 int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key,
                           uint32_t* ids, uint32_t* vis_slots, bool colour, hipStream_t st);
 int vcr_launch_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st);
+int vcr_launch_sh_update_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st);   // a.sh_update + colour in one pass
 int vcr_side_grid();     // workgroups of a side-stream kernel (VCR_SIDE_GRID, default 512 = two per CU)
 int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const int32_t* radii,
                                    const GradRec* sgrad, const float* sgrad_sem, VcrBackwardIO& io,

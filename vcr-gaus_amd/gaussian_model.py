@@ -163,6 +163,28 @@ class FusedAdam:
                                                   sr["exp_avg_sq"].data_ptr(), float(dc["lr"]), float(rest["lr"]), self.betas[0],
                                                   self.betas[1], self.eps, int(sd["step"]), float(self.grad_scale), st))
 
+    @torch.no_grad()
+    def make_sh_update(self, drgb, sh_degree, view_dirs=None, xyz=None, campos_all=None):
+        """The same update as `step_sh_from_rgb` (view_dirs given) / `step_sh_from_rgb_views` (xyz + campos_all given),
+        packaged as a `VcrShUpdate` for `VcrRasterArgs.sh_update`: the rasterizer applies it on its colour stream fused
+        with the SH -> RGB evaluation of the next forward.  Advances the step counters.  Returns (struct, keep-alive)."""
+        groups = {g["name"]: g for g in self.param_groups}
+        dc, rest = groups["f_dc"], groups["f_rest"]
+        sd, sr = self._state(dc), self._state(rest)
+        sd["step"] += 1
+        sr["step"] += 1
+        if sd["step"] != sr["step"]:
+            raise RuntimeError("f_dc / f_rest Adam steps diverged")
+        views = 0 if view_dirs is not None else int(drgb.shape[0])
+        u = _lib.VcrShUpdate(nviews=views, sh_degree=int(sh_degree), step=int(sd["step"]), grad_scale=float(self.grad_scale),
+                             view_dirs=None if view_dirs is None else view_dirs.data_ptr(), drgb=drgb.data_ptr(),
+                             xyz=None if xyz is None else xyz.data_ptr(),
+                             campos_all=None if campos_all is None else campos_all.data_ptr(),
+                             m_dc=sd["exp_avg"].data_ptr(), v_dc=sd["exp_avg_sq"].data_ptr(), m_rest=sr["exp_avg"].data_ptr(),
+                             v_rest=sr["exp_avg_sq"].data_ptr(), lr_dc=float(dc["lr"]), lr_rest=float(rest["lr"]),
+                             beta1=self.betas[0], beta2=self.betas[1], eps=self.eps)
+        return u, (drgb, view_dirs, xyz, campos_all, sd["exp_avg"], sd["exp_avg_sq"], sr["exp_avg"], sr["exp_avg_sq"])
+
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
             for p in g["params"]:

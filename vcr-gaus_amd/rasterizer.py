@@ -72,22 +72,23 @@ SH_GRAD_MODE = "full"   # "rgb": backward skips the SH gradients and leaves dL/d
 last_drgb = {}          # "drgb" [N,3] and "dirs" [N,3] (unit view directions) of the most recent "rgb"-mode backward
 COLOUR_STREAM = None    # torch.cuda.Stream: f_count = 0 forwards evaluate SH -> RGB there (VcrRasterArgs.colour_stream)
 COLOUR_HOOK = None      # callable(): enqueue caller work on COLOUR_STREAM ahead of the colour evaluation (colour_stream_hook)
+COLOUR_SH_UPDATE = None  # callable() -> (_lib.VcrShUpdate, keep-alive) or None: SH Adam step fused into the colour evaluation
 
 
 import contextlib
 
 
 @contextlib.contextmanager
-def modes(sh_grad="full", colour_stream=None, colour_hook=None):
-    """Scoped setting of SH_GRAD_MODE / COLOUR_STREAM / COLOUR_HOOK for the forwards issued inside the block (the backward
-    of such a forward keeps the mode it was recorded with)."""
-    global SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK
-    old = (SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK)
-    SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK = sh_grad, colour_stream, colour_hook
+def modes(sh_grad="full", colour_stream=None, colour_hook=None, colour_sh_update=None):
+    """Scoped setting of SH_GRAD_MODE / COLOUR_STREAM / COLOUR_HOOK / COLOUR_SH_UPDATE for the forwards issued inside the
+    block (the backward of such a forward keeps the mode it was recorded with)."""
+    global SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE
+    old = (SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE)
+    SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE = sh_grad, colour_stream, colour_hook, colour_sh_update
     try:
         yield
     finally:
-        SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK = old
+        SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE = old
 
 
 NUM_DIST = 0      # trailing channels, the fork's compile-time `NUM_DIST` (README.md:155): 0, 1 = distortion, 2 = sum w d, sum w d^2
@@ -119,9 +120,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                                semantics_precomp=_ptr(t["sem"]), opacities=_ptr(t["opac"]), scales=_ptr(t["scales"]),
                                rotations=_ptr(t["rots"]), cov3D_precomp=_ptr(t["cov"]), dirs=_ptr(t["dirs"]))
         fc = int(rs.f_count)
-        hook = None
+        hook = upd = None
         if COLOUR_STREAM is not None and fc == 0 and t["shs"] is not None:
             a.colour_stream = COLOUR_STREAM.cuda_stream
+            if COLOUR_SH_UPDATE is not None and t["shs_rest"] is not None and N > 0:
+                upd = COLOUR_SH_UPDATE()                          # (struct, tensors kept alive until the call returns)
+                if upd is not None:
+                    a.sh_update = _ct.addressof(upd[0])
             if COLOUR_HOOK is not None:
                 fn = COLOUR_HOOK
                 hook = _lib.HOOK_FN(lambda _user: fn())            # kept alive until the forward call returns

@@ -86,6 +86,25 @@ class Trainer:
         vdirs.record_stream(self.side)
         self.model.optimizer.step_sh_from_rgb(drgb, vdirs, deg, stream=self.side)
 
+    def _pending_sh_update(self):
+        """Provider for the rasterizer's `COLOUR_SH_UPDATE`: hands the deferred SH update to the forward call, which applies
+        it on the second stream fused with the SH -> RGB evaluation (one pass over the coefficients instead of two)."""
+        if self._pending_sh is None:
+            return None
+        pend, self._pending_sh = self._pending_sh, None
+        opt = self.model.optimizer
+        if pend[0] == "views":
+            _, gather, drgb_all, xyz0, campos_all, deg = pend
+            with torch.cuda.stream(self.side):
+                gather.wait()            # the SIDE stream waits for the collective
+            for t in (drgb_all, xyz0, campos_all):
+                t.record_stream(self.side)
+            return opt.make_sh_update(drgb_all, deg, xyz=xyz0, campos_all=campos_all)
+        drgb, vdirs, deg = pend
+        drgb.record_stream(self.side)
+        vdirs.record_stream(self.side)
+        return opt.make_sh_update(drgb, deg, view_dirs=vdirs)
+
     def join_side(self):
         """Apply a still-pending SH update and make the current stream wait for the side stream: call before anything
         that reads or replaces the SH coefficients outside `train_step`'s render (evaluation renders, saving, surgery)."""
@@ -306,8 +325,10 @@ class Trainer:
         self.factorised_sh = self._factorised_base or overlap
         if not overlap and self._pending_sh is not None:
             self.join_side()
+        fuse = overlap and not os.environ.get("VCR_NO_FUSED_SH_COLOUR")
         with rasterizer.modes("rgb" if self.factorised_sh else "full", self.side if overlap else None,
-                              self._launch_pending_sh if overlap else None):
+                              self._launch_pending_sh if (overlap and not fuse) else None,
+                              self._pending_sh_update if fuse else None):
             data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True, geometry=not fused)
         if self._pending_sh is not None:         # the render did not go through the two-stream path (e.g. no Gaussians)
             self.join_side()
