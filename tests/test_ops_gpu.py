@@ -523,3 +523,52 @@ def test_fused_normal_losses_match_the_modular_operators(device, active):
     assert float((dd - ref_dd).abs().max()) <= 1e-4 * float(ref_dd.abs().max()) + 1e-9
     assert float((dn - ref_dn).abs().max()) <= 1e-4 * float(ref_dn.abs().max()) + 1e-9
     assert float(dn4[3].abs().max()) == 0.0          # the alpha plane behind the normal planes is zeroed
+
+
+@pytest.mark.parametrize("views", [0, 3])
+def test_fused_sh_update_and_colour_equals_separate_steps(device, views):
+    """VcrRasterArgs.sh_update (SH Adam step fused into the colour evaluation on the colour stream; single-view and
+    data-parallel multi-view form) == the stand-alone update kernel followed by an ordinary render."""
+    from vcr_gaus_amd import rasterizer, synthetic
+    from vcr_gaus_amd.config import make_config
+    from vcr_gaus_amd.gaussian_model import GaussianModel
+    from vcr_gaus_amd.gaussian_renderer import render
+    from vcr_gaus_amd.graphics_utils import get_all_px_dir
+    raw = synthetic.make_gaussians(12000, seed=21)
+    cams = synthetic.make_cameras(3, 128, 96, 110.0, device=device)
+    cfg = make_config("tnt")
+    dirs = get_all_px_dir(cams[0].intr, 96, 128)
+    bg = torch.zeros(3, device=device)
+    g = torch.Generator().manual_seed(5)
+    n = 12000
+    drgb = (torch.randn(max(views, 1), n, 3, generator=g) * 0.05).to(device).contiguous()
+    campos_all = torch.stack([c.camera_center for c in cams]).float().to(device).contiguous()
+    results = []
+    for fused in (False, True):
+        m = GaussianModel(cfg.model)
+        m.create_from_params(raw, spatial_lr_scale=1.0, device=device)
+        m.active_sh_degree = 3
+        m.training_setup(cfg.optim)
+        opt = m.optimizer
+        opt.grad_scale = 1.0 / max(views, 1)
+        xyz0 = m._xyz.detach().clone()
+        vdirs = torch.nn.functional.normalize(xyz0 - campos_all[0], dim=1).contiguous()
+        side = torch.cuda.Stream(device=device)
+        if fused:
+            provider = (lambda: opt.make_sh_update(drgb, 3, xyz=xyz0, campos_all=campos_all)) if views else \
+                (lambda: opt.make_sh_update(drgb[0], 3, view_dirs=vdirs))
+            with torch.no_grad(), rasterizer.modes("full", side, None, provider):
+                out = render(cams[1], m, cfg, bg, dirs=dirs)["render_out"]
+        else:
+            if views:
+                opt.step_sh_from_rgb_views(drgb, xyz0, campos_all, 3)
+            else:
+                opt.step_sh_from_rgb(drgb[0], vdirs, 3)
+            with torch.no_grad():
+                out = render(cams[1], m, cfg, bg, dirs=dirs)["render_out"]
+        torch.cuda.synchronize()
+        results.append((out.clone(), m._features_dc.detach().clone(), m._features_rest.detach().clone(),
+                        opt.state["f_rest"]["exp_avg"].clone(), opt.state["f_dc"]["exp_avg_sq"].clone()))
+        assert opt.state["f_dc"]["step"] == 1 and opt.state["f_rest"]["step"] == 1
+    for a, b in zip(*results):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), float((a - b).abs().max())
