@@ -572,3 +572,23 @@ def test_fused_sh_update_and_colour_equals_separate_steps(device, views):
         assert opt.state["f_dc"]["step"] == 1 and opt.state["f_rest"]["step"] == 1
     for a, b in zip(*results):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), float((a - b).abs().max())
+
+
+def test_bench_priming_restores_the_workload(device):
+    """BenchTrainer.prime() runs real training steps (allocator sizes, host warm-up) and must hand back the model,
+    optimizer and trainer exactly as specified, so the timed steps measure the named workload."""
+    from vcr_gaus_amd import synthetic
+    from vcr_gaus_amd.trainer import BenchTrainer
+    raw = synthetic.make_gaussians(5000, seed=31)
+    cams = synthetic.make_cameras(3, 96, 64, 90.0, device=device)
+    bt = BenchTrainer(raw, cams, device)
+    m, tr = bt.tr.model, bt.tr
+    before = {k: getattr(m, k).detach().clone() for k in ["_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"]}
+    it0, order0, rng0 = tr.current_iteration, list(tr.view_order), tr.rng.getstate()
+    bt.prime(min_seconds=0.05)
+    assert tr.current_iteration == it0 and tr.view_order == order0 and tr.rng.getstate() == rng0
+    assert m.optimizer.state == {} and tr._pending_sh is None
+    for k, v in before.items():
+        assert torch.equal(getattr(m, k).detach(), v), k
+    bt.step(0)                                      # and the trainer still steps
+    assert float(tr.losses["total"]) == float(tr.losses["total"])
