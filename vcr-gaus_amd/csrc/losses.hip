@@ -727,25 +727,24 @@ __global__ void weighted_total_kernel(int K, const float* __restrict__ res, cons
 // One launch for what the loss node needs at the end of its forward: fold the slots of the L1+SSIM sums (2), the
 // scale-regulariser sums (3, optional) and the normal-loss sums (9, optional) in the fixed order of the individual
 // finalize kernels, write the six loss values and their weighted total.
-__global__ void finalize_losses_kernel(double* __restrict__ sums2, double inv_count, double* __restrict__ sums3,
-                                       double* __restrict__ sums9, float* __restrict__ res6, const float* __restrict__ w,
-                                       int sub_index, float* __restrict__ total) {
+__global__ void __launch_bounds__(256) finalize_losses_kernel(double* __restrict__ sums2, double inv_count,
+                                                              double* __restrict__ sums3, double* __restrict__ sums9,
+                                                              float* __restrict__ res6, const float* __restrict__ w,
+                                                              int sub_index, float* __restrict__ total) {
     __shared__ double s_t[14];
-    double* bases[3] = {sums2, sums3, sums9};
-    const int Ks[3] = {2, 3, 9};
-    int off = 0;
-    for (int b = 0; b < 3; ++b) {
-        const int K = Ks[b];
-        for (int k = 0; k < K; ++k) {
-            double t = 0.0;
-            if (bases[b]) {
-                for (int s = threadIdx.x; s < VCR_NSLOT; s += 64) t += bases[b][K + (size_t)s * K + k];
-                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-                if (threadIdx.x == 0) bases[b][k] = t;
-            }
-            if (threadIdx.x == 0) s_t[off + k] = t;
+    // 14 sums (2 + 3 + 9), each folded by ONE wave in the fixed order of the individual finalize kernels (lane l takes
+    // slots l, l+64, l+128, l+192, then a fixed butterfly); the four waves of the block take them round-robin
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int e = wv; e < 14; e += 4) {
+        double* base = e < 2 ? sums2 : (e < 5 ? sums3 : sums9);
+        const int K = e < 2 ? 2 : (e < 5 ? 3 : 9), k = e < 2 ? e : (e < 5 ? e - 2 : e - 5);
+        double t = 0.0;
+        if (base) {
+            for (int s = lane; s < VCR_NSLOT; s += 64) t += base[K + (size_t)s * K + k];
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+            if (lane == 0) base[k] = t;
         }
-        off += K;
+        if (lane == 0) s_t[e] = t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -762,7 +761,7 @@ __global__ void finalize_losses_kernel(double* __restrict__ sums2, double inv_co
 extern "C" int vcr_finalize_losses(int H, int W, double* sums2, double* sums3, double* sums9, float* res6, const float* w,
                                    int sub_index, float* total, void* stream) {
     if (!sums2 || !res6 || !w || !total) { vcr_set_error("vcr_finalize_losses: bad arguments"); return 1; }
-    hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums2, 1.0 / (3.0 * (double)H * (double)W),
+    hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums2, 1.0 / (3.0 * (double)H * (double)W),
                        sums3, sums9, res6, w, sub_index, total);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
