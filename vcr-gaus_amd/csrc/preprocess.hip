@@ -139,6 +139,9 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
 // streamed with fully coalesced 16-byte loads into LDS (row stride 49 dwords -> conflict-free per-lane rows)
 // and each lane then reads its own row.  Works for the combined [N,16,3] layout and for the reference's split
 // storage (_features_dc [N,1,3] + _features_rest [N,15,3]) so no torch.cat is needed.
+#ifndef VCR_SIDE_NT
+#define VCR_SIDE_NT true
+#endif
 #define SH_ROW 49
 #define SH_K 16
 
@@ -592,8 +595,18 @@ __global__ void __launch_bounds__(256) sh_grad_from_rgb_kernel(int N, int deg, i
 // ---- SH Adam with the gradient formed on the fly (single-view training) ------------------------------------------------
 // grad[g][k][c] = basis_k(view_dirs[g]) * drgb[g][c]; every lane builds its Gaussian's 48-value row in LDS, then the
 // block streams params / moments with coalesced 16-byte accesses (same row mapping as coop_copy_*) and applies Adam.
+typedef float vf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+    const vf4 v = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float4* p, const float v[4]) {
+    __builtin_nontemporal_store(vf4{v[0], v[1], v[2], v[3]}, reinterpret_cast<vf4*>(p));
+}
+
 // KEEP: the updated parameter replaces the gradient in the LDS row (for the fused colour evaluation)
-template <bool KEEP = false>
+// NT: streaming (non-temporal) loads / stores of p, m, v
+template <bool KEEP = false, bool NT = false>
 __device__ __forceinline__ void coop_adam(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, int total, int per,
                                           int off, float* s, float lr_bc1, float b1, float b2, float eps, float bc2_sqrt) {
     const int n4 = total >> 2;                              // rows start 16-byte aligned: 256*3 and 256*45 floats per block
@@ -605,7 +618,10 @@ __device__ __forceinline__ void coop_adam(float* __restrict__ p, float* __restri
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e4 = e0 + u * 256;
-            if (e4 < n4) { pp[u] = p4[e4]; mm[u] = m4[e4]; vv[u] = v4[e4]; }
+            if (e4 < n4) {
+                if (NT) { pp[u] = nt_load4(p4 + e4); mm[u] = nt_load4(m4 + e4); vv[u] = nt_load4(v4 + e4); }
+                else { pp[u] = p4[e4]; mm[u] = m4[e4]; vv[u] = v4[e4]; }
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -623,8 +639,12 @@ __device__ __forceinline__ void coop_adam(float* __restrict__ p, float* __restri
                 P[j] -= lr_bc1 * (M[j] / (sqrtf(V[j]) / bc2_sqrt + eps));
                 if (KEEP) *slot = P[j];
             }
-            p4[e4] = make_float4(P[0], P[1], P[2], P[3]); m4[e4] = make_float4(M[0], M[1], M[2], M[3]);
-            v4[e4] = make_float4(V[0], V[1], V[2], V[3]);
+            if (NT) {
+                nt_store4(p4 + e4, P); nt_store4(m4 + e4, M); nt_store4(v4 + e4, V);
+            } else {
+                p4[e4] = make_float4(P[0], P[1], P[2], P[3]); m4[e4] = make_float4(M[0], M[1], M[2], M[3]);
+                v4[e4] = make_float4(V[0], V[1], V[2], V[3]);
+            }
         }
     }
     for (int e = (n4 << 2) + threadIdx.x; e < total; e += 256) {
@@ -763,9 +783,9 @@ __global__ void __launch_bounds__(256) sh_update_colour_kernel(VcrRasterArgs a, 
             for (int k = 0; k < 48; ++k) row[k] = acc[k];
         }
         __syncthreads();
-        coop_adam<true>(p_dc + (size_t)blk_base * 3, u.m_dc + (size_t)blk_base * 3, u.v_dc + (size_t)blk_base * 3, blk_cnt * 3, 3, 0,
+        coop_adam<true, VCR_SIDE_NT>(p_dc + (size_t)blk_base * 3, u.m_dc + (size_t)blk_base * 3, u.v_dc + (size_t)blk_base * 3, blk_cnt * 3, 3, 0,
                         s_sh, lr_dc_bc1, u.beta1, u.beta2, u.eps, bc2_sqrt);
-        coop_adam<true>(p_rest + (size_t)blk_base * 45, u.m_rest + (size_t)blk_base * 45, u.v_rest + (size_t)blk_base * 45,
+        coop_adam<true, VCR_SIDE_NT>(p_rest + (size_t)blk_base * 45, u.m_rest + (size_t)blk_base * 45, u.v_rest + (size_t)blk_base * 45,
                         blk_cnt * 45, 45, 3, s_sh, lr_rest_bc1, u.beta1, u.beta2, u.eps, bc2_sqrt);
         __syncthreads();
         if (i < N && g.tiles[i] != 0) {            // colour of the visible Gaussians from the freshly updated rows
