@@ -46,6 +46,37 @@ struct StageTimer {
 // digit totals of the two radix sorts
 #define VCR_CTR_WORDS (2 * VCR_VIS_SLOTS + 2 * VCR_SORT_TOTALS_WORDS)
 struct Readback { uint32_t V[VCR_VIS_SLOTS]; uint32_t R[VCR_VIS_SLOTS]; };
+// what the host polls: totals + a sequence number published by the device AFTER the totals (system-scope fence)
+struct Published { unsigned long long R; uint32_t V; volatile uint32_t seq; };
+
+Published* pinned_published() {
+    static thread_local Published* p = nullptr;
+    if (!p) {
+        if (hipHostMalloc((void**)&p, sizeof(Published), hipHostMallocDefault) != hipSuccess) { p = nullptr; return nullptr; }
+        p->R = 0; p->V = 0; p->seq = 0;
+    }
+    return p;
+}
+
+// One block: fold the counter slots and publish the totals to pinned host memory.  The host spins on `seq` instead of
+// sleeping in hipEventSynchronize, whose wake-up latency (interrupt path) can exceed the ~0.15 ms of sort work that is
+// queued behind this kernel to cover it.
+__global__ void __launch_bounds__(256) publish_counts_kernel(const uint32_t* __restrict__ slots, Published* host, uint32_t seq) {
+    __shared__ unsigned long long s_r[4];
+    __shared__ uint32_t s_v[4];
+    unsigned long long r = 0; uint32_t v = 0;
+    for (int k = threadIdx.x; k < VCR_VIS_SLOTS; k += 256) { v += slots[k]; r += slots[VCR_VIS_SLOTS + k]; }
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o); r += __shfl_xor(r, o); }
+    if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = v; s_r[threadIdx.x >> 6] = r; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        host->R = s_r[0] + s_r[1] + s_r[2] + s_r[3];
+        host->V = s_v[0] + s_v[1] + s_v[2] + s_v[3];
+        __threadfence_system();
+        host->seq = seq;
+    }
+}
+
 
 Readback* pinned_readback() {
     static thread_local Readback* p = nullptr;
@@ -204,9 +235,12 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         // R and V go back to the host now; the depth sort and the offsets scan do not need them and keep the GPU busy
         // while the host wakes up, sizes the instance buffers and enqueues the rest
         Readback* rb = pinned_readback();
+        Published* pub = pinned_published();
         hipEvent_t ev = readback_event();
-        if (!rb || !ev) { vcr_set_error("hipHostMalloc / hipEventCreate for the readback failed"); return 1; }
-        VCR_HIP_CHECK(hipMemcpyAsync(rb, vis_counter, sizeof(Readback), hipMemcpyDeviceToHost, st));
+        if (!rb || !pub || !ev) { vcr_set_error("hipHostMalloc / hipEventCreate for the readback failed"); return 1; }
+        static thread_local uint32_t seq_counter = 0;
+        const uint32_t seq = ++seq_counter ? seq_counter : ++seq_counter;      // never 0
+        hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(256), 0, st, vis_counter, pub, seq);
         VCR_HIP_CHECK(hipEventRecord(ev, st));
         {
             StageTimer tm(ST_DEPTHSORT, st);
@@ -214,10 +248,17 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
                                         st))
                 return 1;
         }
-        VCR_HIP_CHECK(hipEventSynchronize(ev));
-        uint32_t vsum = 0;
-        for (int k = 0; k < VCR_VIS_SLOTS; ++k) { vsum += rb->V[k]; R += rb->R[k]; }
-        out->num_visible = (int32_t)vsum;
+        {   // spin on the published sequence number; after ~2 s fall back to the event (and report errors through it)
+            unsigned long long spins = 0;
+            while (pub->seq != seq) {
+                __builtin_ia32_pause();
+                if (++spins > (1ull << 30)) { VCR_HIP_CHECK(hipEventSynchronize(ev)); break; }
+            }
+            if (pub->seq != seq) { vcr_set_error("device did not publish the instance count"); return 1; }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
+        R = (int64_t)pub->R;
+        out->num_visible = (int32_t)pub->V;
         if (R >= (1ll << 32)) { vcr_set_error("more than 2^32 tile instances"); return 1; }
 
         void* bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(R, T));
