@@ -170,3 +170,138 @@ def test_factorised_sh_exchange_two_ranks(tmp_path):
         ref = ref + _basis_outer(m._xyz.detach(), _Cam(v).camera_center, drgb, 3)
     assert torch.allclose(got["dc"], ref[:, :1], atol=1e-6) and torch.allclose(got["rest"], ref[:, 1:], atol=1e-6)
     assert torch.allclose(got["gx"], gx)
+
+
+# ---- the two-stream ("deferred SH") data-parallel branch: `Trainer._exchange_grads(overlap=True, surgery=False)` ----------
+class _ShStubOptim(StubOptim):
+    """Records what the deferred SH update receives; applies a plain SGD step so that replicas can be compared."""
+
+    def __init__(self, params):
+        super().__init__(params)
+        self.state = {}
+        self.sh_calls = []
+
+    def _state(self, g):
+        return self.state.setdefault(g["name"], dict(step=0))
+
+    def step_sh_from_rgb_views(self, drgb_all, xyz, campos_all, deg, stream=None):
+        g = sum(_basis_outer(xyz, campos_all[v], drgb_all[v], deg) for v in range(drgb_all.shape[0])) * self.grad_scale
+        self.sh_calls.append(g)
+        by = {q["name"]: q["params"][0] for q in self.param_groups}
+        with torch.no_grad():
+            by["f_dc"].sub_(0.1 * g[:, :1])
+            by["f_rest"].sub_(0.1 * g[:, 1:])
+
+    def step(self):
+        with torch.no_grad():
+            for g in self.param_groups:
+                p = g["params"][0]
+                if p.grad is not None:
+                    p.sub_(0.1 * self.grad_scale * p.grad)
+
+
+def _sh_model():
+    m = StubModel()
+    m._features_dc = torch.nn.Parameter(torch.zeros(N, 1, 3))
+    m._features_rest = torch.nn.Parameter(torch.zeros(N, 15, 3))
+    m.active_sh_degree = 3
+    m.optimizer = _ShStubOptim([m._xyz, m._opacity])
+    m.optimizer.param_groups += [{"params": [m._features_dc], "lr": 0.1, "name": "f_dc"},
+                                 {"params": [m._features_rest], "lr": 0.1, "name": "f_rest"}]
+    return m
+
+
+def deferred_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vcr_gaus_amd import rasterizer
+    m = _sh_model()
+    tr = Trainer(make_config("tnt"), m, [_Cam(i) for i in range(8)], 1.0, torch.device("cpu"), world=world, rank=rank, seed=3)
+    hist = []
+    for step in range(3):
+        cams = tr._next_cameras()
+        view_data(cams[rank], m)                                   # geometry gradients of THIS rank's view
+        gen = torch.Generator().manual_seed(500 + cams[rank])
+        rasterizer.last_drgb["drgb"] = torch.randn(N, 3, generator=gen)
+        rasterizer.last_drgb["dirs"] = torch.zeros(N, 3)
+        xyz_rendered = m._xyz.detach().clone()
+        tr._exchange_grads(True, False)                              # two-stream form, no surgery
+        assert tr._pending_sh is not None and tr._pending_sh[0] == "views" and not rasterizer.last_drgb
+        m.optimizer.step()                                           # geometry Adam runs BEFORE the deferred SH update ...
+        for g in m.optimizer.param_groups:
+            g["params"][0].grad = None
+        tr.join_side()                                               # ... which must still see the means the views were rendered with
+        hist.append((cams, xyz_rendered))
+    torch.save(dict(hist=hist, xyz=m._xyz.detach(), op=m._opacity.detach(), dc=m._features_dc.detach(),
+                    rest=m._features_rest.detach(), scale=m.optimizer.grad_scale), out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def test_deferred_sh_exchange_two_ranks_matches_serial(tmp_path):
+    """with world > 1 the two-stream branch must all-reduce the geometry bucket and queue the all-view SH
+    update; replicas stay identical and equal the single-process accumulation over the same two cameras per step."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "def.pt")
+    mp.spawn(deferred_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    for k in ("xyz", "op", "dc", "rest"):
+        assert torch.equal(r0[k], r1[k]), f"replicas diverged in {k}"
+    assert r0["scale"] == 0.5
+    m = _sh_model()                                                  # serial reference: accumulate both views by hand
+    for cams, _ in r0["hist"]:
+        gx = go = gsh = 0
+        for v in cams:
+            view_data(v, m)
+            gx, go = gx + m._xyz.grad, go + m._opacity.grad
+            drgb = torch.randn(N, 3, generator=torch.Generator().manual_seed(500 + v))
+            gsh = gsh + _basis_outer(m._xyz.detach(), _Cam(v).camera_center, drgb, 3)
+        with torch.no_grad():
+            m._features_dc.sub_(0.1 * 0.5 * gsh[:, :1]); m._features_rest.sub_(0.1 * 0.5 * gsh[:, 1:])
+            m._xyz.sub_(0.1 * 0.5 * gx); m._opacity.sub_(0.1 * 0.5 * go)
+    assert torch.allclose(r0["xyz"], m._xyz, atol=1e-6) and torch.allclose(r0["op"], m._opacity, atol=1e-6)
+    assert torch.allclose(r0["dc"], m._features_dc, atol=1e-6) and torch.allclose(r0["rest"], m._features_rest, atol=1e-6)
+    assert float(r0["dc"].abs().max()) > 0
+
+
+def visi_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vcr_gaus_amd import trainer as T
+    tr = make_trainer(world, rank)
+    tr.model.get_inside_gaus_normalized = lambda: (torch.arange(N) % 5 != 0, None)
+    tr.model._xyz = torch.nn.Parameter(torch.zeros(N, 3))
+    seen = []
+
+    def fake_visi(cam, model, pipe, bg):
+        seen.append(cam)
+        g = torch.Generator().manual_seed(900 + cam)
+        return {"countlist": (torch.rand(N, generator=g) > 0.7).int()}
+
+    def fake_count(cam, model, pipe, bg):
+        g = torch.Generator().manual_seed(700 + cam)
+        return {"gaussians_count": torch.randint(0, 9, (N,), generator=g, dtype=torch.int32),
+                "important_score": torch.rand(N, generator=g)}
+
+    T.visi_acc_render, T.count_render = fake_visi, fake_count
+    cams = list(range(7))                                            # odd count: ranks get 4 / 3 cameras
+    mask = tr.visibility_mask(cams)
+    cnt, imp = tr.importance_scores(cams)
+    torch.save(dict(mask=mask, cnt=cnt, imp=imp, seen=seen), out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def test_visibility_and_importance_passes_shard_cameras(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "vis.pt")
+    mp.spawn(visi_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert sorted(r0["seen"] + r1["seen"]) == list(range(7)) and not set(r0["seen"]) & set(r1["seen"])
+    count = sum((torch.rand(N, generator=torch.Generator().manual_seed(900 + c)) > 0.7).int() for c in range(7))
+    want = (count > 0) & (torch.arange(N) % 5 != 0)
+    assert torch.equal(r0["mask"], want) and torch.equal(r1["mask"], want)
+    cnt = imp = 0
+    for c in range(7):
+        g = torch.Generator().manual_seed(700 + c)
+        cnt = cnt + torch.randint(0, 9, (N,), generator=g, dtype=torch.int32)
+        imp = imp + torch.rand(N, generator=g)
+    assert torch.equal(r0["cnt"], cnt) and torch.allclose(r0["imp"], imp, atol=1e-5) and torch.equal(r1["cnt"], cnt)

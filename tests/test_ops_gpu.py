@@ -296,6 +296,8 @@ def test_rccl_exchange_path_single_rank_group(device):
             tr.force_collectives = coll
             for _ in range(8):
                 tr.train_step()
+            assert tr.last_exchange == {(False, False): "none", (True, False): "factorised",
+                                        (True, True): "factorised-deferred"}[(coll, overlap)]
             tr.join_side()
             torch.cuda.synchronize()
             finals.append({k: getattr(tr.model, k).detach().clone() for k in ["_features_rest", "_xyz", "_scaling"]})

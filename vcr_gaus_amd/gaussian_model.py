@@ -338,6 +338,12 @@ class GaussianModel:
                "obj_dc": training_args.feature_lr}
         groups = [{"params": [getattr(self, attr)], "lr": lrs[name], "name": name}
                   for name, attr in self._param_table().items()]
+        if self.enable_semantic and self.classifier is not None:
+            # `scene/gaussian_model.py:254`: the 1x1-conv classifier trains with Adam at cls_lr.  Not per-Gaussian, so the
+            # groups are flagged "aux": densify / prune surgery skips them (`:428,445,483`); the DP bucket includes them.
+            for pn, prm in self.classifier.named_parameters():
+                groups.append({"params": [prm], "lr": getattr(training_args, "cls_lr", 5e-4), "name": "classifier." + pn,
+                               "aux": True})
         self.optimizer = FusedAdam(groups, eps=1e-15)
         self.xyz_scheduler_args = get_expon_lr_func(
             lr_init=training_args.position_lr_init * self.spatial_lr_scale,
@@ -373,6 +379,8 @@ class GaussianModel:
     def _rebind(self, fn_param, fn_state):
         out = {}
         for g in self.optimizer.param_groups:
+            if g.get("aux"):
+                continue
             p = g["params"][0]
             newp = torch.nn.Parameter(fn_param(g["name"], p.detach()).contiguous().requires_grad_(True))
             st = self.optimizer.state.get(g["name"])

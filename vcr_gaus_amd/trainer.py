@@ -75,16 +75,25 @@ class Trainer:
         pend, self._pending_sh = self._pending_sh, None
         if pend[0] == "views":           # data parallel: (tag, all-gather work, drgb_all, xyz snapshot, campos_all, degree)
             _, gather, drgb_all, xyz0, campos_all, deg = pend
-            with torch.cuda.stream(self.side):
-                gather.wait()            # the SIDE stream waits for the collective
-            for t in (drgb_all, xyz0, campos_all):
-                t.record_stream(self.side)
+            self._side_wait(gather, (drgb_all, xyz0, campos_all))
             self.model.optimizer.step_sh_from_rgb_views(drgb_all, xyz0, campos_all, deg, stream=self.side)
             return
         drgb, vdirs, deg = pend
-        drgb.record_stream(self.side)
-        vdirs.record_stream(self.side)
+        self._side_wait(None, (drgb, vdirs))
         self.model.optimizer.step_sh_from_rgb(drgb, vdirs, deg, stream=self.side)
+
+    def _side_wait(self, work, tensors):
+        """Make the SIDE stream (not the main one) wait for an async collective and keep `tensors` alive for it.
+        Without a side stream (CPU / gloo tests) the wait is a plain blocking wait."""
+        if self.side is None:
+            if work is not None:
+                work.wait()
+            return
+        if work is not None:
+            with torch.cuda.stream(self.side):
+                work.wait()
+        for t in tensors:
+            t.record_stream(self.side)
 
     def _pending_sh_update(self):
         """Provider for the rasterizer's `COLOUR_SH_UPDATE`: hands the deferred SH update to the forward call, which applies
@@ -95,23 +104,20 @@ class Trainer:
         opt = self.model.optimizer
         if pend[0] == "views":
             _, gather, drgb_all, xyz0, campos_all, deg = pend
-            with torch.cuda.stream(self.side):
-                gather.wait()            # the SIDE stream waits for the collective
-            for t in (drgb_all, xyz0, campos_all):
-                t.record_stream(self.side)
+            self._side_wait(gather, (drgb_all, xyz0, campos_all))
             return opt.make_sh_update(drgb_all, deg, xyz=xyz0, campos_all=campos_all)
         drgb, vdirs, deg = pend
-        drgb.record_stream(self.side)
-        vdirs.record_stream(self.side)
+        self._side_wait(None, (drgb, vdirs))
         return opt.make_sh_update(drgb, deg, view_dirs=vdirs)
 
     def join_side(self):
         """Apply a still-pending SH update and make the current stream wait for the side stream: call before anything
         that reads or replaces the SH coefficients outside `train_step`'s render (evaluation renders, saving, surgery)."""
-        if self.side is not None:
-            if self._pending_sh is not None:
+        if self._pending_sh is not None:
+            if self.side is not None:
                 self.side.wait_stream(torch.cuda.current_stream(self.device))
-                self._launch_pending_sh()
+            self._launch_pending_sh()
+        if self.side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
 
     # ---- camera batch: `world` cameras per step, rank r takes the r-th (`trainer.py:326-328`) -------
@@ -185,6 +191,7 @@ class Trainer:
         if self.world == 1 and not getattr(self, "force_collectives", False):   # single-rank factorised path: no collectives
             from . import rasterizer
             drgb = rasterizer.last_drgb.pop("drgb").contiguous()
+            rasterizer.last_drgb.pop("dirs", None)
             campos = self.cameras[self._picked[0]].camera_center.float().reshape(1, 3).contiguous()
             self.model._features_dc.grad, self.model._features_rest.grad = self._sh_grads_from_rgb(drgb[None].contiguous(), campos)
             self.model.optimizer.grad_scale = 1.0
@@ -229,12 +236,37 @@ class Trainer:
                 self._pending_sh = ("views", gather, drgb_all, self.model._xyz.detach().clone(), campos_all,
                                     int(self.model.active_sh_degree))
             else:
+                rasterizer.last_drgb.pop("dirs", None)
                 gather.wait()
                 self.model._features_dc.grad, self.model._features_rest.grad = self._sh_grads_from_rgb(drgb_all, campos_all)
                 if early_feature_step:
                     self.model.optimizer.step(only={"f_dc", "f_rest"})
         for w in works:
             w.wait()
+
+    def _exchange_grads(self, overlap, surgery):
+        """What happens between backward and the optimizer step.  Two-stream form (`overlap`, no surgery this iteration):
+        single GPU -> the SH update is only stashed (applied from the next forward's colour stream); data parallel -> the
+        geometry bucket is all-reduced now, dL/drgb is all-gathered asynchronously and the SH update of ALL views is left
+        pending for the side stream (`defer_sh`).  Otherwise: the serial exchange."""
+        m = self.model
+        if overlap and not surgery:
+            from . import rasterizer
+            for g in m.optimizer.param_groups:         # moments are created (zero-filled) on THIS stream, ahead of
+                if g["name"] in ("f_dc", "f_rest"):    # the projection the side stream will wait for
+                    m.optimizer._state(g)
+            if self.world > 1 or getattr(self, "force_collectives", False):
+                self._allreduce_grads(defer_sh=True)
+                self.last_exchange = "factorised-deferred"      # bucket all-reduce now, all-view SH update on the side stream
+            else:
+                self.last_exchange = "none"
+                m.optimizer.grad_scale = 1.0
+                self._pending_sh = (rasterizer.last_drgb.pop("drgb"), rasterizer.last_drgb.pop("dirs"), int(m.active_sh_degree))
+        else:
+            self.join_side()
+            self._allreduce_grads(early_feature_step=not surgery)
+            collectives = self.world > 1 or getattr(self, "force_collectives", False)
+            self.last_exchange = ("factorised" if self.factorised_sh else "dense") if collectives else "none"
 
     def _sh_grads_from_rgb(self, drgb_all, campos_all):
         """sum over the step's views of basis_k(dir_view) x dL/drgb_view (HIP kernel vcr_sh_grad_from_rgb)."""
@@ -340,25 +372,27 @@ class Trainer:
                        and it % cfg.optim.densification_interval == 0) \
                 or it % cfg.optim.opacity_reset_interval == 0 or it in cfg.optim.prune.iterations \
                 or (cfg.model.white_background and it == cfg.optim.densify_from_iter)
-            if overlap and not surgery:
-                from . import rasterizer
-                for g in m.optimizer.param_groups:         # moments are created (zero-filled) on THIS stream, ahead of
-                    if g["name"] in ("f_dc", "f_rest"):    # the projection the side stream will wait for
-                        m.optimizer._state(g)
-                m.optimizer.grad_scale = 1.0
-                self._pending_sh = (rasterizer.last_drgb.pop("drgb"), rasterizer.last_drgb.pop("dirs"), int(m.active_sh_degree))
-            else:
-                self.join_side()
-                self._allreduce_grads(early_feature_step=not surgery)
+            self._exchange_grads(overlap, surgery)
             if it < cfg.optim.densify_until_iter:
                 self._densify_stats(data)
+                if it > cfg.optim.densify_from_iter and "countlist" in data:        # `trainer.py:350-356`
+                    cl = data["countlist"]
+                    if self.world > 1:
+                        cl = cl.clone()
+                        dist.all_reduce(cl, op=dist.ReduceOp.SUM)
+                    self.visi_list = cl if self.visi_list is None else self.visi_list + cl
                 if it > cfg.optim.densify_from_iter and it % cfg.optim.densification_interval == 0:
                     size_threshold = 20 if it > cfg.optim.opacity_reset_interval else None
                     visi = None
                     dl = cfg.optim.densify_large
                     if dl.percent_dense and dl.sample_cams.num > 0:
                         visi = self.visibility_mask(self._visibility_cameras(dl.sample_cams))
+                        if self.visi_list is not None:
+                            # `trainer.py:366` writes `visi & self.visi_list > 0`; Python parses that as
+                            # `(visi & self.visi_list) > 0` (bool & int tensor promotes to int), i.e. both conditions
+                            visi = (visi & self.visi_list) > 0
                     m.densify_and_prune(cfg.optim.densify_grad_threshold, 0.005, self.extent, size_threshold, visi)
+                    self.visi_list = None
                 if it % cfg.optim.opacity_reset_interval == 0 or (cfg.model.white_background and it == cfg.optim.densify_from_iter):
                     m.reset_opacity()
             if it in cfg.optim.prune.iterations:
@@ -460,18 +494,12 @@ class BenchTrainer:
 
     def step(self, i):
         from . import rasterizer
-        try:
-            self.tr.train_step()
-        except Exception as e:                      # safety net for the multi-GPU run: fall back to the plain all-reduce
-            if not (self.tr.world > 1 and self.tr.factorised_sh and not getattr(self, "_fell_back", False)):
-                raise
-            self._fell_back = True
-            print(f"[bench] factorised SH exchange failed ({e!r}); falling back to dense all-reduce", flush=True)
-            self.tr.factorised_sh = self.tr._factorised_base = False
-            rasterizer.last_drgb.clear()
-            self.tr.model.optimizer.zero_grad(set_to_none=True)
-            self.tr.train_step()
+        self.tr.train_step()          # (no per-rank fallback: a rank that switched exchange algorithm alone would hang RCCL)
         self.last_R, self.last_V = rasterizer.last_stats.get("R", 0), rasterizer.last_stats.get("V", 0)
+
+    def exchange(self):
+        """Which gradient exchange the steps use: none (1 GPU) | factorised (all-gather dL/drgb + bucket all-reduce) | dense."""
+        return getattr(self.tr, "last_exchange", "none")
 
     def describe(self):
         w = self.tr.weights
