@@ -130,5 +130,162 @@ def misc_cases():
          lr_vals=np.array([lr(s) for s in [0, 1, 100, 15000, 30000]]))
 
 
+def misc_grad_cases():
+    """Gradients of the small image / per-Gaussian losses of `trainer.py:243-300` through the reference's functions."""
+    g = torch.Generator().manual_seed(6)
+    out = {}
+    H, W = 37, 53
+    img = torch.rand(3, H, W, generator=g)
+    dist = torch.rand(1, H, W, generator=g).requires_grad_(True)
+    ed = RN.get_edge_aware_distortion_map(img, dist).mean()            # trainer.py:295-298
+    ed.backward()
+    nrm = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1).requires_grad_(True)
+    mask = (torch.rand(H, W, 1, generator=g) > 0.25).float()
+    cv = RL.l1_loss(RL.normal2curv(nrm, mask), 0)                       # trainer.py:282-287
+    cv.backward()
+    op = torch.rand(300, 1, generator=g).requires_grad_(True)
+    en = RL.entropy_loss(op)                                             # trainer.py:247-249
+    en.backward()
+    save("g7_misc_grads.npz", img=img, dist=dist.detach(), edge_loss=ed.detach(), edge_grad=dist.grad, nrm=nrm.detach(),
+         mask=mask, curv_loss=cv.detach(), curv_grad=nrm.grad, op=op.detach(), entropy_loss=en.detach(), entropy_grad=op.grad)
+
+
+def _load_reference_gaussian_model():
+    """Import /root/reference/scene/gaussian_model.py on the CPU: stub the absent third-party modules, keep `scene/__init__`
+    (dataset readers, PIL, cv2 ...) from running, and route the hard-coded device="cuda" allocations to the CPU."""
+    import importlib.util
+    for name in ["plyfile", "simple_knn", "simple_knn._C", "pytorch3d", "pytorch3d.ops", "open3d"]:
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
+    sys.modules["simple_knn._C"].distCUDA2 = None
+    sys.modules["pytorch3d.ops"].ball_query = sys.modules["pytorch3d.ops"].knn_points = None
+    pkg = types.ModuleType("scene")
+    pkg.__path__ = [os.path.join(REF, "scene")]
+    sys.modules["scene"] = pkg
+    real_zeros = torch.zeros
+
+    def zeros(*a, **k):
+        if str(k.get("device", "")).startswith("cuda"):
+            k["device"] = "cpu"
+        return real_zeros(*a, **k)
+
+    torch.zeros = zeros
+    torch.cuda.memory_allocated = lambda *a, **k: 0
+    torch.cuda.empty_cache = lambda: None
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    spec = importlib.util.spec_from_file_location("ref_gaussian_model", os.path.join(REF, "scene", "gaussian_model.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def densify_cases():
+    """`scene/gaussian_model.py:361-364,425-671` executed by the reference's own GaussianModel on seeded inputs: the
+    state (parameters, Adam moments, densification statistics) before and after each operation."""
+    RGM = _load_reference_gaussian_model()
+    out = {}
+    N, extent = 320, 3.3
+    names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "obj_dc"]
+    attr = dict(xyz="_xyz", f_dc="_features_dc", f_rest="_features_rest", opacity="_opacity", scaling="_scaling",
+                rotation="_rotation", obj_dc="_objects_dc")
+    cfgm = types.SimpleNamespace(sh_degree=3, max_mem=22, use_decoupled_appearance=False, enable_semantic=True, ch_sem_feat=2,
+                                 num_cls=2)
+    targs = types.SimpleNamespace(percent_dense=0.01, densify_large=types.SimpleNamespace(percent_dense=2e-3),
+                                  position_lr_init=1.6e-4, position_lr_final=1.6e-6, position_lr_delay_mult=0.01,
+                                  position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05, scaling_lr=5e-3,
+                                  rotation_lr=1e-3, cls_lr=5e-4)
+
+    def fresh(seed):
+        g = torch.Generator().manual_seed(seed)
+        raw = dict(xyz=1.3 * (2 * torch.rand(N, 3, generator=g) - 1),                   # some outside the unit box
+                   f_dc=torch.randn(N, 1, 3, generator=g), f_rest=0.05 * torch.randn(N, 15, 3, generator=g),
+                   # scales straddle percent_dense * extent (0.033), large_percent_dense * extent (0.0066) and 0.1 * extent
+                   scaling=math.log(0.03) + 1.2 * torch.randn(N, 1, generator=g) + 0.5 * torch.randn(N, 3, generator=g),
+                   rotation=torch.randn(N, 4, generator=g),                                # un-normalised, as trained
+                   opacity=1.5 * torch.randn(N, 1, generator=g) - 4.0 * (torch.rand(N, 1, generator=g) > 0.8),
+                   obj_dc=torch.randn(N, 1, 2, generator=g))
+        m = RGM.GaussianModel(cfgm)
+        for k in names:
+            setattr(m, attr[k], torch.nn.Parameter(raw[k].clone().requires_grad_(True)))
+        m.max_radii2D = torch.zeros(N)
+        m.trans, m.scale, m.extent = torch.zeros(3), torch.ones(3), extent
+        m.spatial_lr_scale = 3.0
+        m.training_setup(targs)
+        for grp in m.optimizer.param_groups:        # populate Adam state with non-trivial moments
+            if grp["name"] == "classifier":
+                continue
+            p = grp["params"][0]
+            m.optimizer.state[p] = dict(step=torch.tensor(7.0), exp_avg=0.01 * torch.randn(p.shape, generator=g),
+                                        exp_avg_sq=1e-4 * torch.rand(p.shape, generator=g))
+        m.xyz_gradient_accum = 2e-3 * torch.rand(N, 1, generator=g) * (torch.rand(N, 1, generator=g) > 0.3)
+        m.denom = torch.randint(0, 4, (N, 1), generator=g).float()          # zeros -> NaN grads -> 0 (`:644-645`)
+        m.max_radii2D = 40.0 * torch.rand(N, generator=g)
+        return m, g
+
+    def dump(tag, m):
+        for grp in m.optimizer.param_groups:
+            if grp["name"] == "classifier":
+                continue
+            p = grp["params"][0]
+            out[f"{tag}_{grp['name']}"] = p.detach().clone()
+            st = m.optimizer.state.get(p)
+            if st is not None:
+                out[f"{tag}_{grp['name']}_m"], out[f"{tag}_{grp['name']}_v"] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+        out[f"{tag}_accum"], out[f"{tag}_denom"], out[f"{tag}_radii"] = m.xyz_gradient_accum.clone(), m.denom.clone(), m.max_radii2D.clone()
+
+    # (a) add_densification_stats (+ the max_radii2D update of trainer.py:345)
+    m, g = fresh(11)
+    dump("stats_in", m)
+    vp = torch.zeros(N, 3)
+    vp.grad = 1e-3 * torch.randn(N, 3, generator=g)
+    radii = ((torch.rand(N, generator=g) > 0.35) * torch.randint(1, 60, (N,), generator=g)).int()
+    vis = radii > 0
+    m.max_radii2D[vis] = torch.max(m.max_radii2D[vis], radii[vis])
+    m.add_densification_stats(vp, vis)
+    out["stats_vpgrad"], out["stats_radii"] = vp.grad, radii
+    dump("stats_out", m)
+    # (b) clone, (c) split, (d) prune_points, (e) reset_opacity, (g) prune_gaussians: one operation each from the same start
+    for op in ["clone", "split", "split_visi", "prune", "reset", "prune_gaussians", "densify_and_prune", "densify_and_prune_sized"]:
+        m, g = fresh(12)
+        if op == "clone":
+            dump("start", m)
+        grads = m.xyz_gradient_accum / m.denom
+        grads[grads.isnan()] = 0.0
+        visi = torch.rand(N, generator=g) > 0.4          # [N] as `trainer.py:360-366` passes it (pre-clone length)
+        if op == "clone":
+            m.densify_and_clone(grads, 5e-4, extent)
+        elif op == "split":
+            m.densify_and_split_along_maxscaling(grads, 5e-4, extent)
+        elif op == "split_visi":
+            out["split_visi_mask"] = visi
+            m.densify_and_split_along_maxscaling(grads, 5e-4, extent, visi=visi)
+        elif op == "prune":
+            mask = torch.rand(N, generator=g) > 0.6
+            out["prune_mask"] = mask
+            m.prune_points(mask)
+        elif op == "reset":
+            m.reset_opacity()
+        elif op == "prune_gaussians":
+            score = torch.rand(N, generator=g)
+            out["prune_gaussians_score"] = score
+            m.prune_gaussians(0.3, score)
+        elif op == "densify_and_prune":
+            out["dap_visi"] = visi
+            m.densify_and_prune(5e-4, 0.005, extent, None, visi)
+        else:
+            out["daps_visi"] = visi
+            m.densify_and_prune(5e-4, 0.005, extent, 20, visi)
+        dump(op, m)
+    out["extent"] = np.array(extent)
+    save("g6_densify.npz", **out)
+
+
 if __name__ == "__main__":
-    depth_cases(); image_cases(); sh_cases(); camera_cases(); misc_cases()
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    todo = dict(g1=depth_cases, g2=image_cases, g3=sh_cases, g4=camera_cases, g5=misc_cases, g7=misc_grad_cases, g6=densify_cases)
+    for k, fn in todo.items():          # g6 last: it monkey-patches torch.zeros / torch.cuda for the reference model
+        if not a.only or k in a.only.split(","):
+            fn()
