@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 8
+#define VCR_ABI_VERSION 9
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -244,6 +244,23 @@ int vcr_normal_losses_backward(int H, int W, float fx, float fy, float cx, float
                                const float* normal_planes, const float* gt, const uint8_t* mask, float depth_max,
                                float exp_t, int active, const double* sums9, const float* seeds3, float* scratch6,
                                float* d_depth, float* d_normal_planes, void* stream);
+/* Small regularisers of Trainer._compute_loss.  sums1 / sums3: vcr_sums_elems(1) / vcr_sums_elems(3) doubles (zeroed inside);
+ * `loss`: device float[1].
+ *  - edge-aware mean (tools/normal_utils.py:57-66 followed by .mean(), trainer.py:295-303): mean over H*W of
+ *    map * exp(-max over the 4 neighbours of mean_c |I - I_nb|) on interior pixels, 0 on the border; gradient to `map`.
+ *  - normal curvature (tools/loss_utils.py:287-300 + l1_loss(curv, 0), trainer.py:282-287): normal [H,W,3], mask bytes
+ *    [H,W] (replicate padding, masked 4-neighbour Laplacian, L1 norm over xyz, mean over H*W); gradient to `normal`.
+ *  - opacity entropy (tools/loss_utils.py:30-33, trainer.py:247-249) on sigmoid(opacity_raw) over the Gaussians inside the
+ *    normalised bounding box (xyz NULL: all); gradient to the RAW opacities. */
+int vcr_edge_aware_forward(int H, int W, const float* gt_image, const float* map, double* sums1, float* loss, void* stream);
+int vcr_edge_aware_backward(int H, int W, const float* gt_image, const float* gout, float* dmap, void* stream);
+int vcr_curv_forward(int H, int W, const float* normal_hwc, const uint8_t* mask, double* sums1, float* loss, void* stream);
+int vcr_curv_backward(int H, int W, const float* normal_hwc, const uint8_t* mask, const float* gout, float* dnormal,
+                      void* stream);
+int vcr_entropy_forward(int N, const float* opacity_raw, const float* xyz, const float* trans, const float* scale,
+                        double* sums3, float* loss, void* stream);
+int vcr_entropy_backward(int N, const float* opacity_raw, const float* xyz, const float* trans, const float* scale,
+                         const double* sums3, const float* gout, float* dopacity_raw, void* stream);
 /* l1_loss + ssim (tools/loss_utils.py:36,49-92) in one pass over [3,H,W] images.  sums2 (device, fp64) =
  * {sum|a-b|, sum ssim_map}; partials9: [9,H,W] scratch kept for backward (NULL for inference). */
 int vcr_l1_ssim_forward(int H, int W, const float* img1, const float* img2, double* sums2, float* means2 /* {l1, ssim} */,

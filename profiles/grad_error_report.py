@@ -1,21 +1,31 @@
-"""Per-parameter gradient error of the HIP rasterizer against the fp64 autograd oracle on the parity-test cases
-(max-norm relative error; the number DESIGN.md section 5 quotes).  Needs a GPU: python profiles/grad_error_report.py"""
-import sys, torch
+"""Gradient error table of the HIP rasterizer against the fp64 autograd oracle on the parity-test cases: max-norm relative
+error and element-wise error quantiles (tests/util.py::grad_stats) per parameter.  Needs a GPU:
+    python profiles/grad_error_report.py > profiles/r2_grad_error_table.txt"""
+import sys
+
+import torch
+
 sys.path.insert(0, '.')
-from tests import util
-import tests.test_raster_parity_gpu as T
+from tests import util  # noqa: E402
+import tests.test_raster_parity_gpu as T  # noqa: E402
+
 device = torch.device('cuda:0')
-cases = [c.values if hasattr(c, 'values') else c for c in T.CASES] if hasattr(T, 'CASES') else None
-print("cases:", cases)
-for case in cases:
+print("# case (n, W, H, focal, scale_mult, sem) | param | maxnorm | elem median | p99 | p99.9 | max | flipped pixels / budget")
+for case in T.CASES:
     n, W, H, f, sm, sem = case
-    cam, inp, dirs = util.make_case(n, W, H, f, seed=7, scale_mult=sm, sem=sem)
-    bg = torch.tensor([0.2, 0.1, 0.4])
-    g = torch.Generator().manual_seed(11)
-    (ref, _, _), rl = util.oracle_forward(cam, inp, dirs, bg, dtype=torch.float64, requires_grad=True)
-    wgt = torch.randn(ref.shape, generator=g, dtype=torch.float64)
-    (ref * wgt).sum().backward()
-    (out, _), hl = util.hip_forward(cam, inp, dirs, bg, device, requires_grad=True)
-    (out * wgt.float().to(device)).sum().backward()
-    errs = {k: util.rel_err(hl[k].grad, rl[k].grad) for k in ["means3D", "shs", "normals", "opac", "scales", "rots", "m2", "m2d", "sem"] if rl[k] is not None}
-    print(case, {k: f"{v:.1e}" for k, v in errs.items()})
+    for nd in (0, 2):
+        cam, inp, dirs = util.make_case(n, W, H, f, seed=7, scale_mult=sm, sem=sem)
+        bg = torch.tensor([0.2, 0.1, 0.4])
+        g = torch.Generator().manual_seed(11)
+        (ref, _, _), rl = util.oracle_forward(cam, inp, dirs, bg, dtype=torch.float64, requires_grad=True, num_dist=nd)
+        wgt = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+        (ref * wgt).sum().backward()
+        (out, _), hl = util.hip_forward(cam, inp, dirs, bg, device, requires_grad=True, num_dist=nd)
+        (out * wgt.float().to(device)).sum().backward()
+        bad = util.bad_pixels(out, ref)
+        for k in ["means3D", "shs", "normals", "opac", "scales", "rots", "m2", "m2d", "sem"]:
+            if rl[k] is None:
+                continue
+            st = util.grad_stats(hl[k].grad, rl[k].grad)
+            print(f"{case} nd={nd} | {k:8s} | {st['maxnorm']:.1e} | {st['med']:.1e} | {st['p99']:.1e} | {st['p999']:.1e} | {st['max']:.1e} | {bad}/{util.pixel_budget(ref)}",
+                  flush=True)

@@ -594,3 +594,41 @@ def test_bench_priming_restores_the_workload(device):
         assert torch.equal(getattr(m, k).detach(), v), k
     bt.step(0)                                      # and the trainer still steps
     assert float(tr.losses["total"]) == float(tr.losses["total"])
+
+
+def test_misc_regularisers_vs_reference_vectors(device):
+    """edge-aware distortion mean, normal-curvature loss and opacity entropy (`trainer.py:247-249,282-303`): HIP forward and
+    backward against values / gradients produced by the reference's own functions (g5 / g7 fixtures)."""
+    from vcr_gaus_amd.loss_utils import curv_loss, edge_aware_mean, entropy_regulariser, normal2curv
+    g5, g7 = load("g5_misc.npz"), load("g7_misc_grads.npz")
+    T = lambda a: torch.from_numpy(np.asarray(a)).to(device)
+    # forward maps of g5 (the map form used for visualisation)
+    assert torch.allclose(normal2curv(T(g5["nrm"]), T(g5["mask"])), T(g5["curv"]), atol=1e-6)
+    # edge-aware mean + gradient to the map
+    dist = T(g7["dist"]).clone().requires_grad_(True)
+    l = edge_aware_mean(T(g7["img"]), dist)
+    l.backward()
+    assert abs(float(l) - float(g7["edge_loss"])) < 1e-6 * max(1.0, abs(float(g7["edge_loss"])))
+    assert torch.allclose(dist.grad, T(g7["edge_grad"]), rtol=1e-5, atol=1e-9)
+    # curvature loss + gradient to the normal map (sign function: compare away from exact zeros)
+    nrm = T(g7["nrm"]).clone().requires_grad_(True)
+    l = curv_loss(nrm, T(g7["mask"]))
+    l.backward()
+    assert abs(float(l) - float(g7["curv_loss"])) < 2e-6 * max(1.0, abs(float(g7["curv_loss"])))
+    assert torch.allclose(nrm.grad, T(g7["curv_grad"]), rtol=1e-5, atol=1e-9)
+    # entropy on raw opacities without the box mask == reference entropy_loss(sigmoid(raw)); chain rule for the gradient
+    op = T(g7["op"]).double()
+    raw = torch.log(op / (1 - op)).float().requires_grad_(True)
+    l = entropy_regulariser(raw)
+    l.backward()
+    assert abs(float(l) - float(g7["entropy_loss"])) < 1e-5
+    want = T(g7["entropy_grad"]).double() * op * (1 - op)
+    assert torch.allclose(raw.grad.double(), want, rtol=2e-4, atol=1e-8)
+    # with the bounding-box mask: only inside Gaussians count
+    xyz = torch.randn(raw.shape[0], 3, device=device)
+    trans, scale = torch.tensor([0.1, -0.2, 0.3], device=device), torch.tensor([1.5, 1.0, 0.8], device=device)
+    inside = (((xyz - trans) / scale).abs() < 1).all(-1)
+    l2 = entropy_regulariser(raw.detach().requires_grad_(True), xyz, trans, scale)
+    p = torch.sigmoid(raw.detach()[inside]).double()
+    ref = (-p * torch.log(p + 1e-6) - (1 - p) * torch.log(1 - p + 1e-6)).mean()
+    assert abs(float(l2) - float(ref)) < 1e-5

@@ -191,7 +191,8 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/vcr_raster.h but not exported"
     assert set(_lib.SYMBOLS) == declared
-    assert _lib.load().vcr_abi_version() == 8
+    want = int(re.search(r"#define VCR_ABI_VERSION (\d+)", hdr).group(1))
+    assert _lib.load().vcr_abi_version() == want == _lib.ABI_VERSION
 
 
 def test_rasterizer_refuses_cpu_tensors():

@@ -90,3 +90,37 @@ def rel_err(a, b):
     """max-norm relative error of a tensor against its reference."""
     a, b = a.double().cpu(), b.double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def elem_err(a, b, floor_frac=1e-3):
+    """Element-wise relative error |a-b| / (|b| + floor), floor = floor_frac * rms(b over its non-zero entries): small
+    gradients are checked against their own magnitude (the max-norm figure of `rel_err` is dominated by the largest
+    entries), while entries that are sums of cancelling terms are not divided by ~0."""
+    a, b = a.double().cpu().reshape(-1), b.double().cpu().reshape(-1)
+    nz = b[b != 0]
+    rms = float(nz.square().mean().sqrt()) if nz.numel() else 1.0
+    return (a - b).abs() / (b.abs() + floor_frac * rms)
+
+
+def grad_stats(a, b):
+    """-> dict(maxnorm, med, p99, p999, max) of the gradient error (max-norm relative + element-wise quantiles)."""
+    e = elem_err(a, b)
+    q = torch.quantile(e, torch.tensor([0.5, 0.99, 0.999], dtype=e.dtype)) if e.numel() else torch.zeros(3)
+    return dict(maxnorm=rel_err(a, b), med=float(q[0]), p99=float(q[1]), p999=float(q[2]), max=float(e.max()) if e.numel() else 0.0)
+
+
+# Gradient acceptance used by every parity test: max-norm relative error < 5e-4 AND element-wise (abs+rel, see elem_err)
+# error < 1e-3 on 99 % and < 1e-2 on 99.9 % of the entries.  (A pixel whose alpha >= 1/255 or T < 1e-4 decision flips between fp32 and fp64
+# moves the gradients of the few Gaussians under it discretely -- those are the tolerated 0.1 %; the measured table is
+# committed as profiles/r2_grad_error_table.txt.)
+GRAD_MAXNORM_TOL = 5e-4
+GRAD_ELEM_P99_TOL = 1e-3
+GRAD_ELEM_P999_TOL = 1e-2
+
+
+def assert_grads_close(got, ref, name, maxnorm_tol=GRAD_MAXNORM_TOL, p999_tol=GRAD_ELEM_P999_TOL):
+    st = grad_stats(got, ref)
+    assert st["maxnorm"] < maxnorm_tol, f"grad {name}: max-norm rel err {st['maxnorm']:.2e} (stats {st})"
+    assert st["p99"] < GRAD_ELEM_P99_TOL, f"grad {name}: element-wise p99 err {st['p99']:.2e} (stats {st})"
+    assert st["p999"] < p999_tol, f"grad {name}: element-wise p99.9 err {st['p999']:.2e} (stats {st})"
+    return st

@@ -16,6 +16,7 @@ c_int_p = C.POINTER(C.c_int32)
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 BUF_GEOM, BUF_BINNING, BUF_IMAGE, BUF_SCRATCH = 0, 1, 2, 3
+ABI_VERSION = 9          # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
 
 
 class VcrShUpdate(C.Structure):
@@ -96,6 +97,12 @@ SYMBOLS = {
     "vcr_scale_reg_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "vcr_scale_reg_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 8),
     "vcr_sums_elems": (C.c_int, [C.c_int]),
+    "vcr_edge_aware_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "vcr_edge_aware_backward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 4),
+    "vcr_curv_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "vcr_curv_backward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "vcr_entropy_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 7),
+    "vcr_entropy_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 8),
     "vcr_l1_ssim_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
     "vcr_l1_ssim_backward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 7),
     "vcr_profile_enable": (None, [C.c_int]),
@@ -122,7 +129,7 @@ def load():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.vcr_abi_version() != 8:
+    if lib.vcr_abi_version() != ABI_VERSION:
         raise ImportError("libvcr_raster.so ABI version mismatch")
     _lib = lib
     return lib

@@ -775,3 +775,194 @@ extern "C" int vcr_weighted_total(int K, const float* res, const float* w, int s
 }
 
 extern "C" int vcr_sums_elems(int k) { return k * (1 + VCR_NSLOT); }
+
+// ---------------- small regularisers of `Trainer._compute_loss` (trainer.py:247-249,282-300) -----------------------------
+// edge-aware weighted mean of the distortion / depth-variance map (tools/normal_utils.py:57-66), the normal-curvature
+// loss (tools/loss_utils.py:287-300 + l1_loss(curv, 0)) and the opacity entropy (tools/loss_utils.py:30-33), one
+// streaming kernel each way.  sums layout as above ([K results][VCR_NSLOT x K slots]).
+namespace {
+
+__device__ __forceinline__ float edge_weight(const float* __restrict__ img, int H, int W, int x, int y) {
+    if (x == 0 || y == 0 || x == W - 1 || y == H - 1) return 0.f;                 // zero padding of the interior map
+    const size_t P = (size_t)H * W;
+    float gl = 0.f, gr = 0.f, gt = 0.f, gb = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* p = img + c * P + (size_t)y * W + x;
+        const float v = p[0];
+        gl += fabsf(v - p[-1]); gr += fabsf(v - p[1]); gt += fabsf(v - p[-W]); gb += fabsf(v - p[W]);
+    }
+    return __expf(-fmaxf(fmaxf(gl, gr), fmaxf(gt, gb)) * (1.f / 3.f));
+}
+
+__global__ void __launch_bounds__(256) edge_aware_fwd_kernel(int H, int W, const float* __restrict__ img,
+                                                             const float* __restrict__ map, double* __restrict__ sums) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    float v[1] = {0.f};
+    if (x < W && y < H) v[0] = map[(size_t)y * W + x] * edge_weight(img, H, W, x, y);
+    block_accumulate<1>(sums + 1, v);
+}
+
+__global__ void __launch_bounds__(256) edge_aware_bwd_kernel(int H, int W, const float* __restrict__ img,
+                                                             const float* __restrict__ gout, float* __restrict__ dmap) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < W && y < H) dmap[(size_t)y * W + x] = gout[0] / ((float)H * (float)W) * edge_weight(img, H, W, x, y);
+}
+
+// curvature vector of pixel (x, y): sum over the 4 replicate-padded neighbours nb of (n[nb] - n[c] m[c]) m[nb]
+__device__ __forceinline__ void curv_vec(const float* __restrict__ n, const uint8_t* __restrict__ m, int H, int W, int x, int y,
+                                         float cv[3], float& msum) {
+    const int xs[4] = {x, x > 0 ? x - 1 : 0, x, x < W - 1 ? x + 1 : W - 1};
+    const int ys[4] = {y > 0 ? y - 1 : 0, y, y < H - 1 ? y + 1 : H - 1, y};
+    const size_t c = (size_t)y * W + x;
+    const float mc = m[c] ? 1.f : 0.f;
+    const float c0 = n[3 * c] * mc, c1 = n[3 * c + 1] * mc, c2 = n[3 * c + 2] * mc;
+    cv[0] = cv[1] = cv[2] = 0.f; msum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t q = (size_t)ys[k] * W + xs[k];
+        if (m[q]) { cv[0] += n[3 * q] - c0; cv[1] += n[3 * q + 1] - c1; cv[2] += n[3 * q + 2] - c2; msum += 1.f; }
+    }
+    cv[0] *= mc; cv[1] *= mc; cv[2] *= mc;
+}
+
+__global__ void __launch_bounds__(256) curv_fwd_kernel(int H, int W, const float* __restrict__ n, const uint8_t* __restrict__ m,
+                                                       double* __restrict__ sums) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    float v[1] = {0.f};
+    if (x < W && y < H) {
+        float cv[3], ms;
+        curv_vec(n, m, H, W, x, y, cv, ms);
+        v[0] = fabsf(cv[0]) + fabsf(cv[1]) + fabsf(cv[2]);
+    }
+    block_accumulate<1>(sums + 1, v);
+}
+
+
+// gather form of the adjoint (deterministic): pixel p receives +S[c] m[p] from every pixel c that has p as a
+// (replicate-padded) neighbour, and -S[p] m[p] * (number of masked neighbours of p) from itself; S = sign(curv) m g / (H W).
+__global__ void __launch_bounds__(256) curv_bwd_kernel(int H, int W, const float* __restrict__ n, const uint8_t* __restrict__ m,
+                                                       const float* __restrict__ gout, float* __restrict__ dn) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t p = (size_t)y * W + x;
+    float g[3] = {0.f, 0.f, 0.f};
+    if (m[p]) {
+        float cv[3], ms;
+        curv_vec(n, m, H, W, x, y, cv, ms);
+        const float s0 = sgn(cv[0]), s1 = sgn(cv[1]), s2 = sgn(cv[2]);
+        g[0] = -s0 * ms; g[1] = -s1 * ms; g[2] = -s2 * ms;
+        // pixels c whose up / left / bottom / right neighbour is p (p itself at the matching border)
+        const int cx[4] = {x, x + 1, x, x - 1}, cy[4] = {y + 1, y, y - 1, y};
+        const bool self[4] = {y == 0, x == 0, y == H - 1, x == W - 1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (cx[k] >= 0 && cx[k] < W && cy[k] >= 0 && cy[k] < H) {
+                float c2[3], m2;
+                curv_vec(n, m, H, W, cx[k], cy[k], c2, m2);
+                g[0] += sgn(c2[0]); g[1] += sgn(c2[1]); g[2] += sgn(c2[2]);
+            }
+            if (self[k]) { g[0] += s0; g[1] += s1; g[2] += s2; }
+        }
+    }
+    const float sc = gout[0] / ((float)H * (float)W);
+    dn[3 * p] = g[0] * sc; dn[3 * p + 1] = g[1] * sc; dn[3 * p + 2] = g[2] * sc;
+}
+
+__device__ __forceinline__ bool inside_box(const float* __restrict__ xyz, const float* __restrict__ trans,
+                                           const float* __restrict__ scale, size_t i3) {
+    return fabsf((xyz[i3] - trans[0]) / scale[0]) < 1.f && fabsf((xyz[i3 + 1] - trans[1]) / scale[1]) < 1.f &&
+           fabsf((xyz[i3 + 2] - trans[2]) / scale[2]) < 1.f;
+}
+
+__global__ void __launch_bounds__(256) entropy_fwd_kernel(int N, const float* __restrict__ opacity_raw,
+                                                          const float* __restrict__ xyz, const float* __restrict__ trans,
+                                                          const float* __restrict__ scale, double* __restrict__ sums) {
+    float s = 0.f, cnt = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        if (xyz && !inside_box(xyz, trans, scale, 3 * (size_t)i)) continue;
+        const float p = 1.f / (1.f + __expf(-opacity_raw[i]));
+        s += -p * __logf(p + 1e-6f) - (1.f - p) * __logf(1.f - p + 1e-6f);
+        cnt += 1.f;
+    }
+    const float v[3] = {s, 0.f, cnt};
+    block_accumulate<3>(sums + 3, v);
+}
+
+__global__ void __launch_bounds__(256) entropy_bwd_kernel(int N, const float* __restrict__ opacity_raw,
+                                                          const float* __restrict__ xyz, const float* __restrict__ trans,
+                                                          const float* __restrict__ scale, const double* __restrict__ sums,
+                                                          const float* __restrict__ gout, float* __restrict__ dopacity_raw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float d = 0.f;
+    if (!xyz || inside_box(xyz, trans, scale, 3 * (size_t)i)) {
+        const float p = 1.f / (1.f + __expf(-opacity_raw[i])), q = 1.f - p;
+        const float dH = -__logf(p + 1e-6f) - p / (p + 1e-6f) + __logf(q + 1e-6f) + q / (q + 1e-6f);
+        d = gout[0] / (float)sums[2] * dH * p * q;
+    }
+    dopacity_raw[i] = d;
+}
+
+}  // namespace
+
+extern "C" int vcr_edge_aware_forward(int H, int W, const float* gt_image, const float* map, double* sums1, float* loss,
+                                      void* stream) {
+    if (H <= 0 || W <= 0 || !gt_image || !map || !sums1 || !loss) { vcr_set_error("vcr_edge_aware_forward: bad arguments"); return 1; }
+    hipStream_t st = (hipStream_t)stream;
+    VCR_HIP_CHECK(hipMemsetAsync(sums1, 0, (1 + VCR_NSLOT) * sizeof(double), st));
+    hipLaunchKernelGGL(edge_aware_fwd_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, st, H, W, gt_image, map, sums1);
+    hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, st, 1, sums1, 0, 1.0 / ((double)H * (double)W), loss);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_edge_aware_backward(int H, int W, const float* gt_image, const float* gout, float* dmap, void* stream) {
+    if (H <= 0 || W <= 0 || !gt_image || !gout || !dmap) { vcr_set_error("vcr_edge_aware_backward: bad arguments"); return 1; }
+    hipLaunchKernelGGL(edge_aware_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, (hipStream_t)stream, H, W, gt_image,
+                       gout, dmap);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_curv_forward(int H, int W, const float* normal_hwc, const uint8_t* mask, double* sums1, float* loss,
+                                void* stream) {
+    if (H <= 0 || W <= 0 || !normal_hwc || !mask || !sums1 || !loss) { vcr_set_error("vcr_curv_forward: bad arguments"); return 1; }
+    hipStream_t st = (hipStream_t)stream;
+    VCR_HIP_CHECK(hipMemsetAsync(sums1, 0, (1 + VCR_NSLOT) * sizeof(double), st));
+    hipLaunchKernelGGL(curv_fwd_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, st, H, W, normal_hwc, mask, sums1);
+    hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, st, 1, sums1, 0, 1.0 / ((double)H * (double)W), loss);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_curv_backward(int H, int W, const float* normal_hwc, const uint8_t* mask, const float* gout, float* dnormal,
+                                 void* stream) {
+    if (H <= 0 || W <= 0 || !normal_hwc || !mask || !gout || !dnormal) { vcr_set_error("vcr_curv_backward: bad arguments"); return 1; }
+    hipLaunchKernelGGL(curv_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, (hipStream_t)stream, H, W, normal_hwc, mask,
+                       gout, dnormal);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// xyz == NULL: no bounding-box mask (every Gaussian counts)
+extern "C" int vcr_entropy_forward(int N, const float* opacity_raw, const float* xyz, const float* trans, const float* scale,
+                                   double* sums3, float* loss, void* stream) {
+    if (N < 0 || !opacity_raw || !sums3 || !loss || (xyz && (!trans || !scale))) { vcr_set_error("vcr_entropy_forward: bad arguments"); return 1; }
+    hipStream_t st = (hipStream_t)stream;
+    VCR_HIP_CHECK(hipMemsetAsync(sums3, 0, 3 * (1 + VCR_NSLOT) * sizeof(double), st));
+    if (N > 0)
+        hipLaunchKernelGGL(entropy_fwd_kernel, dim3(min((N + 255) / 256, 2048)), dim3(256), 0, st, N, opacity_raw, xyz, trans, scale, sums3);
+    hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, st, 3, sums3, 1, 1.0, loss);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_entropy_backward(int N, const float* opacity_raw, const float* xyz, const float* trans, const float* scale,
+                                    const double* sums3, const float* gout, float* dopacity_raw, void* stream) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(entropy_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, opacity_raw, xyz, trans, scale,
+                       sums3, gout, dopacity_raw);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}

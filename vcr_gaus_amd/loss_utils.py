@@ -148,9 +148,116 @@ def cos_weight(render_normal, gt_normal, exp_t=1.0):
     return cos.detach()
 
 
+class _Entropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, opacity_raw, xyz, trans, scale):
+        lib = _lib.load()
+        o = opacity_raw.detach().contiguous().float()
+        x = None if xyz is None else xyz.detach().contiguous().float()
+        t = None if xyz is None else trans.detach().contiguous().float()
+        sc = None if xyz is None else scale.detach().contiguous().float()
+        sums = torch.empty(lib.vcr_sums_elems(3), dtype=torch.float64, device=o.device)
+        loss = torch.empty(1, dtype=torch.float32, device=o.device)
+        p = lambda v: None if v is None else v.data_ptr()
+        _lib.check(lib.vcr_entropy_forward(o.numel(), o.data_ptr(), p(x), p(t), p(sc), sums.data_ptr(), loss.data_ptr(),
+                                           _lib.stream_of(o)))
+        ctx.save_for_backward(o, x, t, sc, sums)
+        ctx.shape = opacity_raw.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        o, x, t, sc, sums = ctx.saved_tensors
+        d = torch.empty_like(o)
+        go = gout.contiguous().float().reshape(1)
+        p = lambda v: None if v is None else v.data_ptr()
+        _lib.check(lib.vcr_entropy_backward(o.numel(), o.data_ptr(), p(x), p(t), p(sc), sums.data_ptr(), go.data_ptr(),
+                                            d.data_ptr(), _lib.stream_of(o)))
+        return d.view(ctx.shape), None, None, None
+
+
+def entropy_regulariser(opacity_raw, xyz=None, trans=None, scale=None):
+    """`entropy_loss(get_opacity[inside])` of `trainer.py:247-249` on the RAW opacities, the sigmoid and the bounding-box
+    mask (`tools/math_utils.py:70-74`) fused: one kernel each way."""
+    return _Entropy.apply(opacity_raw, xyz, trans, scale)
+
+
 def entropy_loss(opacity):
-    """`tools/loss_utils.py:30-33` (weight 0 in every shipped config)."""
+    """`tools/loss_utils.py:30-33` on activated opacities (API compatibility; the trainer uses `entropy_regulariser`)."""
     return (-opacity * torch.log(opacity + 1e-6) - (1 - opacity) * torch.log(1 - opacity + 1e-6)).mean()
+
+
+class _Curv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, normal, mask):
+        lib = _lib.load()
+        n = normal.detach().contiguous().float()
+        H, W = n.shape[:2]
+        m = mask.detach().reshape(H, W).contiguous().to(torch.uint8)
+        sums = torch.empty(lib.vcr_sums_elems(1), dtype=torch.float64, device=n.device)
+        loss = torch.empty(1, dtype=torch.float32, device=n.device)
+        _lib.check(lib.vcr_curv_forward(H, W, n.data_ptr(), m.data_ptr(), sums.data_ptr(), loss.data_ptr(), _lib.stream_of(n)))
+        ctx.save_for_backward(n, m)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        n, m = ctx.saved_tensors
+        H, W = n.shape[:2]
+        d = torch.empty_like(n)
+        go = gout.contiguous().float().reshape(1)
+        _lib.check(lib.vcr_curv_backward(H, W, n.data_ptr(), m.data_ptr(), go.data_ptr(), d.data_ptr(), _lib.stream_of(n)))
+        return d, None
+
+
+def curv_loss(normal, mask):
+    """`l1_loss(normal2curv(normal, mask), 0)` (`tools/loss_utils.py:287-300`, `trainer.py:282-287`): normal [H,W,3],
+    mask [H,W] or [H,W,1] (bool / 0-1), fused forward and backward."""
+    return _Curv.apply(normal, mask)
+
+
+def normal2curv(normal, mask=None):
+    """`tools/loss_utils.py:287-300` (the map itself, for visualisation; the loss runs on `curv_loss`)."""
+    pad = torch.nn.functional.pad
+    n = pad(normal[None], [0, 0, 1, 1, 1, 1], mode="replicate")
+    m = pad(mask[None].to(torch.float32), [0, 0, 1, 1, 1, 1], mode="replicate").to(torch.bool)
+    c = n[:, 1:-1, 1:-1] * m[:, 1:-1, 1:-1]
+    tot = sum((n[:, ys, xs] - c) * m[:, ys, xs] for ys, xs in ((slice(None, -2), slice(1, -1)), (slice(1, -1), slice(None, -2)),
+                                                             (slice(2, None), slice(1, -1)), (slice(1, -1), slice(2, None))))
+    return (tot[0] * mask).norm(1, -1, True)
+
+
+class _EdgeAwareMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gt_image, dmap):
+        lib = _lib.load()
+        g = gt_image.detach().contiguous().float()
+        d = dmap.detach().contiguous().float()
+        H, W = g.shape[-2:]
+        sums = torch.empty(lib.vcr_sums_elems(1), dtype=torch.float64, device=g.device)
+        loss = torch.empty(1, dtype=torch.float32, device=g.device)
+        _lib.check(lib.vcr_edge_aware_forward(H, W, g.data_ptr(), d.data_ptr(), sums.data_ptr(), loss.data_ptr(), _lib.stream_of(g)))
+        ctx.save_for_backward(g)
+        ctx.shape = dmap.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        (g,) = ctx.saved_tensors
+        H, W = g.shape[-2:]
+        d = torch.empty(H, W, dtype=torch.float32, device=g.device)
+        go = gout.contiguous().float().reshape(1)
+        _lib.check(lib.vcr_edge_aware_backward(H, W, g.data_ptr(), go.data_ptr(), d.data_ptr(), _lib.stream_of(g)))
+        return None, d.view(ctx.shape)
+
+
+def edge_aware_mean(gt_image, distortion_map):
+    """`get_edge_aware_distortion_map(gt_image, map).mean()` (`tools/normal_utils.py:57-66`, `trainer.py:295-303`),
+    forward and backward in one kernel each."""
+    return _EdgeAwareMean.apply(gt_image, distortion_map)
 
 
 def psnr(img1, img2):

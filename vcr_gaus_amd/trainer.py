@@ -19,8 +19,7 @@ import torch.distributed as dist
 
 from .gaussian_model import GaussianModel
 from .gaussian_renderer import count_render, render, visi_acc_render
-from .loss_utils import l1_ssim, normal_loss, scale_regulariser
-from .normal_utils import get_edge_aware_distortion_map
+from .loss_utils import curv_loss, edge_aware_mean, entropy_regulariser, l1_ssim, normal_loss, scale_regulariser
 
 
 class Trainer:
@@ -132,7 +131,7 @@ class Trainer:
 
     # ---- losses (`trainer.py:233-321`) -------------------------------------------------------------------
     def _compute_loss(self, data, cam):
-        extra = [k for k in ("distortion", "depth_var", "semantic", "entropy", "mono_depth") if k in self.weights]
+        extra = [k for k in ("distortion", "depth_var", "semantic", "entropy", "mono_depth", "curv") if k in self.weights]
         if not extra and "render_out" in data and getattr(self, "use_fused_losses", True):
             from .fused_losses import fused_losses          # one autograd node for the whole image-space loss
             total, vals = fused_losses(data["render_out"], self.model, cam, self.weights, self.current_iteration,
@@ -146,6 +145,8 @@ class Trainer:
         L["l1"], L["ssim"] = l1, 1.0 - ssim_v
         if "l1_scale" in self.weights:
             L["l1_scale"] = scale_regulariser(self.model._scaling, self.model._xyz, self.model.trans, self.model.scale)
+        if "entropy" in self.weights:                                        # `trainer.py:247-249`
+            L["entropy"] = entropy_regulariser(self.model._opacity, self.model._xyz, self.model.trans, self.model.scale)
         gt_normal = getattr(cam, "normal", None)
         if "mono_normal" in self.weights and it > cfg.optim.normal_from_iter:
             L["mono_normal"] = normal_loss(data["normal"], gt_normal)
@@ -154,12 +155,14 @@ class Trainer:
                                             exp_t=cfg.optim.exp_t, mask=data.get("mask_static"),
                                             depth=data["depth"] if cfg.optim.mask_depth_thr > 0 else None,
                                             depth_max=self.extent * cfg.optim.mask_depth_thr)
+            if "curv" in self.weights and it > getattr(cfg.optim, "curv_from_iter", 0):      # `trainer.py:282-287`
+                L["curv"] = curv_loss(data["est_normal"], self._render_mask(data))
         if "consistent_normal" in self.weights and it > cfg.optim.consistent_normal_from_iter:
             L["consistent_normal"] = normal_loss(data["est_normal"], data["normal"])
         if "distortion" in self.weights and it > cfg.optim.close_depth_from_iter and "distortion" in data:
-            L["distortion"] = get_edge_aware_distortion_map(gt_image, data["distortion"]).mean()
+            L["distortion"] = edge_aware_mean(gt_image, data["distortion"])
         if "depth_var" in self.weights and it > cfg.optim.close_depth_from_iter and "depth_var" in data:
-            L["depth_var"] = get_edge_aware_distortion_map(gt_image, data["depth_var"]).mean()
+            L["depth_var"] = edge_aware_mean(gt_image, data["depth_var"])
         if "semantic" in self.weights and "render_sem" in data:
             logits = data["render_sem"].reshape(-1, self.model.num_cls)
             L["semantic"] = torch.nn.functional.cross_entropy(logits, cam.mask.view(-1).long()) / \
@@ -170,6 +173,21 @@ class Trainer:
         total = torch.dot(torch.stack([L[k] for k in names]), wvec)      # one weighted sum instead of 2 ops per loss
         L["total"] = total
         return total
+
+    def _render_mask(self, data):
+        """`data["mask"]` of the reference's render (camera mask AND depth < extent * mask_depth_thr,
+        `gaussian_renderer/__init__.py:125-131`); with `lazy_mask` renders it is formed here, on demand."""
+        m = data.get("mask")
+        if m is None:
+            with torch.no_grad():
+                m = data.get("mask_static")
+                thr = self.cfg.optim.mask_depth_thr
+                if thr > 0:
+                    m1 = (data["depth"] < self.extent * thr).squeeze(0)
+                    m = m1 if m is None else (m & m1)
+                if m is None:
+                    m = torch.ones(data["depth"].shape[1:], dtype=torch.bool, device=data["depth"].device)
+        return m
 
     def _weight_vector(self, names):
         key = tuple(names)
@@ -351,7 +369,7 @@ class Trainer:
         cam = self.cameras[self._next_cameras()[self.rank]]
         bg = self.bg_table[it % self.bg_table.shape[0]] if cfg.optim.random_background else self.background
         fused = getattr(self, "use_fused_losses", True) and not any(
-            k in self.weights for k in ("distortion", "depth_var", "semantic", "entropy", "mono_depth"))
+            k in self.weights for k in ("distortion", "depth_var", "semantic", "entropy", "mono_depth", "curv"))
         from . import rasterizer
         overlap = self.overlap_sh and m._xyz.shape[0] >= self.overlap_min_gaussians
         self.factorised_sh = self._factorised_base or overlap
