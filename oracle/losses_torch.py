@@ -62,3 +62,8 @@ def ssim(img1, img2):
     c1, c2 = 0.01 ** 2, 0.03 ** 2
     m = ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s11 + s22 + c2))
     return m.mean()
+
+
+def entropy_loss(opacity):
+    """`tools/loss_utils.py:30-33` (pinned by g5 / g7)."""
+    return (-opacity * torch.log(opacity + 1e-6) - (1 - opacity) * torch.log(1 - opacity + 1e-6)).mean()

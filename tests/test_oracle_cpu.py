@@ -269,3 +269,18 @@ def test_lazy_dictionaries_and_scoped_modes():
             assert rasterizer.SH_GRAD_MODE == "full" and rasterizer.COLOUR_STREAM is None
         assert rasterizer.SH_GRAD_MODE == "rgb"
     assert (rasterizer.SH_GRAD_MODE, rasterizer.COLOUR_STREAM, rasterizer.COLOUR_HOOK) == ("full", None, None)
+
+
+def test_oracle_trainer_pieces_match_reference_vectors():
+    """edge-aware map, normal2curv, entropy of oracle/trainer_torch.py + losses_torch.py vs the reference (g5, g7)."""
+    from oracle import trainer_torch as OT
+    g5, g7 = load("g5_misc.npz"), load("g7_misc_grads.npz")
+    assert torch.allclose(OT.edge_aware_map(g5["img"], g5["dist"]), g5["edge"], atol=1e-7)
+    assert torch.allclose(OT.normal2curv(g5["nrm"], g5["mask"]), g5["curv"], atol=1e-6)
+    assert abs(float(OL.entropy_loss(g5["op"])) - float(g5["entropy"])) < 1e-7
+    n = g7["nrm"].double().requires_grad_(True)
+    l = OT.normal2curv(n, g7["mask"].double()).abs().mean()
+    l.backward()
+    assert abs(float(l) - float(g7["curv_loss"])) < 1e-6 and torch.allclose(n.grad.float(), g7["curv_grad"], atol=1e-8)
+    lr = [OT.expon_lr(int(s), 1.6e-4, 1.6e-6, lr_delay_mult=0.01, max_steps=30000) for s in g5["lr_steps"]]
+    assert np.allclose(lr, g5["lr_vals"].numpy(), rtol=1e-12)
