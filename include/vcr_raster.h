@@ -261,6 +261,14 @@ int vcr_entropy_forward(int N, const float* opacity_raw, const float* xyz, const
                         double* sums3, float* loss, void* stream);
 int vcr_entropy_backward(int N, const float* opacity_raw, const float* xyz, const float* trans, const float* scale,
                          const double* sums3, const float* gout, float* dopacity_raw, void* stream);
+/* Depth -> TSDF input (tools/graphics_utils.py:134-141 depth2point, tools/depth2mesh.py:37-52): depth_out = depth, zeroed
+ * where gt_alpha < 0.5 (gt_alpha may be NULL), alpha < alpha_thres (alpha may be NULL) or the back-projected world point
+ * is outside the normalised bounding box |(p - trans) / scale| < 1 (trans NULL: no box test); xyz_cam / xyz_world
+ * ([H,W,3], may be NULL) receive depth2point of the UNMASKED depth.  c2w_rowmajor16: HOST pointer to the row-major 4x4
+ * camera-to-world matrix (inverse of the reference's `extrinsic_matrix` = world_view_transform^T). */
+int vcr_tsdf_depth_input(int H, int W, float fx, float fy, float cx, float cy, const float* c2w_rowmajor16, const float* trans,
+                         const float* scale, const float* depth, const float* alpha, float alpha_thres, const float* gt_alpha,
+                         float* depth_out, float* xyz_cam, float* xyz_world, void* stream);
 /* l1_loss + ssim (tools/loss_utils.py:36,49-92) in one pass over [3,H,W] images.  sums2 (device, fp64) =
  * {sum|a-b|, sum ssim_map}; partials9: [9,H,W] scratch kept for backward (NULL for inference). */
 int vcr_l1_ssim_forward(int H, int W, const float* img1, const float* img2, double* sums2, float* means2 /* {l1, ssim} */,

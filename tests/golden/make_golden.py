@@ -150,6 +150,34 @@ def misc_grad_cases():
          mask=mask, curv_loss=cv.detach(), curv_grad=nrm.grad, op=op.detach(), entropy_loss=en.detach(), entropy_grad=op.grad)
 
 
+def tsdf_input_cases():
+    """`tools/graphics_utils.py:134-141` (depth2point) and the depth masking of `tools/depth2mesh.py:37-52` (alpha threshold,
+    gt alpha mask, bounding-box test on the back-projected world points) run through the reference's functions."""
+    g = torch.Generator().manual_seed(8)
+    out = {}
+    for tag, (H, W) in {"a": (40, 56), "b": (33, 47)}.items():
+        K = RG.getIntrinsic(0.9, 0.7, H, W)
+        A = torch.randn(3, 3, generator=g)
+        R, _ = torch.linalg.qr(A)
+        w2c = torch.eye(4)
+        w2c[:3, :3], w2c[:3, 3] = R, torch.tensor([0.1, -0.2, 2.5])
+        depth = (1.0 + 3.0 * torch.rand(1, H, W, generator=g))
+        alpha = torch.rand(1, H, W, generator=g)
+        gt_alpha = torch.rand(1, H, W, generator=g)
+        trans, scale = torch.tensor([0.1, 0.0, -0.1]), torch.tensor([1.2, 1.0, 0.9])
+        xyz_cam, xyz_world = RG.depth2point(depth[0], K, w2c)
+        d = depth.clone()
+        d[(gt_alpha < 0.5)] = 0                                   # depth2mesh.py:45-46
+        d[(alpha < 0.5)] = 0                                      # :48 (alpha_thres 0.5)
+        world = RG.depth2point(d[0], K, w2c)[1]                   # :50
+        inside = RM.get_inside_normalized(world.view(-1, 3), trans, scale)[0]
+        d.view(-1)[~inside] = 0                                   # :51-52
+        out.update({f"{tag}_K": K, f"{tag}_w2c": w2c, f"{tag}_depth": depth, f"{tag}_alpha": alpha, f"{tag}_gt_alpha": gt_alpha,
+                    f"{tag}_trans": trans, f"{tag}_scale": scale, f"{tag}_xyz_cam": xyz_cam, f"{tag}_xyz_world": xyz_world,
+                    f"{tag}_masked": d})
+    save("g8_tsdf_input.npz", **out)
+
+
 def _load_reference_gaussian_model():
     """Import /root/reference/scene/gaussian_model.py on the CPU: stub the absent third-party modules, keep `scene/__init__`
     (dataset readers, PIL, cv2 ...) from running, and route the hard-coded device="cuda" allocations to the CPU."""
@@ -285,7 +313,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = dict(g1=depth_cases, g2=image_cases, g3=sh_cases, g4=camera_cases, g5=misc_cases, g7=misc_grad_cases, g6=densify_cases)
+    todo = dict(g1=depth_cases, g2=image_cases, g3=sh_cases, g4=camera_cases, g5=misc_cases, g7=misc_grad_cases, g8=tsdf_input_cases, g6=densify_cases)
     for k, fn in todo.items():          # g6 last: it monkey-patches torch.zeros / torch.cuda for the reference model
         if not a.only or k in a.only.split(","):
             fn()

@@ -632,3 +632,105 @@ def test_misc_regularisers_vs_reference_vectors(device):
     p = torch.sigmoid(raw.detach()[inside]).double()
     ref = (-p * torch.log(p + 1e-6) - (1 - p) * torch.log(1 - p + 1e-6)).mean()
     assert abs(float(l2) - float(ref)) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_tsdf_depth_input_vs_reference_vectors(device, tag):
+    """depth2point + the depth masking of tsdf_fusion (`tools/graphics_utils.py:134-141`, `tools/depth2mesh.py:37-52`)
+    against the reference's own outputs (g8 fixture)."""
+    from vcr_gaus_amd import depth2mesh
+    g = load("g8_tsdf_input.npz")
+    K, w2c = g[f"{tag}_K"], g[f"{tag}_w2c"]
+    depth = g[f"{tag}_depth"].to(device)
+    cam, wld = depth2mesh.depth2point(depth[0], K, w2c)
+    assert torch.allclose(cam.cpu(), g[f"{tag}_xyz_cam"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(wld.cpu(), g[f"{tag}_xyz_world"], rtol=1e-5, atol=2e-6)
+
+    class V:
+        intr_scalars = (float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]))
+        world_view_transform = w2c.t().contiguous()
+        gt_alpha_mask = g[f"{tag}_gt_alpha"].to(device)
+
+    class M:
+        trans, scale = g[f"{tag}_trans"].to(device), g[f"{tag}_scale"].to(device)
+
+    out = depth2mesh.tsdf_depth_input({"depth": depth, "alpha": g[f"{tag}_alpha"].to(device)}, V, M, alpha_thres=0.5)
+    want = g[f"{tag}_masked"]
+    assert out.shape == want.shape
+    diff = (out.cpu() != want)
+    assert float(diff.double().mean()) < 2e-3            # a point within one ulp of the box face may fall on the other side
+    assert 0.2 < float((want == 0).double().mean()) < 0.98
+    assert torch.allclose(out.cpu()[~diff], want[~diff])
+
+
+def test_get_covariance_and_checkpoint_roundtrip(device):
+    """`GaussianModel.get_covariance` (`scene/gaussian_model.py:38-42,194`) vs the oracle's Sigma = (R S)(R S)^T, and
+    `capture` / `restore` (`:88-123`) reproducing parameters, Adam moments, statistics and learning rates."""
+    from oracle import raster_torch as OR
+    from vcr_gaus_amd import synthetic
+    from vcr_gaus_amd.config import make_config
+    from vcr_gaus_amd.gaussian_model import GaussianModel
+    cfg = make_config("tnt")
+    raw = synthetic.make_gaussians(777, seed=9)
+    m = GaussianModel(cfg.model)
+    m.create_from_params(raw, 2.5, device=device)
+    m.training_setup(cfg.optim)
+    cov = m.get_covariance(1.3).detach().cpu().double()
+    q = torch.nn.functional.normalize(raw["rotation"].double())
+    S3 = OR.cov3d_from_scale_rot(torch.exp(raw["scaling"].double()), 1.3, q)
+    want = torch.stack([S3[:, 0, 0], S3[:, 0, 1], S3[:, 0, 2], S3[:, 1, 1], S3[:, 1, 2], S3[:, 2, 2]], 1)
+    assert torch.allclose(cov, want, rtol=1e-5, atol=2e-6 * float(want.abs().max()))     # fp32 products of the rotation
+    # a few Adam steps so that the optimizer state is non-trivial
+    for i in range(3):
+        for g in m.optimizer.param_groups:
+            g["params"][0].grad = torch.randn_like(g["params"][0]) * 1e-3
+        m.update_learning_rate(100 * (i + 1))
+        m.optimizer.step()
+    m.xyz_gradient_accum += 0.5
+    m.denom += 2
+    m.max_radii2D += 7
+    m.active_sh_degree = 2
+    import copy
+    snap = copy.deepcopy(m.capture())          # (what torch.save / torch.load of the checkpoint tuple does)
+    before = {k: getattr(m, k).detach().clone() for k in ["_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"]}
+    m2 = GaussianModel(cfg.model)
+    m2.restore(snap, cfg.optim)
+    assert m2.active_sh_degree == 2 and m2.spatial_lr_scale == 2.5
+    for k, v in before.items():
+        assert torch.equal(getattr(m2, k).detach(), v)
+    assert torch.equal(m2.xyz_gradient_accum, m.xyz_gradient_accum) and torch.equal(m2.denom, m.denom)
+    assert torch.equal(m2.max_radii2D, m.max_radii2D)
+    for name, st in m.optimizer.state.items():
+        st2 = m2.optimizer.state[name]
+        assert st2["step"] == st["step"] and torch.equal(st2["exp_avg"], st["exp_avg"]) and torch.equal(st2["exp_avg_sq"], st["exp_avg_sq"])
+    assert [g["lr"] for g in m2.optimizer.param_groups] == [g["lr"] for g in m.optimizer.param_groups]
+    # and the restored model keeps training identically
+    for mm in (m, m2):
+        torch.manual_seed(3)
+        for g in mm.optimizer.param_groups:
+            g["params"][0].grad = torch.randn_like(g["params"][0]) * 1e-3
+        mm.optimizer.step()
+    assert torch.equal(m._xyz, m2._xyz) and torch.equal(m._features_rest, m2._features_rest)
+
+
+def test_ply_roundtrip_on_device(device, tmp_path):
+    """save_ply / load_ply (`scene/gaussian_model.py:272-320,366-423`) with the model on the GPU: same field order as the
+    reference's point_cloud.ply and a bit-exact parameter round trip."""
+    from vcr_gaus_amd import synthetic
+    from vcr_gaus_amd.config import make_config
+    from vcr_gaus_amd.gaussian_model import GaussianModel
+    cfg = make_config("tnt")
+    raw = synthetic.make_gaussians(513, seed=10, sem_channels=2)
+    m = GaussianModel(cfg.model)
+    m.create_from_params(raw, 1.0, device=device)
+    path = str(tmp_path / "point_cloud.ply")
+    m.save_ply(path)
+    head = open(path, "rb").read(4096).split(b"end_header")[0].decode()
+    props = [l.split()[-1] for l in head.splitlines() if l.startswith("property")]
+    assert props[:6] == ["x", "y", "z", "nx", "ny", "nz"] and props[6:9] == ["f_dc_0", "f_dc_1", "f_dc_2"]
+    assert props[9] == "f_rest_0" and props[9 + 45:9 + 45 + 8] == ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+    assert props[-2:] == ["obj_dc_0", "obj_dc_1"]
+    m2 = GaussianModel(cfg.model)
+    m2.load_ply(path, device=device)
+    for k in ["_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity", "_objects_dc"]:
+        assert torch.equal(getattr(m, k).detach(), getattr(m2, k).detach()), k

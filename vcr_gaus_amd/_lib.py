@@ -97,6 +97,8 @@ SYMBOLS = {
     "vcr_scale_reg_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "vcr_scale_reg_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 8),
     "vcr_sums_elems": (C.c_int, [C.c_int]),
+    "vcr_tsdf_depth_input": (C.c_int, [C.c_int, C.c_int] + [C.c_float] * 4 + [C.POINTER(C.c_float)] + [C.c_void_p] * 4
+                             + [C.c_float] + [C.c_void_p] * 4 + [C.c_void_p]),
     "vcr_edge_aware_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5),
     "vcr_edge_aware_backward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 4),
     "vcr_curv_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5),

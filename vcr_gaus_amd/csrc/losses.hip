@@ -966,3 +966,59 @@ extern "C" int vcr_entropy_backward(int N, const float* opacity_raw, const float
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// ---------------- depth -> TSDF input (tools/graphics_utils.py:134-141, tools/depth2mesh.py:37-52) --------------------------
+// One pass over the rendered depth: zero it where alpha < alpha_thres, where the (optional) ground-truth alpha mask is
+// < 0.5, and where the back-projected WORLD point lies outside the normalised bounding box; optionally emit the camera- /
+// world-space points (depth2point) of the depth as given.  c2w: row-major 4x4 camera-to-world matrix.
+namespace {
+struct Mat34 { float m[12]; };
+
+__global__ void __launch_bounds__(256) tsdf_input_kernel(int H, int W, Intr k, Mat34 c2w, const float* __restrict__ trans,
+                                                         const float* __restrict__ scale, const float* __restrict__ depth_in,
+                                                         const float* __restrict__ alpha, float alpha_thres,
+                                                         const float* __restrict__ gt_alpha, float* __restrict__ depth_out,
+                                                         float* __restrict__ xyz_cam, float* __restrict__ xyz_world) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t p = (size_t)y * W + x;
+    const float z0 = depth_in[p];
+    const float ux = ((float)x + 0.5f - k.cx) / k.fx, uy = ((float)y + 0.5f - k.cy) / k.fy;
+    if (xyz_cam || xyz_world) {
+        const float X = ux * z0, Y = uy * z0;
+        if (xyz_cam) { xyz_cam[3 * p] = X; xyz_cam[3 * p + 1] = Y; xyz_cam[3 * p + 2] = z0; }
+        if (xyz_world) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) xyz_world[3 * p + r] = c2w.m[4 * r] * X + c2w.m[4 * r + 1] * Y + c2w.m[4 * r + 2] * z0 + c2w.m[4 * r + 3];
+        }
+    }
+    if (!depth_out) return;
+    float z = z0;
+    if (gt_alpha && gt_alpha[p] < 0.5f) z = 0.f;
+    if (alpha && alpha[p] < alpha_thres) z = 0.f;
+    if (trans) {                                            // the box test sees the point of the ALREADY masked depth
+        const float X = ux * z, Y = uy * z;
+        bool in = true;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float w = c2w.m[4 * r] * X + c2w.m[4 * r + 1] * Y + c2w.m[4 * r + 2] * z + c2w.m[4 * r + 3];
+            in = in && fabsf((w - trans[r]) / scale[r]) < 1.f;
+        }
+        if (!in) z = 0.f;
+    }
+    depth_out[p] = z;
+}
+}  // namespace
+
+extern "C" int vcr_tsdf_depth_input(int H, int W, float fx, float fy, float cx, float cy, const float* c2w_rowmajor16,
+                                    const float* trans, const float* scale, const float* depth, const float* alpha,
+                                    float alpha_thres, const float* gt_alpha, float* depth_out, float* xyz_cam,
+                                    float* xyz_world, void* stream) {
+    if (H <= 0 || W <= 0 || !c2w_rowmajor16 || !depth || (trans && !scale)) { vcr_set_error("vcr_tsdf_depth_input: bad arguments"); return 1; }
+    Mat34 m;
+    for (int i = 0; i < 12; ++i) m.m[i] = c2w_rowmajor16[i];
+    hipLaunchKernelGGL(tsdf_input_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, (hipStream_t)stream, H, W,
+                       Intr{fx, fy, cx, cy}, m, trans, scale, depth, alpha, alpha_thres, gt_alpha, depth_out, xyz_cam, xyz_world);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
