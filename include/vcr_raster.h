@@ -261,6 +261,19 @@ int vcr_entropy_forward(int N, const float* opacity_raw, const float* xyz, const
                         double* sums3, float* loss, void* stream);
 int vcr_entropy_backward(int N, const float* opacity_raw, const float* xyz, const float* trans, const float* scale,
                          const double* sums3, const float* gout, float* dopacity_raw, void* stream);
+/* Densify / prune row surgery (scene/gaussian_model.py:425-531: _prune_optimizer, cat_tensors_to_optimizer,
+ * densification_postfix) for ALL per-Gaussian arrays of the model (parameters, both Adam moments, statistics) in one launch.
+ *   vcr_rows_plan : offsets (vcr_rows_plan_bytes(N) bytes) <- per-256-row-block exclusive scan of mask; offsets[nblk] = M.
+ *   vcr_rows_move : mode 0: out[k] = in[k][mask]  ([M, width]);
+ *                   mode 1: out[k] = cat(in[k], in[k][mask] x copies) ([N + copies*M, width]), appended rows zero-filled
+ *                   where zero_new is set (the Adam moments of new Gaussians).  Arrays are float rows of `width` floats. */
+#define VCR_MAX_ROW_ARRAYS 32
+typedef struct VcrRowArray { const float* in; float* out; int32_t width; int32_t zero_new; } VcrRowArray;
+typedef struct VcrRowArrays { VcrRowArray a[VCR_MAX_ROW_ARRAYS]; int32_t n; } VcrRowArrays;
+size_t vcr_rows_plan_bytes(int N);
+int vcr_rows_plan(int N, const uint8_t* mask, uint32_t* offsets, void* stream);
+int vcr_rows_move(int N, const uint8_t* mask, const uint32_t* offsets, const VcrRowArrays* arrays, int mode, int copies,
+                  void* stream);
 /* Depth -> TSDF input (tools/graphics_utils.py:134-141 depth2point, tools/depth2mesh.py:37-52): depth_out = depth, zeroed
  * where gt_alpha < 0.5 (gt_alpha may be NULL), alpha < alpha_thres (alpha may be NULL) or the back-projected world point
  * is outside the normalised bounding box |(p - trans) / scale| < 1 (trans NULL: no box test); xyz_cam / xyz_world

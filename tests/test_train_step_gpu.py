@@ -84,10 +84,9 @@ def test_one_training_step_matches_oracle(device, preset, fused):
 def test_step_with_schedule_state_sh2_and_extra_losses(device):
     """Later iteration (decayed xyz lr), SH degree 2, entropy + curvature losses on (the modular loss path).  The
     curvature loss is an L1 norm of a Laplacian: where a component is ~0 its sign differs between fp32 and fp64 and the
-    gradient of the depth under that pixel moves by a fixed quantum, hence the 10x element-wise allowance (the max-norm
-    tolerance is the standard one)."""
+    gradient of the depth under that pixel moves by a fixed quantum, hence the 10x element-wise and 4x max-norm allowance."""
     ov = {"loss_weight": {"entropy": 0.01, "curv": 0.05}, "curv_from_iter": 0}
-    check(*run_case(device, "dtu", True, iteration=7001, overrides=ov, sh_degree=2), p999_tol=1e-1)
+    check(*run_case(device, "dtu", True, iteration=7001, overrides=ov, sh_degree=2), maxnorm_tol=2e-3, p999_tol=1e-1)
 
 
 def test_step_with_depth_variance_loss(device):

@@ -28,6 +28,17 @@ class VcrShUpdate(C.Structure):
     ]
 
 
+MAX_ROW_ARRAYS = 32
+
+
+class VcrRowArray(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("width", C.c_int32), ("zero_new", C.c_int32)]
+
+
+class VcrRowArrays(C.Structure):
+    _fields_ = [("a", VcrRowArray * MAX_ROW_ARRAYS), ("n", C.c_int32)]
+
+
 class VcrRasterArgs(C.Structure):
     _fields_ = [
         ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("S", C.c_int32), ("K", C.c_int32),
@@ -97,6 +108,9 @@ SYMBOLS = {
     "vcr_scale_reg_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "vcr_scale_reg_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 8),
     "vcr_sums_elems": (C.c_int, [C.c_int]),
+    "vcr_rows_plan_bytes": (C.c_size_t, [C.c_int]),
+    "vcr_rows_plan": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vcr_rows_move": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(VcrRowArrays), C.c_int, C.c_int, C.c_void_p]),
     "vcr_tsdf_depth_input": (C.c_int, [C.c_int, C.c_int] + [C.c_float] * 4 + [C.POINTER(C.c_float)] + [C.c_void_p] * 4
                              + [C.c_float] + [C.c_void_p] * 4 + [C.c_void_p]),
     "vcr_edge_aware_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5),

@@ -269,3 +269,112 @@ extern "C" int vcr_densify_stats(int N, const float* grad2d, const int32_t* radi
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// ---------------- densify / prune row surgery (scene/gaussian_model.py:425-531) -------------------------------------------
+// The reference re-packs every parameter tensor and both Adam moments with boolean-mask indexing + torch.cat, ~40 kernels
+// and as many allocations per operation.  Here ONE launch moves the selected rows of ALL arrays of the model at once:
+//   mode 0 (compact): out = in[mask]                                        (prune_points, `:456-475`)
+//   mode 1 (append) : out = cat(in, in[mask] x copies)  (zero_new: zeros)   (densification_postfix, `:477-531`)
+// vcr_rows_plan counts the selected rows per 256-row block and scans the counts (offsets[nblk] = total, read by the host to
+// size the outputs -- the same synchronisation the reference's `mask.sum()` / boolean indexing implies).
+namespace {
+constexpr int ROWS_PER_BLOCK = 256;
+
+__global__ void __launch_bounds__(256) rows_count_kernel(int N, const uint8_t* __restrict__ mask, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t s[4];
+    const int i = blockIdx.x * ROWS_PER_BLOCK + threadIdx.x;
+    const bool k = i < N && mask[i];
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(k);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+// exclusive scan of nblk counts by ONE workgroup (nblk <= a few 10^4): offsets[0..nblk), offsets[nblk] = total
+__global__ void __launch_bounds__(1024) rows_scan_kernel(int nblk, uint32_t* __restrict__ counts_offsets) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + t;
+        const uint32_t v = i < nblk ? counts_offsets[i] : 0u;
+        uint32_t inc = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = (uint32_t)__shfl_up((int)inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t pre = carry;
+        for (int k = 0; k < w; ++k) pre += wsum[k];
+        if (i < nblk) counts_offsets[i] = pre + inc - v;
+        __syncthreads();
+        if (t == 1023) carry = pre + inc;
+        __syncthreads();
+    }
+    if (t == 0) counts_offsets[nblk] = carry;
+}
+
+__global__ void __launch_bounds__(256) rows_move_kernel(int N, const uint8_t* __restrict__ mask,
+                                                        const uint32_t* __restrict__ offsets, int nblk, VcrRowArrays arr,
+                                                        int mode, int copies) {
+    __shared__ uint32_t s_rank[ROWS_PER_BLOCK];          // destination rank of the row inside the selection, or ~0u
+    __shared__ uint32_t s_w[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int row0 = blockIdx.x * ROWS_PER_BLOCK;
+    const int i = row0 + t;
+    const bool k = i < N && mask[i];
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(k);
+    if (lane == 0) s_w[w] = (uint32_t)__popcll(b);
+    __syncthreads();
+    uint32_t pre = offsets[blockIdx.x];
+    for (int q = 0; q < w; ++q) pre += s_w[q];
+    s_rank[t] = k ? pre + (uint32_t)__popcll(b & ((1ull << lane) - 1ull)) : 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t M = offsets[nblk];
+    const int rows = min(ROWS_PER_BLOCK, N - row0);
+    for (int a = 0; a < arr.n; ++a) {
+        const VcrRowArray A = arr.a[a];
+        const int wd = A.width;
+        const float* __restrict__ src = A.in + (size_t)row0 * wd;
+        for (int e = t; e < rows * wd; e += 256) {
+            const int r = e / wd, j = e - r * wd;
+            const uint32_t rk = s_rank[r];
+            const float v = src[e];
+            if (mode == 1) A.out[(size_t)row0 * wd + e] = v;                       // the first N rows are kept as they are
+            if (rk != 0xFFFFFFFFu) {
+                if (mode == 0) A.out[(size_t)rk * wd + j] = v;
+                else
+                    for (int c = 0; c < copies; ++c)
+                        A.out[((size_t)N + (size_t)c * M + rk) * wd + j] = A.zero_new ? 0.f : v;
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" size_t vcr_rows_plan_bytes(int N) { return sizeof(uint32_t) * ((size_t)(N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK + 1); }
+
+extern "C" int vcr_rows_plan(int N, const uint8_t* mask, uint32_t* offsets, void* stream) {
+    if (N < 0 || (N > 0 && (!mask || !offsets))) { vcr_set_error("vcr_rows_plan: bad arguments"); return 1; }
+    const int nblk = (N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipStream_t st = (hipStream_t)stream;
+    if (nblk > 0) hipLaunchKernelGGL(rows_count_kernel, dim3(nblk), dim3(256), 0, st, N, mask, offsets);
+    hipLaunchKernelGGL(rows_scan_kernel, dim3(1), dim3(1024), 0, st, nblk, offsets);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_rows_move(int N, const uint8_t* mask, const uint32_t* offsets, const VcrRowArrays* arrays, int mode,
+                             int copies, void* stream) {
+    if (!arrays || arrays->n < 0 || arrays->n > VCR_MAX_ROW_ARRAYS || mode < 0 || mode > 1 || copies < 1) {
+        vcr_set_error("vcr_rows_move: bad arguments"); return 1;
+    }
+    if (N <= 0 || arrays->n == 0) return 0;
+    const int nblk = (N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(rows_move_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, N, mask, offsets, nblk, *arrays, mode, copies);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -7,8 +7,11 @@ per-step arithmetic routed to HIP kernels:
   * Adam over all parameter groups: one launch (`FusedAdam`, replaces `torch.optim.Adam` at `:258`)
   * densification statistics: one kernel (`add_densification_stats`, `:669-671` + `trainer.py:345`)
 
-Densify / prune (every 100 iterations) stays as tensor surgery on the device, with the
-reference's deterministic split rule (`scene/gaussian_model.py:579-628`).
+  * densify / prune row surgery: parameters, both Adam moments and the statistics of ALL groups re-packed by one
+    plan + one move launch (`_move_rows`, replaces `_prune_optimizer` / `cat_tensors_to_optimizer`, `:425-531`)
+
+The selection rules (gradient threshold, clone / deterministic two-way split, prune masks) are the reference's
+(`scene/gaussian_model.py:579-667`) as a handful of small torch ops on the device.
 """
 import ctypes as C
 
@@ -391,9 +394,69 @@ class GaussianModel:
             out[g["name"]] = newp
         self._set_params(out)
 
+    # -- fused row surgery (HIP): every per-Gaussian array of the model moves in ONE launch (csrc/model_ops.hip) ------------
+    def _move_rows(self, mask, mode, copies=1, reset_stats=True):
+        """mode 0: keep the rows where `mask` (prune); mode 1: append `copies` copies of the rows where `mask` (clone /
+        split), Adam moments of the appended rows zero.  Parameters, both moments and the densification statistics are
+        re-packed by `vcr_rows_plan` + `vcr_rows_move`; returns the number of selected rows."""
+        lib = _lib.load()
+        dev, N = self.device, self._xyz.shape[0]
+        m8 = mask.to(torch.uint8).contiguous()
+        st = _lib.stream_of(m8)
+        plan = torch.empty(lib.vcr_rows_plan_bytes(N) // 4, dtype=torch.int32, device=dev)
+        _lib.check(lib.vcr_rows_plan(N, m8.data_ptr(), plan.data_ptr(), st))
+        M = int(plan[-1])                                   # the one host sync (the reference's boolean indexing has the same)
+        newN = M if mode == 0 else N + copies * M
+        items = []                                          # (setter, old tensor, zero_new)
+        for g in self.optimizer.param_groups:
+            if g.get("aux"):
+                continue
+            items.append((("p", g), g["params"][0].detach(), False))
+            stt = self.optimizer.state.get(g["name"])
+            if stt is not None:
+                items.append((("m", stt), stt["exp_avg"], True))
+                items.append((("v", stt), stt["exp_avg_sq"], True))
+        keep_stats = mode == 0 or not reset_stats
+        if keep_stats:
+            items += [(("s", "xyz_gradient_accum"), self.xyz_gradient_accum, True), (("s", "denom"), self.denom, True),
+                      (("s", "max_radii2D"), self.max_radii2D, True)]
+        arr = _lib.VcrRowArrays()
+        outs = []
+        for k, (_, t, zero_new) in enumerate(items):
+            t = t.contiguous()
+            out = torch.empty((newN,) + tuple(t.shape[1:]), dtype=torch.float32, device=dev)
+            width = 1
+            for d in t.shape[1:]:
+                width *= int(d)
+            arr.a[k].inp, arr.a[k].out, arr.a[k].width, arr.a[k].zero_new = t.data_ptr(), out.data_ptr(), width, int(zero_new)
+            outs.append((t, out))
+        arr.n = len(items)
+        _lib.check(lib.vcr_rows_move(N, m8.data_ptr(), plan.data_ptr(), C.byref(arr), mode, copies, st))
+        new_params = {}
+        for (kind, ref), (_, out) in zip([it[0] for it in items], outs):
+            if kind == "p":
+                ref["params"][0] = torch.nn.Parameter(out.requires_grad_(True))
+                new_params[ref["name"]] = ref["params"][0]
+            elif kind == "m":
+                ref["exp_avg"] = out
+            elif kind == "v":
+                ref["exp_avg_sq"] = out
+            else:
+                setattr(self, ref, out)
+        self._set_params(new_params)
+        if not keep_stats:
+            self.xyz_gradient_accum = torch.zeros((newN, 1), device=dev)
+            self.denom = torch.zeros((newN, 1), device=dev)
+            self.max_radii2D = torch.zeros(newN, device=dev)
+        return M
+
     @torch.no_grad()
     def prune_points(self, mask):
-        keep = ~mask
+        """`scene/gaussian_model.py:456-475`."""
+        if self._xyz.is_cuda:
+            self._move_rows(~mask, 0)
+            return
+        keep = ~mask                  # host tensors (CPU unit tests of the surgery logic): plain indexing
         self._rebind(lambda n, p: p[keep], lambda n, s: s[keep])
         self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
         self.denom = self.denom[keep]
@@ -401,6 +464,7 @@ class GaussianModel:
 
     @torch.no_grad()
     def densification_postfix(self, new, reset=True):
+        """`scene/gaussian_model.py:495-531` for explicitly given new rows (`new`: {group: tensor})."""
         self._rebind(lambda n, p: torch.cat((p, new[n]), 0), lambda n, s: torch.cat((s, torch.zeros_like(new[n])), 0))
         N, dev = self._xyz.shape[0], self.device
         if reset:
@@ -420,11 +484,18 @@ class GaussianModel:
             out[name] = torch.cat([v] * times, 0) if times > 1 else v
         return out
 
+    def _append_selected(self, sel, copies=1):
+        """cat(rows, rows[sel] x copies) for every array (moments of the new rows zero, statistics reset)."""
+        if self._xyz.is_cuda:
+            return self._move_rows(sel, 1, copies=copies, reset_stats=True)
+        self.densification_postfix(self._gather(sel, times=copies))
+        return int(sel.sum())
+
     @torch.no_grad()
     def densify_and_clone(self, grads, grad_threshold, scene_extent):
         sel = torch.norm(grads, dim=-1) >= grad_threshold
         sel &= self.get_scaling.max(dim=1).values <= self.percent_dense * scene_extent
-        self.densification_postfix(self._gather(sel))
+        self._append_selected(sel)
 
     @torch.no_grad()
     def densify_and_split_along_maxscaling(self, grads, grad_threshold, scene_extent, visi=None, N=2, n_std=2):
@@ -450,14 +521,14 @@ class GaussianModel:
         max_s = scaling[ar, axis]
         dirs = rots.gather(2, axis[:, None, None].expand(-1, 3, -1)).squeeze(-1)
         off = dirs * (n_std * max_s / 3.0)[:, None]
-        new = self._gather(sel, times=N)
         base = self._xyz.detach()[sel]
-        new["xyz"] = torch.cat((base + off, base - off), 0)
         ns = scaling.clone()
         ns[ar, axis] = max_s / (0.8 * N)
-        new["scaling"] = torch.log(ns).repeat(N, 1)
-        self.densification_postfix(new)
-        prune = torch.cat((sel, torch.zeros(N * int(sel.sum()), device=self.device, dtype=torch.bool)))
+        # all arrays: two copies of the selected rows appended; then the children's means / log-scales overwrite theirs
+        self._append_selected(sel, copies=N)
+        self._xyz.data[n0:] = torch.cat((base + off, base - off), 0)
+        self._scaling.data[n0:] = torch.log(ns).repeat(N, 1)
+        prune = torch.cat((sel, torch.zeros(self._xyz.shape[0] - n0, device=self.device, dtype=torch.bool)))
         self.prune_points(prune)
 
     @torch.no_grad()
