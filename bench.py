@@ -21,14 +21,16 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0   # what a streaming kernel reaches on this part (same guide)
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4.0   # wave64 VALU instructions / ns: 1024 SIMDs, one 4-cycle issue slot each at 2.4 GHz
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="metric_1m_1080p")
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -92,6 +94,83 @@ def cpu_baseline(raw, cam, dirs, stride):
             "est_s_per_iter": est}
 
 
+def cpu_baseline_c1():
+    """BASELINE config c1 in full on the host cores: the oracle's render (10 k Gaussians, 256x256, SH 3, intersection
+    depth) forward + backward, fp32, 1 warm-up + 5 repetitions, median."""
+    from oracle import model_torch as OM
+    from oracle import raster_torch as OR
+    from vcr_gaus_amd import synthetic
+    from vcr_gaus_amd.graphics_utils import get_all_px_dir
+    n, views, W, H, focal, sem = synthetic.WORKLOADS["c1_10k_256"]
+    raw = synthetic.make_gaussians(n, seed=0)
+    cam = synthetic.make_cameras(views, W, H, focal)[0]
+    dirs = get_all_px_dir(cam.intr, H, W)
+    s = OR.Settings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3), 1.0, cam.world_view_transform,
+                    cam.full_proj_transform, 3, cam.camera_center)
+    ts = []
+    for rep in range(6):
+        t0 = time.perf_counter()
+        act = {k: v.clone().requires_grad_(True) for k, v in OM.activations(raw).items()}
+        ncam = OM.camera_normals(OM.get_normal(act["rotation"], act["scaling"]), act["xyz"], cam.camera_center, cam.R_w2c)
+        out, _, _ = OR.rasterize(s, act["xyz"], torch.zeros(n, 3, requires_grad=True), None, act["shs"], None, ncam, None,
+                                 act["opacity"], act["scaling"], act["rotation"], None, dirs)
+        out.abs().mean().backward()
+        ts.append(time.perf_counter() - t0)
+    med = sorted(ts[1:])[2]
+    return {"workload": "c1_10k_256 render fwd+bwd (oracle, fp32)", "median_s": med, "iters_per_s": 1.0 / med,
+            "mpix_per_s": W * H / med / 1e6, "reps": 5}
+
+
+def cpu_loss_chain(H, W):
+    """The image-space loss chain of the step (compute_normals + cos-weighted monosdf_normal_loss + l1 + ssim, forward and
+    backward) at the benchmark resolution on the host cores: oracle/losses_torch.py, which is pinned to the reference's own
+    tools/normal_utils.py / tools/loss_utils.py by the g1 / g2 fixtures.  1 warm-up + 3 repetitions, median, ms."""
+    from oracle import losses_torch as OL
+    g = torch.Generator().manual_seed(0)
+    K = torch.tensor([[1165.0, 0, W / 2], [0, 1165.0, H / 2], [0, 0, 1]])
+    gt_n = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1)
+    gt_i = torch.rand(3, H, W, generator=g)
+    ts = []
+    for rep in range(4):
+        depth = (2.0 + torch.rand(1, H, W, generator=g)).requires_grad_(True)
+        img = torch.rand(3, H, W, generator=g).requires_grad_(True)
+        rn = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1)
+        t0 = time.perf_counter()
+        n = OL.compute_normals(depth, K)
+        loss = OL.monosdf_normal_loss(n, gt_n, OL.cos_weight(rn, gt_n, 0.005)) + 0.8 * OL.l1_loss(img, gt_i) + 0.2 * (1 - OL.ssim(img, gt_i))
+        loss.backward()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    return sorted(ts[1:])[1]
+
+
+def pmc_value(counter, kernel="composite_fwd", names=("sq", "grbm")):
+    import csv
+    for rnd in ("r2", "r1"):
+        for name in names:
+            path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{name}.csv")
+            if os.path.exists(path):
+                for r in csv.DictReader(open(path)):
+                    if r["kernel"].startswith(kernel) and r["counter"] == counter:
+                        return float(r["avg_per_dispatch"]), f"profiles/{rnd}_pmc_{name}.csv"
+    return None, None
+
+
+def valu_block(R, ms_fwd, workload):
+    naive_instr = 256.0 * R / 64.0 * 30.0
+    out = {"naive_pair_evals": 256 * R, "naive_wave_instr": naive_instr, "peak_ginstr_s": VALU_PEAK_GINSTR,
+           "naive_ms_at_peak": naive_instr / VALU_PEAK_GINSTR * 1e-6, "kernel_ms": ms_fwd}
+    if workload == "metric_1m_1080p":
+        insts, src = pmc_value("SQ_INSTS_VALU")
+        busy, _ = pmc_value("SQ_ACTIVE_INST_VALU")
+        gui, _ = pmc_value("GRBM_GUI_ACTIVE")
+        if insts:
+            out.update(executed_wave_instr=insts, executed_ginstr_s=insts / (ms_fwd * 1e6) if ms_fwd > 0 else None,
+                       executed_frac_of_peak=insts / (ms_fwd * 1e6) / VALU_PEAK_GINSTR if ms_fwd > 0 else None, source=src)
+        if busy and gui:
+            out["valu_busy_frac_pmc"] = busy * 4.0 / (1024.0 * gui / 8.0)       # DESIGN.md section 4: SIMD-cycles busy / available
+    return out
+
+
 def pmc_traffic(kernel="composite_fwd_v2_kernel"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r1_pmc_fetch.csv, r1_pmc_write.csv; separate --pmc runs of THIS command on the metric workload).
@@ -99,8 +178,10 @@ def pmc_traffic(kernel="composite_fwd_v2_kernel"):
     the x2 the MI355X guide prescribes (uncalibrated for this gather pattern)."""
     import csv
     vals = {}
+    rnd = "r2" if os.path.exists(os.path.join(ROOT, "profiles", "r2_pmc_fetch.csv")) else "r1"
+    pmc_traffic.source = f"profiles/{rnd}_pmc_{{fetch,write}}.csv (rocprofv3 --pmc, separate passes)"
     for name in ("fetch", "write"):
-        path = os.path.join(ROOT, "profiles", f"r1_pmc_{name}.csv")
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{name}.csv")
         if not os.path.exists(path):
             return None
         for r in csv.DictReader(open(path)):
@@ -142,11 +223,16 @@ def main():
     sync()
     _lib.profile_enable(True)
     _lib.profile_read()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step spread (GPU timeline)
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         trainer.step(args.warmup + i)
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
     prof = _lib.profile_read()
     _lib.profile_enable(False)
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -162,6 +248,7 @@ def main():
         achieved = alg_bytes / (ms_fwd * 1e-3) / 1e9 if ms_fwd > 0 else 0.0
         stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
         raster_fwd_ms = sum(stages[k] for k in ["preprocess", "depth_sort_scan", "binning", "composite_fwd"])
+        shape = trainer.scene_shape()            # one extra (untimed) debug render: longest tile list, covered pixels
         line = {
             "metric": "train iters/sec @1M Gaussians 1080p (full step: render fwd, losses, bwd, optimizer)",
             "value": world * args.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
@@ -169,19 +256,32 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "gaussians": n, "width": W, "height": H, "sh_degree": 3,
                        "views_per_step": world, "tile_instances_R": R, "visible_V": trainer.last_V,
-                       "step": trainer.describe()},
+                       "max_tile_len": shape["max_tile_len"], "covered_pixels": shape["covered_pixels"],
+                       "exchange": trainer.exchange(), "step": trainer.describe()},
+            "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": per_step[0], "max": per_step[-1],
+                        "note": "per-step GPU-timeline spread (events after every step); `value` uses the wall clock of all K steps"},
             "raster_mpix_per_s": world * P / (raster_fwd_ms * 1e-3) / 1e6 if raster_fwd_ms > 0 else None,
+            "raster_covered_mpix_per_s": world * shape["covered_pixels"] / (raster_fwd_ms * 1e-3) / 1e6 if raster_fwd_ms > 0 else None,
             "stage_ms": stages,
             "roofline": {"kernel": "composite_fwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                          "traffic": pmc_traffic() if args.workload == "metric_1m_1080p" else None,
-                         "traffic_source": "profiles/r1_pmc_{fetch,write}.csv (rocprofv3 --pmc, separate passes)",
-                         "algorithmic_bytes": alg_bytes, "avg_ms": ms_fwd},
+                         "traffic_source": getattr(pmc_traffic, "source", None),
+                         "algorithmic_bytes": alg_bytes, "avg_ms": ms_fwd,
+                         # the kernel is VALU-bound in practice.  `naive_*`: the algorithm's (pixel, Gaussian) pair
+                         # evaluations (256 per tile instance, ~30 wave64 VALU instructions per 64 pairs) priced at the issue
+                         # peak; `executed_*`: what the kernel really issues (SQ_INSTS_VALU of the committed PMC pass; the
+                         # per-quad culling skips most pairs) and the share of the launch the VALUs are busy.
+                         "valu": valu_block(R, ms_fwd, args.workload)},
         }
         if world == 1 and not args.no_cpu_baseline:
             stride = args.cpu_tile_stride or max(1, ((W + 15) // 16) * ((H + 15) // 16) // 192)
             dirs = get_all_px_dir(cams[0].intr, H, W)
             line["cpu_baseline"] = cpu_baseline(raw, cams[0], dirs, stride)
+            line["cpu_baseline"]["c1_full"] = cpu_baseline_c1()
+            line["cpu_baseline"]["loss_chain_ms"] = {"resolution": f"{W}x{H}", "value": cpu_loss_chain(H, W),
+                                                      "what": "compute_normals + cos-weighted monosdf + l1 + ssim, fwd+bwd, oracle/losses_torch.py"}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -515,6 +515,23 @@ class BenchTrainer:
         self.tr.train_step()          # (no per-rank fallback: a rank that switched exchange algorithm alone would hang RCCL)
         self.last_R, self.last_V = rasterizer.last_stats.get("R", 0), rasterizer.last_stats.get("V", 0)
 
+    @torch.no_grad()
+    def scene_shape(self):
+        """Untimed diagnostics of the workload: longest per-tile list and number of covered pixels (alpha > 0) of the last
+        camera, from one extra render with `debug` set (that render synchronises)."""
+        from . import rasterizer
+        tr = self.tr
+        tr.join_side()
+        cam = tr.cameras[tr._picked[tr.rank]] if tr._picked else tr.cameras[0]
+        dbg = tr.cfg.pipline.debug
+        tr.cfg.pipline.debug = True
+        try:
+            pkg = render(cam, tr.model, tr.cfg, tr.background, dirs=tr.dirs)
+        finally:
+            tr.cfg.pipline.debug = dbg
+        return {"max_tile_len": int(rasterizer.last_stats.get("max_tile_len", -1)),
+                "covered_pixels": int((pkg["alpha"] > 0).sum())}
+
     def exchange(self):
         """Which gradient exchange the steps use: none (1 GPU) | factorised (all-gather dL/drgb + bucket all-reduce) | dense."""
         return getattr(self.tr, "last_exchange", "none")
