@@ -7,9 +7,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 run() {  # name counters...
     local name=$1; shift
     rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$name -o pmc -- \
-        python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $R/gpurun_out/pmc_$name.log 2>&1
+        python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $R/gpurun_out/pmc_$name.log 2>&1
     python $R/profiles/summarize.py counters $(ls $R/gpurun_out/pmc_$name/*counter_collection.csv | head -1) \
-        $R/gpurun_out/r1_pmc_$name.csv composite_ adam_kernel sh_adam rs_ > /dev/null
+        $R/gpurun_out/r2_pmc_$name.csv composite_ adam_kernel sh_adam rs_ > /dev/null
 }
 for set in "$@"; do
     case $set in

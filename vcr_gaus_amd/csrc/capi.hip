@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <chrono>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -52,7 +53,8 @@ struct Published { unsigned long long R; uint32_t V; volatile uint32_t seq; };
 Published* pinned_published() {
     static thread_local Published* p = nullptr;
     if (!p) {
-        if (hipHostMalloc((void**)&p, sizeof(Published), hipHostMallocDefault) != hipSuccess) { p = nullptr; return nullptr; }
+        // coherent (uncached on the device side) so that the host sees the device's system-scope stores while the stream runs
+        if (hipHostMalloc((void**)&p, sizeof(Published), hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) { p = nullptr; return nullptr; }
         p->R = 0; p->V = 0; p->seq = 0;
     }
     return p;
@@ -201,20 +203,21 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         const size_t tmp1 = vcr_binning_temp_bytes(N, 0, tbits);
         const size_t nb = vcr_align(sizeof(uint32_t) * (size_t)N);
         const size_t ctr_bytes = vcr_align(sizeof(uint32_t) * VCR_CTR_WORDS);
-        char* s1 = (char*)alloc(user, VCR_BUF_SCRATCH, 6 * nb + ctr_bytes + tmp1);
+        const size_t status_bytes = vcr_duplicate_status_bytes(N);       // look-back words of the emission kernel, zeroed with the counters
+        char* s1 = (char*)alloc(user, VCR_BUF_SCRATCH, 5 * nb + ctr_bytes + status_bytes + tmp1);
         if (!s1) { vcr_set_error("allocator returned NULL"); return 1; }
         uint32_t* depth_key = (uint32_t*)s1;
         uint32_t* ids = (uint32_t*)(s1 + nb);                 // iota from preprocess; reused as the sort's second key buffer
         uint32_t* key_sorted = (uint32_t*)(s1 + 2 * nb);
         uint32_t* ids_sorted = (uint32_t*)(s1 + 3 * nb);
-        uint32_t* offsets = (uint32_t*)(s1 + 4 * nb);
-        uint32_t* tmp_v = (uint32_t*)(s1 + 5 * nb);
-        uint32_t* ctr = (uint32_t*)(s1 + 6 * nb);
+        uint32_t* tmp_v = (uint32_t*)(s1 + 4 * nb);
+        uint32_t* ctr = (uint32_t*)(s1 + 5 * nb);
+        unsigned long long* dup_status = (unsigned long long*)(s1 + 5 * nb + ctr_bytes);
         uint32_t* vis_counter = ctr;
         uint32_t* totals_depth = ctr + 2 * VCR_VIS_SLOTS;
         uint32_t* totals_tile = totals_depth + VCR_SORT_TOTALS_WORDS;
-        void* temp1 = s1 + 6 * nb + ctr_bytes;
-        VCR_HIP_CHECK(hipMemsetAsync(ctr, 0, sizeof(uint32_t) * VCR_CTR_WORDS, st));
+        void* temp1 = s1 + 5 * nb + ctr_bytes + status_bytes;
+        VCR_HIP_CHECK(hipMemsetAsync(ctr, 0, ctr_bytes + status_bytes, st));
         // two-stream form: geometry here, SH -> RGB on the colour stream behind whatever the caller queued there
         const bool split_colour = a.colour_stream && a.colour_stream != stream && a.shs && !a.colors_precomp;
         if (a.sh_update && !split_colour) { vcr_set_error("sh_update needs colour_stream and SH colours"); return 1; }
@@ -241,40 +244,54 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         static thread_local uint32_t seq_counter = 0;
         const uint32_t seq = ++seq_counter ? seq_counter : ++seq_counter;      // never 0
         hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(256), 0, st, vis_counter, pub, seq);
+        VCR_HIP_CHECK(hipGetLastError());
         VCR_HIP_CHECK(hipEventRecord(ev, st));
         {
             StageTimer tm(ST_DEPTHSORT, st);
-            if (vcr_depth_sort_and_scan(N, depth_key, ids, tmp_v, key_sorted, ids_sorted, g.tiles, offsets, totals_depth, temp1, tmp1,
-                                        st))
+            if (vcr_depth_sort(N, depth_key, ids, tmp_v, key_sorted, ids_sorted, totals_depth, temp1, st)) {
+                if (split_colour) (void)hipStreamWaitEvent(st, colour_event(1), 0);
                 return 1;
-        }
-        {   // spin on the published sequence number; after ~2 s fall back to the event (and report errors through it)
-            unsigned long long spins = 0;
-            while (pub->seq != seq) {
-                __builtin_ia32_pause();
-                if (++spins > (1ull << 30)) { VCR_HIP_CHECK(hipEventSynchronize(ev)); break; }
             }
-            if (pub->seq != seq) { vcr_set_error("device did not publish the instance count"); return 1; }
+        }
+        // From here on the colour stream may already be running work that consumed the caller's pending SH update: every
+        // error return below first joins it (the caller's retry / error handling must not see an un-joined stream).
+        auto fail_joined = [&]() { if (split_colour) (void)hipStreamWaitEvent(st, colour_event(1), 0); return 1; };
+        {   // spin on the published sequence number for at most ~2 ms of wall time, then sleep in the event (which also
+            // surfaces a device fault or a failed launch as an error instead of a hang)
+            const auto t_spin = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (pub->seq != seq) {
+#if defined(__x86_64__) || defined(__i386__)
+                __builtin_ia32_pause();
+#endif
+                if ((++spins & 1023u) == 0 &&
+                    std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(2)) {
+                    const hipError_t e = hipEventSynchronize(ev);
+                    if (e != hipSuccess) { vcr_set_error("readback event: %s", hipGetErrorString(e)); return fail_joined(); }
+                    break;
+                }
+            }
+            if (pub->seq != seq) { vcr_set_error("device did not publish the instance count"); return fail_joined(); }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
         }
         R = (int64_t)pub->R;
         out->num_visible = (int32_t)pub->V;
-        if (R >= (1ll << 32)) { vcr_set_error("more than 2^32 tile instances"); return 1; }
+        if (R >= (1ll << 32)) { vcr_set_error("more than 2^32 tile instances"); return fail_joined(); }
 
         void* bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(R, T));
-        if (!bin_p) { vcr_set_error("allocator returned NULL"); return 1; }
+        if (!bin_p) { vcr_set_error("allocator returned NULL"); return fail_joined(); }
         BinState b = BinState::view(bin_p, R, T);
         out->binning = bin_p;
         const size_t tmp2 = vcr_binning_temp_bytes(N, R, tbits);
         const size_t rbts = vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1));
         char* s2 = (char*)alloc(user, VCR_BUF_SCRATCH, 5 * rbts + tmp2);
-        if (!s2) { vcr_set_error("allocator returned NULL"); return 1; }
+        if (!s2) { vcr_set_error("allocator returned NULL"); return fail_joined(); }
         {
             StageTimer tm(ST_BINNING, st);
-            if (vcr_duplicate_and_sort(a, g, out->radii, ids_sorted, offsets, R, tbits, (uint32_t*)s2, (uint32_t*)(s2 + rbts),
+            if (vcr_duplicate_and_sort(a, g, out->radii, ids_sorted, dup_status, R, tbits, (uint32_t*)s2, (uint32_t*)(s2 + rbts),
                                        (uint32_t*)(s2 + 2 * rbts), (uint32_t*)(s2 + 3 * rbts), (uint32_t*)(s2 + 4 * rbts),
                                        b.point_list, b.ranges, b.tile_order, T, totals_tile, s2 + 5 * rbts, tmp2, st))
-                return 1;
+                return fail_joined();
         }
         out->num_rendered = R;
         if (a.debug) {                       // diagnostics only: longest per-tile list (one extra sync)

@@ -875,7 +875,7 @@ int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, u
 }
 
 int vcr_side_grid() {
-    static const int g = [] { const char* e = getenv("VCR_SIDE_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    static const int g = [] { const char* e = getenv("VCR_SIDE_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
     return g;
 }
 

@@ -2,7 +2,7 @@
 // R ~ 3e6 tile keys of <= 14 bits) -- problem sizes where a device-wide library sort is launch- and latency-bound
 // (rocPRIM onesweep here: 2 memsets + 1 kernel per 8-bit pass, ~40 us per pass at N = 1e6, plus a histogram kernel).
 //
-// Two kernels per 8-bit pass, no look-back chains, no memsets, no single-block scans:
+// Two kernels per 8-bit pass (three above 4.2 M items, see rs_hist_scan_kernel), no look-back chains, no memsets:
 //   upsweep   : every block counts the digits of its slice into LDS, writes one row of hist[block][digit] and adds
 //               the row to totals[pass][digit] (256 atomics per block);
 //   downsweep : every block sums the rows of the blocks before it (coalesced 1 KB rows out of L2), scans the 256
@@ -21,6 +21,10 @@ constexpr int RS_WAVES = RS_BLOCK / 64;
 constexpr int RS_CHUNKS = VCR_RS_CHUNKS;      // 64-item chunks per wave
 constexpr int RS_IPB = RS_BLOCK * RS_CHUNKS;  // items per block
 constexpr int RS_RADIX = 256;
+#ifndef VCR_RS_INLINE_PREFIX_MAX
+#define VCR_RS_INLINE_PREFIX_MAX 512
+#endif
+constexpr int RS_INLINE_PREFIX_MAX = VCR_RS_INLINE_PREFIX_MAX;   // blocks (x 8192 items) up to which the downsweep sums earlier rows itself
 
 __global__ void __launch_bounds__(RS_BLOCK) rs_upsweep_kernel(int64_t n, const uint32_t* __restrict__ keys, int shift,
                                                              uint32_t mask, uint32_t* __restrict__ hist,
@@ -43,8 +47,33 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_upsweep_kernel(int64_t n, const u
     }
 }
 
-template <bool IOTA>
-__global__ void __launch_bounds__(RS_BLOCK) rs_downsweep_kernel(int64_t n, const uint32_t* __restrict__ keys_in,
+// Exclusive scan over the blocks of every digit's counts, in place (hist[b][d] -> number of items with digit d in the
+// blocks before b): one workgroup per digit.  Used when the block count is large (> RS_INLINE_PREFIX_MAX blocks); below
+// that the downsweep sums the rows of the earlier blocks itself, which spares a launch but is quadratic in the block count.
+__global__ void __launch_bounds__(256) rs_hist_scan_kernel(int nblk, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_part[256];
+    const int d = blockIdx.x, t = threadIdx.x;
+    const int per = (nblk + 255) / 256, b0 = t * per, b1 = min(nblk, b0 + per);
+    uint32_t sum = 0;
+    for (int b = b0; b < b1; ++b) sum += hist[(size_t)b * RS_RADIX + d];
+    s_part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {                    // Hillis-Steele over the 256 partials
+        const uint32_t v = t >= o ? s_part[t - o] : 0u;
+        __syncthreads();
+        s_part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[t] - sum;
+    for (int b = b0; b < b1; ++b) {
+        const uint32_t c = hist[(size_t)b * RS_RADIX + d];
+        hist[(size_t)b * RS_RADIX + d] = run;
+        run += c;
+    }
+}
+
+template <bool IOTA, bool PRESCAN>
+__global__ void __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) rs_downsweep_kernel(int64_t n, const uint32_t* __restrict__ keys_in,
                                                                const uint32_t* __restrict__ vals_in, int shift, int nbits,
                                                                const uint32_t* __restrict__ hist,
                                                                const uint32_t* __restrict__ totals,
@@ -53,14 +82,18 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_downsweep_kernel(int64_t n, const
     __shared__ uint32_t before_blk[4][RS_RADIX];          // partial sums over the rows of the earlier blocks
     __shared__ uint32_t dig_base[RS_RADIX];               // exclusive scan of the digit totals
     __shared__ uint32_t lstart[RS_RADIX];                 // block-local start of every digit
-    __shared__ uint2 items[RS_IPB];                       // the slice in sorted order (64 KB at 8 chunks)
+    // Half of the slice in sorted order (32 KB at 8 chunks): the reorder runs in two rounds so that the workgroup needs
+    // 54 KB of LDS, not 86 KB -- with 86 KB it could not become resident on a CU that holds the two persistent 50 KB
+    // workgroups of the side stream's SH-update kernel, and every scatter pass waited for that whole kernel
+    __shared__ uint2 items[RS_IPB / 2];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint32_t mask = (1u << nbits) - 1u;
     for (int i = t; i < RS_WAVES * RS_RADIX; i += RS_BLOCK) (&cnt[0][0])[i] = 0;
     {   // rows of the blocks before this one: 4 thread groups x 256 digits, independent coalesced loads
         const int d = t & (RS_RADIX - 1), grp = t >> 8;
         uint32_t s = 0;
-        for (int b = grp; b < (int)blockIdx.x; b += 4) s += hist[(size_t)b * RS_RADIX + d];
+        if (PRESCAN) { if (grp == 0) s = hist[(size_t)blockIdx.x * RS_RADIX + d]; }
+        else for (int b = grp; b < (int)blockIdx.x; b += 4) s += hist[(size_t)b * RS_RADIX + d];
         before_blk[grp][d] = s;
         if (t < RS_RADIX) dig_base[t] = totals[t];
     }
@@ -135,21 +168,28 @@ __global__ void __launch_bounds__(RS_BLOCK) rs_downsweep_kernel(int64_t n, const
     }
     __syncthreads();
     // reorder through LDS so that the global writes of a wave are runs of consecutive addresses, not 64 scattered words
-#pragma unroll
-    for (int c = 0; c < RS_CHUNKS; ++c) {
-        if (wbase + c * 64 + lane < n) items[cnt[w][(key[c] >> shift) & mask] + rank[c]] = make_uint2(key[c], val[c]);
-    }
-    __syncthreads();
     const int64_t left = n - (int64_t)blockIdx.x * RS_IPB;
     const int nvalid = left < RS_IPB ? (int)left : RS_IPB;
 #pragma unroll
-    for (int c = 0; c < RS_CHUNKS; ++c) {
-        const int j = c * RS_BLOCK + t;
-        if (j < nvalid) {
-            const uint2 kv = items[j];
-            const uint32_t dst = (uint32_t)j + dig_base[(kv.x >> shift) & mask];
-            keys_out[dst] = kv.x;
-            vals_out[dst] = kv.y;
+    for (int c = 0; c < RS_CHUNKS; ++c) rank[c] += cnt[w][(key[c] >> shift) & mask];     // position inside the sorted slice
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const uint32_t lo = (uint32_t)half * (RS_IPB / 2);
+        if (half) __syncthreads();                          // round 0 has drained `items`
+#pragma unroll
+        for (int c = 0; c < RS_CHUNKS; ++c) {
+            if (wbase + c * 64 + lane < n && rank[c] - lo < (uint32_t)(RS_IPB / 2)) items[rank[c] - lo] = make_uint2(key[c], val[c]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < RS_CHUNKS / 2; ++c) {
+            const int j = (int)lo + c * RS_BLOCK + t;
+            if (j < nvalid) {
+                const uint2 kv = items[j - (int)lo];
+                const uint32_t dst = (uint32_t)j + dig_base[(kv.x >> shift) & mask];
+                keys_out[dst] = kv.x;
+                vals_out[dst] = kv.y;
+            }
         }
     }
 }
@@ -222,12 +262,13 @@ int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, 
         uint32_t* vout = to_out ? vals_out : vals_tmp;
         uint32_t* tot = totals + p * RS_RADIX;
         hipLaunchKernelGGL(rs_upsweep_kernel, dim3(nblk), dim3(RS_BLOCK), 0, st, n, kin, shift, (1u << nbits) - 1u, hist, tot);
-        if (vin)
-            hipLaunchKernelGGL(rs_downsweep_kernel<false>, dim3(nblk), dim3(RS_BLOCK), 0, st, n, kin, vin, shift, nbits, hist, tot,
-                               kout, vout);
-        else
-            hipLaunchKernelGGL(rs_downsweep_kernel<true>, dim3(nblk), dim3(RS_BLOCK), 0, st, n, kin, vin, shift, nbits, hist, tot,
-                               kout, vout);
+        const bool prescan = nblk > RS_INLINE_PREFIX_MAX;
+        if (prescan) hipLaunchKernelGGL(rs_hist_scan_kernel, dim3(RS_RADIX), dim3(256), 0, st, nblk, hist);
+#define VCR_DOWN(IOTA, PRE) hipLaunchKernelGGL((rs_downsweep_kernel<IOTA, PRE>), dim3(nblk), dim3(RS_BLOCK), 0, st, n, kin, vin, shift, \
+                                               nbits, hist, tot, kout, vout)
+        if (vin) { if (prescan) VCR_DOWN(false, true); else VCR_DOWN(false, false); }
+        else { if (prescan) VCR_DOWN(true, true); else VCR_DOWN(true, false); }
+#undef VCR_DOWN
         kin = kout; vin = vout;
     }
     VCR_HIP_CHECK(hipGetLastError());

@@ -147,11 +147,11 @@ int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const in
                                    const GradRec* sgrad, const float* sgrad_sem, VcrBackwardIO& io,
                                    hipStream_t st);
 size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits);
-int vcr_depth_sort_and_scan(int N, const uint32_t* depth_key, uint32_t* tmp_k, uint32_t* tmp_v, uint32_t* key_sorted,
-                            uint32_t* ids_sorted, const uint32_t* tiles, uint32_t* offsets, uint32_t* totals, void* temp,
-                            size_t temp_bytes, hipStream_t st);
+size_t vcr_duplicate_status_bytes(int N);
+int vcr_depth_sort(int N, const uint32_t* depth_key, uint32_t* tmp_k, uint32_t* tmp_v, uint32_t* key_sorted,
+                   uint32_t* ids_sorted, uint32_t* totals, void* temp, hipStream_t st);
 int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const uint32_t* ids_sorted,
-                           const uint32_t* offsets, int64_t R, int tile_bits, uint32_t* keys_a, uint32_t* vals_a,
+                           unsigned long long* status, int64_t R, int tile_bits, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_t, uint32_t* vals_t, uint32_t* keys_b, uint32_t* point_list, uint2* ranges,
                            uint32_t* tile_order, int num_tiles, uint32_t* totals, void* temp, size_t temp_bytes,
                            hipStream_t st);
