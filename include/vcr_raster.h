@@ -293,6 +293,7 @@ int vcr_l1_ssim_backward(int H, int W, const float* img1, const float* img2, con
  * live roofline figure; no reference counterpart).  Stage order: preprocess, depth sort+scan,
  * duplicate+tile sort+ranges, composite forward, composite backward, preprocess backward. */
 void vcr_profile_enable(int on);
+void vcr_profile_select(unsigned stage_mask);   /* bit k = time stage k (default: all); an event pair costs a few us of stream time */
 int  vcr_profile_num_stages(void);
 int  vcr_profile_read(float* ms, int32_t* launches, int n);
 

@@ -21,7 +21,8 @@ tr.prime()
 for i in range(10):
     tr.step(i)
 torch.cuda.synchronize()
-_lib.profile_enable(True)
+st = os.environ.get("AB_STAGES")
+_lib.profile_enable(st != "none", None if not st or st == "none" else st.split(","))
 _lib.profile_read()
 t0 = time.perf_counter()
 for i in range(steps):

@@ -122,6 +122,7 @@ SYMBOLS = {
     "vcr_l1_ssim_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
     "vcr_l1_ssim_backward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 7),
     "vcr_profile_enable": (None, [C.c_int]),
+    "vcr_profile_select": (None, [C.c_uint]),
     "vcr_profile_num_stages": (C.c_int, []),
     "vcr_profile_read": (C.c_int, [c_float_p, c_int_p, C.c_int]),
 }
@@ -165,8 +166,12 @@ def last_error():
     return load().vcr_last_error().decode()
 
 
-def profile_enable(on=True):
-    load().vcr_profile_enable(1 if on else 0)
+def profile_enable(on=True, stages=None):
+    """`stages`: iterable of stage names to time (default all); every timed stage adds an event pair to the stream."""
+    lib = load()
+    mask = 0xFFFFFFFF if stages is None else sum(1 << STAGES.index(s) for s in stages)
+    lib.vcr_profile_select(mask)
+    lib.vcr_profile_enable(1 if on else 0)
 
 
 def profile_read():

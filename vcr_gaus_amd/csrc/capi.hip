@@ -21,6 +21,7 @@ namespace {
 enum { ST_PREPROCESS = 0, ST_DEPTHSORT, ST_BINNING, ST_COMPOSITE_FWD, ST_COMPOSITE_BWD, ST_PREPROCESS_BWD, ST_COUNT };
 struct StageEvt { hipEvent_t a, b; int stage; };
 bool g_prof = false;
+unsigned g_prof_mask = 0xFFFFFFFFu;     // stages that get events (every event pair costs a few us of stream time)
 std::vector<StageEvt> g_used;
 std::vector<hipEvent_t> g_free;
 
@@ -36,7 +37,7 @@ struct StageTimer {
     hipStream_t st;
     int stage;
     StageTimer(int stage_, hipStream_t st_) : st(st_), stage(stage_) {
-        if (g_prof) { a = get_event(); b = get_event(); (void)hipEventRecord(a, st); }
+        if (g_prof && ((g_prof_mask >> stage_) & 1u)) { a = get_event(); b = get_event(); (void)hipEventRecord(a, st); }
     }
     ~StageTimer() {
         if (a) { (void)hipEventRecord(b, st); g_used.push_back({a, b, stage}); }
@@ -362,6 +363,7 @@ extern "C" int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* 
 }
 
 extern "C" void vcr_profile_enable(int on) { g_prof = on != 0; }
+extern "C" void vcr_profile_select(unsigned stage_mask) { g_prof_mask = stage_mask; }
 
 extern "C" int vcr_profile_num_stages(void) { return ST_COUNT; }
 
