@@ -734,3 +734,31 @@ def test_ply_roundtrip_on_device(device, tmp_path):
     m2.load_ply(path, device=device)
     for k in ["_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity", "_objects_dc"]:
         assert torch.equal(getattr(m, k).detach(), getattr(m2, k).detach()), k
+
+
+def test_semantic_classifier_is_trained(device):
+    """`scene/gaussian_model.py:254`: the 1x1-conv classifier is an Adam group at cls_lr: with the semantic
+    loss on, its weights move, its gradients are released after the step, and densify / prune leave the group alone."""
+    from vcr_gaus_amd import synthetic
+    from vcr_gaus_amd.trainer import make_synthetic_trainer
+    raw = synthetic.make_gaussians(3000, seed=12, sem_channels=2)
+    raw["scaling"] = raw["scaling"] + 1.5
+    cams = synthetic.make_cameras(3, 96, 64, 80.0, device=device)
+    tr = make_synthetic_trainer(raw, cams, device, preset="tnt", overlap_sh=False,
+                                optim={"loss_weight": {"semantic": 0.005}, "densify_from_iter": 2, "densification_interval": 2,
+                                       "densify_until_iter": 100, "prune": {"iterations": []}})
+    m = tr.model
+    names = [g["name"] for g in m.optimizer.param_groups]
+    assert "classifier.weight" in names and "classifier.bias" in names
+    w0, b0 = m.classifier.weight.detach().clone(), m.classifier.bias.detach().clone()
+    n0 = m._xyz.shape[0]
+    for _ in range(5):
+        tr.train_step()
+    torch.cuda.synchronize()
+    assert "semantic" in tr.losses and float(tr.losses["semantic"]) > 0
+    assert float((m.classifier.weight - w0).abs().max()) > 0 and float((m.classifier.bias - b0).abs().max()) > 0
+    assert m.classifier.weight.grad is None and m.classifier.bias.grad is None
+    assert m._xyz.shape[0] != n0                                      # densification ran with the aux groups present
+    st = m.optimizer.state["classifier.weight"]
+    assert st["step"] == 5 and st["exp_avg"].shape == m.classifier.weight.shape
+    assert any(g["params"][0] is m.classifier.weight for g in m.optimizer.param_groups)

@@ -102,21 +102,23 @@ class FusedAdam:
             st = self._state(g)
             st["step"] += 1
             by_step.setdefault(st["step"], []).append(g)
-        for step, gs in by_step.items():
-            n = len(gs)
-            P, G, M, V = ((C.c_void_p * n)() for _ in range(4))
-            numel = (C.c_int64 * n)()
-            lr = (C.c_float * n)()
-            keep = []
-            for k, g in enumerate(gs):
-                p = g["params"][0]
-                st = self.state[g["name"]]
-                grad = p.grad.contiguous()
-                keep.append(grad)
-                P[k], G[k], M[k], V[k] = p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-                numel[k], lr[k] = p.numel(), g["lr"]
-            _lib.check(lib.vcr_adam_step(n, P, G, M, V, numel, lr, self.betas[0], self.betas[1], self.eps, step,
-                                         float(self.grad_scale), _lib.stream_of(gs[0]["params"][0])))
+        for step, gs_all in by_step.items():
+            for c0 in range(0, len(gs_all), 8):                      # vcr_adam_step takes at most 8 tensors per launch
+                gs = gs_all[c0:c0 + 8]
+                n = len(gs)
+                P, G, M, V = ((C.c_void_p * n)() for _ in range(4))
+                numel = (C.c_int64 * n)()
+                lr = (C.c_float * n)()
+                keep = []
+                for k, g in enumerate(gs):
+                    p = g["params"][0]
+                    st = self.state[g["name"]]
+                    grad = p.grad.contiguous()
+                    keep.append(grad)
+                    P[k], G[k], M[k], V[k] = p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                    numel[k], lr[k] = p.numel(), g["lr"]
+                _lib.check(lib.vcr_adam_step(n, P, G, M, V, numel, lr, self.betas[0], self.betas[1], self.eps, step,
+                                             float(self.grad_scale), _lib.stream_of(gs[0]["params"][0])))
         if only is not None:
             for g in live:
                 g["params"][0].grad = None
