@@ -207,8 +207,10 @@ def main():
     from vcr_gaus_amd.graphics_utils import get_all_px_dir
     from vcr_gaus_amd.trainer import BenchTrainer
 
-    n, views, W, H, focal, sem = synthetic.WORKLOADS[args.workload]
+    n, views, W, H, focal, sem, smult = synthetic.workload(args.workload)
     raw = synthetic.make_gaussians(n, seed=0, sem_channels=sem)
+    if smult != 1.0:
+        raw["scaling"] = raw["scaling"] + math.log(smult)
     cams = synthetic.make_cameras(max(args.views, world), W, H, focal, device=dev)
     trainer = BenchTrainer(raw, cams, dev, world=world, rank=rank)
 
@@ -262,7 +264,7 @@ def main():
             "value": world * args.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "gaussians": n, "width": W, "height": H, "sh_degree": 3,
+            "config": {"workload": args.workload, "scale_mult": smult, "gaussians": n, "width": W, "height": H, "sh_degree": 3,
                        "views_per_step": world, "tile_instances_R": R, "visible_V": trainer.last_V,
                        "max_tile_len": shape["max_tile_len"], "covered_pixels": shape["covered_pixels"],
                        "exchange": trainer.exchange(), "step": trainer.describe()},

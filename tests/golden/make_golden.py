@@ -184,7 +184,23 @@ def _load_reference_gaussian_model():
     import importlib.util
     for name in ["plyfile", "simple_knn", "simple_knn._C", "pytorch3d", "pytorch3d.ops", "open3d"]:
         sys.modules.setdefault(name, types.ModuleType(name))
-    sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
+    captured = {}
+
+    class _PlyElement:                              # stand-ins that CAPTURE what the reference hands to plyfile
+        @staticmethod
+        def describe(elements, name):
+            captured["names"], captured["elements"], captured["element"] = list(elements.dtype.names), elements, name
+            return elements
+
+    class _PlyData:
+        def __init__(self, els):
+            pass
+
+        def write(self, path):
+            captured["path"] = path
+
+    sys.modules["plyfile"].PlyData, sys.modules["plyfile"].PlyElement = _PlyData, _PlyElement
+    sys.modules["plyfile"].captured = captured
     sys.modules["simple_knn._C"].distCUDA2 = None
     sys.modules["pytorch3d.ops"].ball_query = sys.modules["pytorch3d.ops"].knn_points = None
     pkg = types.ModuleType("scene")
@@ -305,6 +321,19 @@ def densify_cases():
             m.densify_and_prune(5e-4, 0.005, extent, 20, visi)
         dump(op, m)
     out["extent"] = np.array(extent)
+    # PLY wire format (`scene/gaussian_model.py:272-311`): field names + the vertex table the reference passes to plyfile
+    m, g = fresh(13)
+    import tempfile
+    real_save = torch.save
+    torch.save = lambda *a, **k: None               # (model.pth with the classifier weights is not part of the fixture)
+    try:
+        m.save_ply(os.path.join(tempfile.mkdtemp(), "point_cloud", "point_cloud.ply"))
+    finally:
+        torch.save = real_save
+    cap = sys.modules["plyfile"].captured
+    out["ply_names"] = np.array(cap["names"])
+    out["ply_table"] = np.stack([cap["elements"][nm] for nm in cap["names"]], 1).astype("<f4")
+    dump("ply", m)
     save("g6_densify.npz", **out)
 
 

@@ -119,3 +119,27 @@ def test_densification_stats_kernel_matches_reference(device):
     vp.grad = torch.from_numpy(G["stats_vpgrad"]).to(device)
     m.add_densification_stats(vp, None, radii=torch.from_numpy(G["stats_radii"]).to(device))
     check(m, "stats_out")
+
+
+def test_ply_bytes_match_the_table_the_reference_writes(tmp_path):
+    """`save_ply` (`scene/gaussian_model.py:272-311`): same property names in the same order and, row by row, the same
+    float32 vertex table the reference hands to plyfile (captured by make_golden.py); `load_ply` restores the parameters."""
+    m = model_from("ply", torch.device("cpu"))
+    path = str(tmp_path / "pc" / "point_cloud.ply")
+    m.save_ply(path)
+    blob = open(path, "rb").read()
+    head, payload = blob.split(b"end_header\n", 1)
+    lines = head.decode().splitlines()
+    assert lines[0] == "ply" and lines[1] == "format binary_little_endian 1.0" and lines[2] == f"element vertex {G['ply_table'].shape[0]}"
+    names = [l.split()[-1] for l in lines if l.startswith("property")]
+    assert names == [str(n) for n in G["ply_names"]]
+    assert all(l.split()[1] == "float" for l in lines if l.startswith("property"))
+    table = np.frombuffer(payload, dtype="<f4").reshape(G["ply_table"].shape)
+    assert np.array_equal(table, G["ply_table"])
+    cfg = make_config("tnt")
+    cfg.model.enable_semantic, cfg.model.ch_sem_feat, cfg.model.num_cls = True, 2, 2
+    m2 = GaussianModel(cfg.model)
+    m2.load_ply(path, device="cpu")
+    tab = m._param_table()
+    for name in NAMES:
+        assert torch.equal(getattr(m2, tab[name]).detach(), getattr(m, tab[name]).detach()), name

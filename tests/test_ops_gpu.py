@@ -762,3 +762,30 @@ def test_semantic_classifier_is_trained(device):
     st = m.optimizer.state["classifier.weight"]
     assert st["step"] == 5 and st["exp_avg"].shape == m.classifier.weight.shape
     assert any(g["params"][0] is m.classifier.weight for g in m.optimizer.param_groups)
+
+
+def test_convert_shs_python_path_equals_native_sh(device):
+    """`pipline.convert_SHs_python` (`gaussian_renderer/__init__.py:81-87`): colours from `eval_sh` in Python handed over as
+    colors_precomp give the render of the native SH path, and the SH coefficients receive the same gradients."""
+    from vcr_gaus_amd import synthetic
+    from vcr_gaus_amd.config import make_config
+    from vcr_gaus_amd.gaussian_model import GaussianModel
+    from vcr_gaus_amd.gaussian_renderer import render
+    from vcr_gaus_amd.graphics_utils import get_all_px_dir
+    raw = synthetic.make_gaussians(3000, seed=14)
+    raw["scaling"] = raw["scaling"] + 1.8
+    cam = synthetic.make_cameras(3, 96, 64, 80.0, device=device)[1]
+    dirs = get_all_px_dir(cam.intr, 64, 96)
+    outs, grads = [], []
+    for py in (False, True):
+        cfg = make_config("tnt")
+        cfg.pipline.convert_SHs_python = py
+        m = GaussianModel(cfg.model)
+        m.create_from_params(raw, 1.0, device=device)
+        m.active_sh_degree = 2
+        pkg = render(cam, m, cfg, torch.tensor([0.1, 0.2, 0.3], device=device), dirs=dirs)
+        (pkg["render"] * torch.linspace(0.5, 1.5, 96, device=device)).sum().backward()
+        outs.append(pkg["render"].detach()); grads.append((m._features_dc.grad.clone(), m._features_rest.grad.clone(), m._xyz.grad.clone()))
+    assert torch.allclose(outs[0], outs[1], atol=2e-6)
+    for a, b in zip(grads[0], grads[1]):
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-9

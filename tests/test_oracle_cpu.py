@@ -284,3 +284,12 @@ def test_oracle_trainer_pieces_match_reference_vectors():
     assert abs(float(l) - float(g7["curv_loss"])) < 1e-6 and torch.allclose(n.grad.float(), g7["curv_grad"], atol=1e-8)
     lr = [OT.expon_lr(int(s), 1.6e-4, 1.6e-6, lr_delay_mult=0.01, max_steps=30000) for s in g5["lr_steps"]]
     assert np.allclose(lr, g5["lr_vals"].numpy(), rtol=1e-12)
+
+
+def test_eval_sh_matches_reference_vectors():
+    """vcr_gaus_amd.sh_utils.eval_sh (the `convert_SHs_python` path) vs `tools/sh_utils.py:57-112` outputs (g3), reference layout."""
+    from vcr_gaus_amd.sh_utils import eval_sh
+    g = load("g3_sh.npz")
+    for deg in range(4):
+        rgb = torch.clamp_min(eval_sh(deg, g["sh"], g["dirs"]) + 0.5, 0.0)
+        assert torch.allclose(rgb, g[f"rgb_deg{deg}"], atol=1e-6)

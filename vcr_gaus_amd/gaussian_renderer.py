@@ -83,6 +83,12 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
     # SH coefficients go to the kernel in the model's split storage (no torch.cat of get_features)
     shs, shs_rest, colors_precomp = (pc._features_dc, pc._features_rest, None) if override_color is None \
         else (None, None, override_color)
+    if override_color is None and cfg.pipline.convert_SHs_python:        # `gaussian_renderer/__init__.py:81-87`
+        from .sh_utils import eval_sh
+        shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+        dir_pp = pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
+        sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp / dir_pp.norm(dim=1, keepdim=True))
+        shs, shs_rest, colors_precomp = None, None, torch.clamp_min(sh2rgb + 0.5, 0.0)
     sem_feats = pc.get_objects.squeeze(1) if cfg.optim.loss_weight.semantic > 0 else None
 
     rendered_out, radii = rasterizer(

@@ -23,6 +23,17 @@ WORKLOADS = {
     "c5_360_5m_1600x1200": (5_000_000, 100, 1600, 1200, 1250.0, 0),
     "metric_1m_1080p": (1_000_000, 8, 1920, 1080, 1165.0, 0),
 }
+# Denser variants of a workload (same scene, every scale multiplied): the Appendix-B recipe gives R/N ~ 3 tile instances per
+# Gaussian and leaves 84 % of the 1080p tiles empty; real trained scenes sit at R/N ~ 10-20.  name -> (base, scale multiplier)
+DENSE_VARIANTS = {"dense_1m_1080p": ("metric_1m_1080p", 3.5)}
+
+
+def workload(name):
+    """-> (n, views, width, height, focal, sem_channels, scale_mult) for a name of WORKLOADS or DENSE_VARIANTS."""
+    if name in DENSE_VARIANTS:
+        base, mult = DENSE_VARIANTS[name]
+        return WORKLOADS[base] + (mult,)
+    return WORKLOADS[name] + (1.0,)
 
 
 def _surface_points(n, g):
