@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--workload", default="metric_1m_1080p")
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tile-stride", type=int, default=0, help="0 = auto (~15 s of CPU work)")
+    ap.add_argument("--cpu-tile-stride", type=int, default=0, help="0 = auto (~1/8 of the tiles, 10-30 s of CPU work)")
     return ap.parse_args()
 
 
@@ -61,12 +61,16 @@ def cpu_baseline(raw, cam, dirs, stride):
 
     rawc = {k: v.cpu() for k, v in raw.items()}
     N = rawc["xyz"].shape[0]
-    t0 = time.perf_counter()
-    lv, ncam = inputs(rawc)
-    pre = OR.preprocess(s, lv["xyz"], torch.zeros(N, 3), lv["shs"], None, ncam, None, lv["opacity"], lv["scaling"],
-                        lv["rotation"], None)
-    (pre["px"].sum() + pre["conic"].sum() + pre["rgb"].sum() + pre["plane"].sum() + pre["depth"].sum()).backward()
-    t_pre = time.perf_counter() - t0
+
+    def per_gaussian_stage():
+        t0 = time.perf_counter()
+        lv, ncam = inputs(rawc)
+        pre = OR.preprocess(s, lv["xyz"], torch.zeros(N, 3), lv["shs"], None, ncam, None, lv["opacity"], lv["scaling"],
+                            lv["rotation"], None)
+        (pre["px"].sum() + pre["conic"].sum() + pre["rgb"].sum() + pre["plane"].sum() + pre["depth"].sum()).backward()
+        return time.perf_counter() - t0, pre
+
+    t_pre, pre = min((per_gaussian_stage() for _ in range(2)), key=lambda r: r[0])          # best of 2 (the first warms up)
     # Gaussians touching the sampled tiles
     gx, gy = pre["grid"]
     tiles = torch.arange(0, gx * gy, stride)
@@ -75,22 +79,26 @@ def cpu_baseline(raw, cam, dirs, stride):
     for x, y in zip(tx.tolist(), ty.tolist()):
         hit |= pre["vis"] & (pre["xmin"] <= x) & (x < pre["xmax"]) & (pre["ymin"] <= y) & (y < pre["ymax"])
     sub = {k: v[hit] for k, v in rawc.items()}
-    lv2, ncam2 = inputs(sub)
     n2 = sub["xyz"].shape[0]
-    tm = {}
-    t1 = time.perf_counter()
-    out, _, st = OR.rasterize(s, lv2["xyz"], torch.zeros(n2, 3, requires_grad=True), None, lv2["shs"], None, ncam2, None,
-                              lv2["opacity"], lv2["scaling"], lv2["rotation"], None, dirs.cpu(), tile_stride=stride,
-                              timings=tm)
-    if out.requires_grad:
-        out.abs().mean().backward()
-    t_tiles = time.perf_counter() - t1
+    runs = []
+    for rep in range(3):                                   # 1 warm-up + 2 repetitions, the faster one counts
+        lv2, ncam2 = inputs(sub)
+        tm = {}
+        t1 = time.perf_counter()
+        out, _, st = OR.rasterize(s, lv2["xyz"], torch.zeros(n2, 3, requires_grad=True), None, lv2["shs"], None, ncam2, None,
+                                  lv2["opacity"], lv2["scaling"], lv2["rotation"], None, dirs.cpu(), tile_stride=stride,
+                                  timings=tm)
+        if out.requires_grad:
+            out.abs().mean().backward()
+        runs.append(time.perf_counter() - t1)
+    t_tiles = min(runs[1:])
     scale = tm["tiles_total"] / max(tm["tiles_done"], 1)
     est = t_pre + t_tiles * scale
     return {"value": 1.0 / est, "unit": "iters/s", "cores": cores, "kind": "port",
             "sample": f"oracle/raster_torch.py fp32, {cores} threads: per-Gaussian stage fwd+bwd on all {N} Gaussians "
-                      f"({t_pre:.1f} s) + binning/compositing fwd+bwd of {tm['tiles_done']}/{tm['tiles_total']} tiles over "
-                      f"the {n2} Gaussians touching them ({t_tiles:.1f} s, scaled x{scale:.0f})",
+                      f"({t_pre:.1f} s, best of 2) + binning/compositing fwd+bwd of {tm['tiles_done']}/{tm['tiles_total']} tiles over "
+                      f"the {n2} Gaussians touching them ({t_tiles:.1f} s, best of 2 after a warm-up, scaled x{scale:.0f}); "
+                      f"{sum(runs) + 2 * t_pre:.0f} s of CPU work in total",
             "est_s_per_iter": est}
 
 
@@ -285,8 +293,10 @@ def main():
                          # per-quad culling skips most pairs) and the share of the launch the VALUs are busy.
                          "valu": valu_block(R, ms_fwd, args.workload)},
         }
+        if world == 1 and args.workload == "metric_1m_1080p":
+            line["roofline"]["dense_variant"] = trainer.dense_variant_roofline(3.5, HBM_PEAK_GBS, sem)
         if world == 1 and not args.no_cpu_baseline:
-            stride = args.cpu_tile_stride or max(1, ((W + 15) // 16) * ((H + 15) // 16) // 192)
+            stride = args.cpu_tile_stride or max(1, ((W + 15) // 16) * ((H + 15) // 16) // 1024)
             dirs = get_all_px_dir(cams[0].intr, H, W)
             line["cpu_baseline"] = cpu_baseline(raw, cams[0], dirs, stride)
             line["cpu_baseline"]["c1_full"] = cpu_baseline_c1()

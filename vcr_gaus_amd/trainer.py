@@ -532,6 +532,36 @@ class BenchTrainer:
         return {"max_tile_len": int(rasterizer.last_stats.get("max_tile_len", -1)),
                 "covered_pixels": int((pkg["alpha"] > 0).sum())}
 
+    @torch.no_grad()
+    def dense_variant_roofline(self, scale_mult, peak_gbs, sem=0, reps=10):
+        """Untimed context for the headline roofline figure: the SAME compositing kernel on the same scene with every scale
+        multiplied by `scale_mult` (R/N ~ 10 instead of ~ 3: what trained scenes look like).  -> achieved GB/s on
+        algorithmic bytes / fraction, from `reps` forward renders; the model is restored afterwards."""
+        import math
+        from . import _lib, rasterizer
+        tr, m = self.tr, self.tr.model
+        tr.join_side()
+        cam = tr.cameras[0]
+        m._scaling.data += math.log(scale_mult)
+        try:
+            for i in range(reps + 2):
+                if i == 2:
+                    torch.cuda.synchronize()
+                    _lib.profile_enable(True, stages=["composite_fwd"])
+                    _lib.profile_read()
+                render(cam, m, tr.cfg, tr.background, dirs=tr.dirs)
+            torch.cuda.synchronize()
+            ms, cnt = _lib.profile_read()["composite_fwd"]
+        finally:
+            _lib.profile_enable(False)
+            m._scaling.data -= math.log(scale_mult)
+        R, P = rasterizer.last_stats["R"], cam.image_height * cam.image_width
+        alg = (60 + 4 * sem) * R + (4 * (8 + sem) + 20) * P
+        avg = ms / max(cnt, 1)
+        ach = alg / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        return {"scale_mult": scale_mult, "tile_instances_R": R, "avg_ms": avg, "algorithmic_bytes": alg, "achieved": ach,
+                "frac": ach / peak_gbs}
+
     def exchange(self):
         """Which gradient exchange the steps use: none (1 GPU) | factorised (all-gather dL/drgb + bucket all-reduce) | dense."""
         return getattr(self.tr, "last_exchange", "none")
