@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 9
+#define VCR_ABI_VERSION 10
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -150,7 +150,8 @@ int vcr_activate_forward(int N, const float* scaling_raw, const float* rotation_
                          float* opac, float* normals_cam /* may be NULL */, uint8_t* aux, void* stream);
 int vcr_activate_backward(int N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
                           const float* R_w2c, const uint8_t* aux, const float* d_scales, const float* d_rots,
-                          const float* d_opac, const float* d_normals /* any may be NULL */, float* d_scaling_raw,
+                          const float* d_opac, const float* d_normals /* any may be NULL */, const float* d_scaling_extra /* optional [N,3]: added to d_scaling_raw (a gradient that reaches the raw scales on another path, e.g. l1_scale) */,
+                          float* d_scaling_raw,
                           float* d_rotation_raw, float* d_opacity_raw, void* stream);
 /* Data-parallel SH gradients without all-reducing them: per view the SH gradient is basis_k(dir) x dL/drgb, so ranks
  * all-gather dL/drgb (drgb_all [nviews,N,3]) and rebuild sum_v basis_k(normalize(xyz - campos_all[v])) * drgb_all[v]

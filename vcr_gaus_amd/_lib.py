@@ -16,7 +16,7 @@ c_int_p = C.POINTER(C.c_int32)
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 BUF_GEOM, BUF_BINNING, BUF_IMAGE, BUF_SCRATCH = 0, 1, 2, 3
-ABI_VERSION = 9          # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
+ABI_VERSION = 10         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
 
 
 class VcrShUpdate(C.Structure):
@@ -78,7 +78,7 @@ SYMBOLS = {
     "vcr_rasterize_forward": (C.c_int, [C.POINTER(VcrRasterArgs), C.POINTER(VcrForwardOut), ALLOC_FN, C.c_void_p, C.c_void_p]),
     "vcr_rasterize_backward": (C.c_int, [C.POINTER(VcrRasterArgs), C.POINTER(VcrBackwardIO), ALLOC_FN, C.c_void_p, C.c_void_p]),
     "vcr_activate_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 12),
-    "vcr_activate_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 13),
+    "vcr_activate_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 14),
     "vcr_sort_pairs_u32_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "vcr_sort_pairs_u32": (C.c_int, [C.c_int64] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "vcr_normal_losses_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int,

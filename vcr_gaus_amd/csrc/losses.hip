@@ -724,6 +724,8 @@ __global__ void weighted_total_kernel(int K, const float* __restrict__ res, cons
     *total = t;
 }
 
+// (The folded slots are zeroed again, so a caller may keep ONE reduction buffer alive across steps instead of zero-filling
+// a fresh one per call.)
 // One launch for what the loss node needs at the end of its forward: fold the slots of the L1+SSIM sums (2), the
 // scale-regulariser sums (3, optional) and the normal-loss sums (9, optional) in the fixed order of the individual
 // finalize kernels, write the six loss values and their weighted total.
@@ -740,7 +742,7 @@ __global__ void __launch_bounds__(256) finalize_losses_kernel(double* __restrict
         const int K = e < 2 ? 2 : (e < 5 ? 3 : 9), k = e < 2 ? e : (e < 5 ? e - 2 : e - 5);
         double t = 0.0;
         if (base) {
-            for (int s = lane; s < VCR_NSLOT; s += 64) t += base[K + (size_t)s * K + k];
+            for (int s = lane; s < VCR_NSLOT; s += 64) { t += base[K + (size_t)s * K + k]; base[K + (size_t)s * K + k] = 0.0; }
             for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
             if (lane == 0) base[k] = t;
         }

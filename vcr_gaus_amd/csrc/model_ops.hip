@@ -55,13 +55,14 @@ __global__ void __launch_bounds__(256) activate_bwd_kernel(int N, const float* _
                                                            const float* __restrict__ Rw2c, const uint8_t* __restrict__ aux,
                                                            const float* __restrict__ d_scales, const float* __restrict__ d_rots,
                                                            const float* __restrict__ d_opac, const float* __restrict__ d_normals,
-                                                           float* __restrict__ d_scaling_raw, float* __restrict__ d_rotation_raw,
+                                                           const float* __restrict__ d_scaling_extra, float* __restrict__ d_scaling_raw, float* __restrict__ d_rotation_raw,
                                                            float* __restrict__ d_opacity_raw) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const size_t i3 = 3 * (size_t)i;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) d_scaling_raw[i3 + k] = d_scales ? d_scales[i3 + k] * expf(scaling_raw[i3 + k]) : 0.f;
+    for (int k = 0; k < 3; ++k)
+        d_scaling_raw[i3 + k] = (d_scales ? d_scales[i3 + k] * expf(scaling_raw[i3 + k]) : 0.f) + (d_scaling_extra ? d_scaling_extra[i3 + k] : 0.f);
     const float o = 1.f / (1.f + expf(-opacity_raw[i]));
     d_opacity_raw[i] = d_opac ? d_opac[i] * o * (1.f - o) : 0.f;
     const float4 qr = reinterpret_cast<const float4*>(rotation_raw)[i];
@@ -216,12 +217,12 @@ extern "C" int vcr_activate_forward(int N, const float* scaling_raw, const float
 
 extern "C" int vcr_activate_backward(int N, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
                                      const float* R_w2c, const uint8_t* aux, const float* d_scales, const float* d_rots,
-                                     const float* d_opac, const float* d_normals, float* d_scaling_raw, float* d_rotation_raw,
-                                     float* d_opacity_raw, void* stream) {
+                                     const float* d_opac, const float* d_normals, const float* d_scaling_extra,
+                                     float* d_scaling_raw, float* d_rotation_raw, float* d_opacity_raw, void* stream) {
     if (N <= 0) return 0;
     hipLaunchKernelGGL(activate_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, scaling_raw,
-                       rotation_raw, opacity_raw, R_w2c, aux, d_scales, d_rots, d_opac, d_normals, d_scaling_raw,
-                       d_rotation_raw, d_opacity_raw);
+                       rotation_raw, opacity_raw, R_w2c, aux, d_scales, d_rots, d_opac, d_normals, d_scaling_extra,
+                       d_scaling_raw, d_rotation_raw, d_opacity_raw);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }

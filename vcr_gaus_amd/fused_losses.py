@@ -10,6 +10,10 @@ from . import _lib
 
 NAMES = ["l1", "ssim", "l1_scale", "mono_normal", "depth_normal", "consistent_normal"]
 _ONES = {}
+_SUMS = {}               # device -> [reduction buffer, in use]: kept alive across steps (vcr_finalize_losses re-zeroes its slots)
+# True (set by the trainer around loss + backward): the l1_scale gradient does not travel through autograd to `_scaling` but is
+# handed to the activation backward of the same graph (gaussian_model.PENDING_SCALE_GRAD), which adds it in its kernel.
+DEFER_SCALE_GRAD = False
 
 
 def unit_seed(device):
@@ -25,6 +29,7 @@ class _FusedLosses(torch.autograd.Function):
     @staticmethod
     def forward(ctx, out, scaling_raw, xyz, gt_image, gt_normal, mask, intr, wvec, active, exp_t, depth_max, trans, scale):
         lib = _lib.load()
+        ctx.set_materialize_grads(False)          # (no zero-filled gradient for the non-differentiable `res` output)
         o = out.detach().contiguous()
         C, H, W = o.shape
         P = H * W
@@ -32,8 +37,17 @@ class _FusedLosses(torch.autograd.Function):
         st = _lib.stream_of(o)
         base = o.data_ptr()
         n2, n3, n9 = lib.vcr_sums_elems(2), lib.vcr_sums_elems(3), lib.vcr_sums_elems(9)
-        # ONE memset for all reductions and the six results (+ the weighted total), which live in the buffer's tail
-        sums = torch.zeros(n2 + n3 + n9 + 4, dtype=torch.float64, device=dev)
+        # ONE buffer for all reductions and the six results (+ the weighted total), which live in its tail.  It is reused
+        # from step to step: the finalize kernel leaves the slots zeroed again (a fresh zero-filled one only if the previous
+        # forward's backward has not run yet).
+        ent = _SUMS.get(dev)
+        if ent is not None and not ent[1] and ent[0].numel() == n2 + n3 + n9 + 4:
+            sums = ent[0]
+        else:
+            sums = torch.zeros(n2 + n3 + n9 + 4, dtype=torch.float64, device=dev)
+            ent = _SUMS[dev] = [sums, False]
+        ent[1] = torch.is_grad_enabled() and ent[0] is sums
+        ctx.sums_entry = ent if ent[0] is sums else None
         res8 = sums[n2 + n3 + n9:].view(torch.float32)
         res, total = res8[:6], torch.empty((), device=dev)       # (not a view: a view output costs a select_backward)
         s_ssim, s_scale, s_nrm = sums.data_ptr(), sums.data_ptr() + 8 * n2, sums.data_ptr() + 8 * (n2 + n3)
@@ -54,6 +68,7 @@ class _FusedLosses(torch.autograd.Function):
                                                      float(depth_max), float(exp_t), nbits, s_nrm, rp(3), 3, st))
         ctx.save_for_backward(o, gi, part, sums, sr, xz, gn, m, wvec, trans, scale)
         ctx.meta = (H, W, C, tuple(intr), tuple(active), float(exp_t), float(depth_max), n2, n3, nbits)
+        ctx.scale_key = id(scaling_raw) if DEFER_SCALE_GRAD else None
         # ONE finalize for all reductions; total = sum_k w_k L_k with the ssim entry meaning (1 - ssim): wvec[1] = -w_ssim,
         # the constant +w_ssim is added in-kernel
         _lib.check(lib.vcr_finalize_losses(H, W, s_ssim, s_scale if active[2] else None, s_nrm if nbits else None, res.data_ptr(),
@@ -63,6 +78,10 @@ class _FusedLosses(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, _g_res):
+        if ctx.sums_entry is not None:
+            ctx.sums_entry[1] = False               # (the reduction results are read below, on this stream, before any reuse)
+        if g_total is None:
+            return (None,) * 13
         lib = _lib.load()
         o, gi, part, sums, sr, xz, gn, m, wvec, trans, scale = ctx.saved_tensors
         H, W, C, intr, active, exp_t, depth_max, n2, n3, nbits = ctx.meta
@@ -92,6 +111,10 @@ class _FusedLosses(torch.autograd.Function):
             d_sc = torch.empty_like(sr)
             _lib.check(lib.vcr_scale_reg_backward(sr.shape[0], sr.data_ptr(), xz.data_ptr(), trans.data_ptr(), scale.data_ptr(),
                                                   s_scale, gp(2), d_sc.data_ptr(), st))
+        if d_sc is not None and ctx.scale_key is not None:
+            from .gaussian_model import PENDING_SCALE_GRAD
+            PENDING_SCALE_GRAD[ctx.scale_key] = d_sc        # added by the activation backward of the same graph
+            d_sc = None
         return (dout, d_sc) + (None,) * 11
 
 

@@ -24,6 +24,12 @@ from .general_utils import build_rotation, get_expon_lr_func, inverse_sigmoid
 GROUPS = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "obj_dc"]
 
 
+# Gradients that reach `_scaling` on a second path (the l1_scale regulariser of the fused loss node) can be handed to the
+# activation backward here instead of through autograd: the kernel adds them to its own result, which spares the engine's
+# add kernel for two incoming gradients of one leaf.  {id(raw scaling parameter): tensor [N,3]}; see fused_losses.py.
+PENDING_SCALE_GRAD = {}
+
+
 class _FusedActivate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scaling, rotation, opacity, xyz, campos, R_w2c, want_normal):
@@ -43,6 +49,7 @@ class _FusedActivate(torch.autograd.Function):
                                             nrm.data_ptr() if want_normal else None, aux.data_ptr(), _lib.stream_of(xyz)))
         ctx.save_for_backward(sr, rr, orr, Rw, aux)
         ctx.want_normal = want_normal
+        ctx.scale_key = id(scaling)
         if want_normal:
             return scales, rots, opac, nrm
         return scales, rots, opac
@@ -58,8 +65,10 @@ class _FusedActivate(torch.autograd.Function):
 
         keep = [None if t is None else t.contiguous().float() for t in (d_scales, d_rots, d_opac, d_nrm)]
         ds, dr, do = torch.empty_like(sr), torch.empty_like(rr), torch.empty_like(orr)
+        extra = PENDING_SCALE_GRAD.pop(ctx.scale_key, None)
         _lib.check(lib.vcr_activate_backward(N, sr.data_ptr(), rr.data_ptr(), orr.data_ptr(), Rw.data_ptr(), aux.data_ptr(),
                                              *[None if t is None else t.data_ptr() for t in keep],
+                                             None if extra is None else extra.data_ptr(),
                                              ds.data_ptr(), dr.data_ptr(), do.data_ptr(), _lib.stream_of(sr)))
         return ds, dr, do, None, None, None, None
 

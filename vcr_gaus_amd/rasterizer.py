@@ -100,6 +100,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, means2D_densify, sh, colors_precomp, normals_precomp,
                 semantics_precomp, opacities, scales, rotations, cov3Ds_precomp, dirs, rs, sh_rest=None, num_dist=0):
         lib = _lib.load()
+        ctx.set_materialize_grads(False)          # (no zero-filled [N] gradient for the non-differentiable radii)
         dev = means3D.device
         if dev.type != "cuda":
             raise RuntimeError("vcr_raster: tensors must live on a HIP device (no CPU path exists)")
@@ -161,6 +162,8 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out, _grad_radii=None):
+        if grad_out is None:
+            return (None,) * 15
         lib = _lib.load()
         rs, t = ctx.rs, ctx.args_t
         (radii,) = ctx.saved_tensors

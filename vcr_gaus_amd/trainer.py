@@ -382,9 +382,16 @@ class Trainer:
             data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True, geometry=not fused)
         if self._pending_sh is not None:         # the render did not go through the two-stream path (e.g. no Gaussians)
             self.join_side()
-        loss = self._compute_loss(data, cam)
-        from .fused_losses import unit_seed
-        loss.backward(unit_seed(loss.device))
+        from . import fused_losses, gaussian_model
+        fused_losses.DEFER_SCALE_GRAD = True        # l1_scale's gradient joins the activation backward's kernel (same graph)
+        try:
+            loss = self._compute_loss(data, cam)
+            loss.backward(fused_losses.unit_seed(loss.device))
+        finally:
+            fused_losses.DEFER_SCALE_GRAD = False
+        left = gaussian_model.PENDING_SCALE_GRAD.pop(id(m._scaling), None)
+        if left is not None:                        # (no activation backward consumed it: add it the ordinary way)
+            m._scaling.grad = left if m._scaling.grad is None else m._scaling.grad + left
         with torch.no_grad():
             surgery = (it < cfg.optim.densify_until_iter and it > cfg.optim.densify_from_iter
                        and it % cfg.optim.densification_interval == 0) \
