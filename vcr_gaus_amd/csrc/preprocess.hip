@@ -821,7 +821,7 @@ extern "C" int vcr_sh_adam_from_rgb(int N, int sh_degree, const float* view_dirs
     if ((((uintptr_t)features_dc) | ((uintptr_t)features_rest) | ((uintptr_t)m_dc) | ((uintptr_t)v_dc) | ((uintptr_t)m_rest) |
          ((uintptr_t)v_rest)) & 15) { vcr_set_error("vcr_sh_adam_from_rgb: tensors must be 16-byte aligned"); return 1; }
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    const int nblk = (N + 255) / 256, grid = nblk < vcr_side_grid() ? nblk : vcr_side_grid();
+    const int nblk = (N + 255) / 256, grid = nblk < vcr_side_grid(N) ? nblk : vcr_side_grid(N);
     hipLaunchKernelGGL(sh_adam_from_rgb_kernel, dim3(grid), dim3(256), 256 * SH_ROW * sizeof(float), (hipStream_t)stream,
                        N, sh_degree, view_dirs, drgb, features_dc, features_rest, m_dc, v_dc, m_rest, v_rest,
                        (float)(lr_dc / bc1), (float)(lr_rest / bc1), beta1, beta2, eps, (float)sqrt(bc2), grad_scale);
@@ -838,7 +838,7 @@ extern "C" int vcr_sh_adam_from_rgb_views(int N, int sh_degree, int nviews, cons
     if ((((uintptr_t)features_dc) | ((uintptr_t)features_rest) | ((uintptr_t)m_dc) | ((uintptr_t)v_dc) | ((uintptr_t)m_rest) |
          ((uintptr_t)v_rest)) & 15) { vcr_set_error("vcr_sh_adam_from_rgb_views: tensors must be 16-byte aligned"); return 1; }
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    const int nblk = (N + 255) / 256, grid = nblk < vcr_side_grid() ? nblk : vcr_side_grid();
+    const int nblk = (N + 255) / 256, grid = nblk < vcr_side_grid(N) ? nblk : vcr_side_grid(N);
     hipLaunchKernelGGL(sh_adam_from_views_kernel, dim3(grid), dim3(256), 256 * SH_ROW * sizeof(float), (hipStream_t)stream, N,
                        sh_degree, nviews, xyz, campos_all, drgb_all, features_dc, features_rest, m_dc, v_dc, m_rest, v_rest,
                        (float)(lr_dc / bc1), (float)(lr_rest / bc1), beta1, beta2, eps, (float)sqrt(bc2), grad_scale);
@@ -874,9 +874,13 @@ int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, u
     return 0;
 }
 
-int vcr_side_grid() {
-    static const int g = [] { const char* e = getenv("VCR_SIDE_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
-    return g;
+// Workgroups of a side-stream kernel (persistent grid).  One per CU up to 3 M Gaussians: there the sort chain on the main
+// stream is the critical path and must find room beside it; two per CU above, where the 1.15 kB per
+// Gaussian of the SH update make the side stream itself the critical path (5 M: 4.9 vs 4.7 ms/step).  VCR_SIDE_GRID overrides.
+int vcr_side_grid(int N) {
+    static const int g = [] { const char* e = getenv("VCR_SIDE_GRID"); return e ? atoi(e) : 0; }();
+    if (g > 0) return g;
+    return N > 3000000 ? 512 : 256;
 }
 
 int vcr_launch_sh_update_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st) {
@@ -886,7 +890,7 @@ int vcr_launch_sh_update_colour(const VcrRasterArgs& a, GeomState g, hipStream_t
     if (u.sh_degree < 0 || u.sh_degree > 3 || u.step < 1 || u.nviews < 0 || !u.drgb || !u.m_dc || !u.v_dc || !u.m_rest || !u.v_rest ||
         (u.nviews == 0 ? !u.view_dirs : (!u.xyz || !u.campos_all))) { vcr_set_error("sh_update: bad arguments"); return 1; }
     const double bc1 = 1.0 - pow((double)u.beta1, u.step), bc2 = 1.0 - pow((double)u.beta2, u.step);
-    const int nblk = (a.N + 255) / 256, grid = nblk < vcr_side_grid() ? nblk : vcr_side_grid();
+    const int nblk = (a.N + 255) / 256, grid = nblk < vcr_side_grid(a.N) ? nblk : vcr_side_grid(a.N);
     hipLaunchKernelGGL(sh_update_colour_kernel, dim3(grid), dim3(256), 256 * SH_ROW * sizeof(float), st, a, g, u,
                        (float)(u.lr_dc / bc1), (float)(u.lr_rest / bc1), (float)sqrt(bc2));
     VCR_HIP_CHECK(hipGetLastError());
@@ -895,7 +899,7 @@ int vcr_launch_sh_update_colour(const VcrRasterArgs& a, GeomState g, hipStream_t
 
 int vcr_launch_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st) {
     if (a.N == 0) return 0;
-    const int nblk = (a.N + 255) / 256, blocks = nblk < vcr_side_grid() ? nblk : vcr_side_grid();
+    const int nblk = (a.N + 255) / 256, blocks = nblk < vcr_side_grid(a.N) ? nblk : vcr_side_grid(a.N);
     if (a.K == SH_K)
         hipLaunchKernelGGL(colour_fwd_kernel<true>, dim3(blocks), dim3(256), 256 * SH_ROW * sizeof(float), st, a, g);
     else

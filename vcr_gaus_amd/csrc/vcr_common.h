@@ -142,7 +142,7 @@ int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, u
                           uint32_t* ids, uint32_t* vis_slots, bool colour, hipStream_t st);
 int vcr_launch_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st);
 int vcr_launch_sh_update_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st);   // a.sh_update + colour in one pass
-int vcr_side_grid();     // workgroups of a side-stream kernel (VCR_SIDE_GRID, default 512 = two per CU)
+int vcr_side_grid(int N);     // workgroups of a side-stream kernel (one per CU up to 3 M Gaussians, two above; VCR_SIDE_GRID)
 int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const int32_t* radii,
                                    const GradRec* sgrad, const float* sgrad_sem, VcrBackwardIO& io,
                                    hipStream_t st);
