@@ -155,13 +155,13 @@ int vcr_depth_sort(int N, const uint32_t* depth_key, uint32_t* tmp_k, uint32_t* 
 int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const uint32_t* ids_sorted,
                            unsigned long long* status, int64_t R, int tile_bits, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_t, uint32_t* vals_t, uint32_t* keys_b, uint32_t* point_list, uint2* ranges,
-                           uint32_t* tile_order, int num_tiles, uint32_t* totals, void* temp, size_t temp_bytes,
-                           hipStream_t st) {
+                           uint32_t* tile_order, uint32_t* meta, int num_tiles, uint32_t* totals, void* temp,
+                           size_t temp_bytes, hipStream_t st) {
     static const bool no_lpt = getenv("VCR_NO_LPT") != nullptr;          // experiment switches
     static const bool no_snake = getenv("VCR_NO_SNAKE") != nullptr;
     if (R <= 0) {
         VCR_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, st));
-        return vcr_launch_tile_order(num_tiles, ranges, tile_order, false, false, st);   // identity order
+        return vcr_launch_tile_order(num_tiles, ranges, tile_order, meta, false, false, st);   // identity order
     }
     const int blocks = (a.N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS);
     hipLaunchKernelGGL(duplicate_kernel, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, g.rect,
@@ -173,5 +173,5 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
     const int64_t rb = (R + 255) / 256;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)rb), dim3(256), 0, st, R, keys_b, ranges);
     VCR_HIP_CHECK(hipGetLastError());
-    return vcr_launch_tile_order(num_tiles, ranges, tile_order, !no_lpt, !no_snake, st);
+    return vcr_launch_tile_order(num_tiles, ranges, tile_order, meta, !no_lpt, !no_snake, st);
 }

@@ -291,7 +291,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             StageTimer tm(ST_BINNING, st);
             if (vcr_duplicate_and_sort(a, g, out->radii, ids_sorted, dup_status, R, tbits, (uint32_t*)s2, (uint32_t*)(s2 + rbts),
                                        (uint32_t*)(s2 + 2 * rbts), (uint32_t*)(s2 + 3 * rbts), (uint32_t*)(s2 + 4 * rbts),
-                                       b.point_list, b.ranges, b.tile_order, T, totals_tile, s2 + 5 * rbts, tmp2, st))
+                                       b.point_list, b.ranges, b.tile_order, b.meta, T, totals_tile, s2 + 5 * rbts, tmp2, st))
                 return fail_joined();
         }
         out->num_rendered = R;
@@ -313,7 +313,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         BinState b = BinState::view(bin_p, 0, T);
         out->binning = bin_p;
         VCR_HIP_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * (size_t)T, st));
-        if (vcr_launch_tile_order(T, b.ranges, b.tile_order, false, false, st)) return 1;   // identity order
+        if (vcr_launch_tile_order(T, b.ranges, b.tile_order, b.meta, false, false, st)) return 1;   // identity order
         VCR_HIP_CHECK(hipMemsetAsync(img_p, 0, ImageState::bytes(P), st));
         if (a.f_count != 3)
             hipLaunchKernelGGL(fill_background_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, a.f_count ? 3 : C, a.bg,

@@ -41,14 +41,32 @@ struct PixelMap {
     bool inside;
 };
 
-__device__ __forceinline__ PixelMap pixel_of_thread(int tile, int gx, int W, int H) {
+// `sub` < 0: the wave owns the whole 8x8 quad `wv` of the tile.  sub = 0..3 ("split" work items of the heaviest tiles): it
+// owns only the 4x4 sub-block (sub & 1, sub >> 1) of that quad -- lanes keep the 8x8 numbering relative to the sub-block's
+// origin and the 48 lanes outside it are masked like out-of-image pixels, so the culling rectangle (bounding box of the
+// live lanes) shrinks to the sub-block by itself.  Four waves then share a quad's list: 1.9x its shading work, but less
+// than half its serial length, which is what bounds the launch.
+__device__ __forceinline__ PixelMap pixel_of_thread(int tile, int gx, int W, int H, int sub) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     PixelMap p;
-    p.x = (tile % gx) * VCR_TILE + (wv & 1) * 8 + (lane & 7);
-    p.y = (tile / gx) * VCR_TILE + (wv >> 1) * 8 + (lane >> 3);
-    p.inside = p.x < W && p.y < H;
+    const int ox = sub < 0 ? 0 : (sub & 1) * 4, oy = sub < 0 ? 0 : (sub >> 1) * 4;
+    p.x = (tile % gx) * VCR_TILE + (wv & 1) * 8 + ox + (lane & 7);
+    p.y = (tile / gx) * VCR_TILE + (wv >> 1) * 8 + oy + (lane >> 3);
+    p.inside = p.x < W && p.y < H && (sub < 0 || ((lane & 7) < 4 && (lane >> 3) < 4));
     p.pix = p.y * W + p.x;
     return p;
+}
+
+// blockIdx -> (tile, sub): the first 4 * S blocks are the split items of the S heaviest tiles (tile_order is longest-first,
+// S = meta[0] is decided on the device by tile_order_kernel), then one block per remaining tile; the grid is sized for the
+// largest S, surplus blocks return -1.
+__device__ __forceinline__ int work_item(const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ meta, int num_tiles,
+                                         int& sub) {
+    const int b = (int)blockIdx.x, n_split = (int)meta[0];
+    if (b < 4 * n_split) { sub = b & 3; return (int)tile_order[b >> 2]; }
+    sub = -1;
+    const int i = b - 3 * n_split;
+    return i < num_tiles ? (int)tile_order[i] : -1;
 }
 
 // ================= one wave = one 8x8 quad, no LDS, no barriers ==========================================
@@ -100,13 +118,15 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
                                                                const float* __restrict__ semv,
                                                                const uint32_t* __restrict__ point_list,
                                                                const uint2* __restrict__ ranges,
-                                                               const uint32_t* __restrict__ tile_order,
-                                                               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                               const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ meta,
+                                                               int num_tiles, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                                float* __restrict__ moments, float* __restrict__ out,
                                                                int32_t* __restrict__ count, float* __restrict__ score) {
     const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
-    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
-    const PixelMap pm = pixel_of_thread(tile, gx, a.W, a.H);
+    int sub;
+    const int tile = work_item(tile_order, meta, num_tiles, sub);
+    if (tile < 0) return;
+    const PixelMap pm = pixel_of_thread(tile, gx, a.W, a.H, sub);
     const uint2 range = ranges[tile];
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -117,7 +137,8 @@ __global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, 
     int n_surv = 0, n_hit = 0, n_chunks = 0;
     long long t_cull = 0, t_surv = 0, t_mark = 0;
 #endif
-    const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8), Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8);
+    const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8 + (sub < 0 ? 0 : (sub & 1) * 4));
+    const float Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8 + (sub < 0 ? 0 : (sub >> 1) * 4));
     const f2 fxy = {(float)pm.x, (float)pm.y};
     float rx = 0.f, ry = 0.f, rz = 1.f;
     if (ISECT && pm.inside) { rx = a.dirs[pm.pix]; ry = a.dirs[P + pm.pix]; rz = a.dirs[2 * P + pm.pix]; }
@@ -292,21 +313,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 
                                                                const float* __restrict__ semv,
                                                                const uint32_t* __restrict__ point_list,
                                                                const uint2* __restrict__ ranges,
-                                                               const uint32_t* __restrict__ tile_order,
-                                                               const float* __restrict__ final_T,
+                                                               const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ meta,
+                                                               int num_tiles, const float* __restrict__ final_T,
                                                                const uint32_t* __restrict__ n_contrib,
                                                                const float* __restrict__ moments,
                                                                const float* __restrict__ dL_dout, GradRec* __restrict__ sgrad,
                                                                float* __restrict__ sgrad_sem) {
     const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
-    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
-    const PixelMap pm = pixel_of_thread(tile, gx, a.W, a.H);
+    int sub;
+    const int tile = work_item(tile_order, meta, num_tiles, sub);
+    if (tile < 0) return;
+    const PixelMap pm = pixel_of_thread(tile, gx, a.W, a.H, sub);
     const uint2 range = ranges[tile];
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ float4 s_rec_all[4 * 256];                 // per wave: 4 planes x 64 slots x 16 B
     float4* const srec = s_rec_all + wv * 256;
-    const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8), Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8);
+    const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8 + (sub < 0 ? 0 : (sub & 1) * 4));
+    const float Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8 + (sub < 0 ? 0 : (sub >> 1) * 4));
     const f2 fxy = {(float)pm.x, (float)pm.y};
     float rx = 0.f, ry = 0.f, rz = 1.f;
     if (ISECT && pm.inside) { rx = a.dirs[pm.pix]; ry = a.dirs[P + pm.pix]; rz = a.dirs[2 * P + pm.pix]; }
@@ -468,8 +492,8 @@ template <int S, bool ISECT, int ND>
 int launch_fwd_fc(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o, int tiles,
                   hipStream_t st) {
 #define VCR_FWD(FC, NDD)                                                                                          \
-    hipLaunchKernelGGL((composite_fwd_v2_kernel<S, ISECT, FC, NDD>), dim3(tiles), dim3(256), 0, st, a, g.rec, g.sem, \
-                       b.point_list, b.ranges, b.tile_order, im.final_T, im.n_contrib, im.moments, o.out, o.count, o.score)
+    hipLaunchKernelGGL((composite_fwd_v2_kernel<S, ISECT, FC, NDD>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
+                       b.point_list, b.ranges, b.tile_order, b.meta, tiles, im.final_T, im.n_contrib, im.moments, o.out, o.count, o.score)
     switch (a.f_count) {
         case 0: VCR_FWD(0, ND); break;
         case 1: case 2: VCR_FWD(1, 0); break;
@@ -496,8 +520,8 @@ template <bool ISECT, int ND>
 int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, const float* dL_dout, GradRec* sgrad,
                  float* sgrad_sem, int tiles, hipStream_t st) {
 #define VCR_BWD(SS)                                                                                              \
-    hipLaunchKernelGGL((composite_bwd_v2_kernel<SS, ISECT, ND>), dim3(tiles), dim3(256), 0, st, a, g.rec, g.sem,  \
-                       b.point_list, b.ranges, b.tile_order, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem)
+    hipLaunchKernelGGL((composite_bwd_v2_kernel<SS, ISECT, ND>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem,  \
+                       b.point_list, b.ranges, b.tile_order, b.meta, tiles, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem)
     switch (a.S) {
         case 0: VCR_BWD(0); break;
         case 1: VCR_BWD(1); break;

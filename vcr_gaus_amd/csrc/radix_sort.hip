@@ -10,6 +10,7 @@
 //               of a digit inside a chunk are found with one ballot per digit bit) and scatters.
 // `totals` (VCR_SORT_TOTALS_WORDS words) must be zero on entry; the caller zeroes it together with its other counters.
 #include "vcr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -197,18 +198,41 @@ __global__ void __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(8
 // Block-scheduling order of the compositing kernels: tiles by list length, longest first, folded boustrophedon-wise
 // with the period of the chip.  The order is a placement policy, so lengths are quantised
 // (2048 classes of 4 entries) and ties land in arbitrary order: ONE single-workgroup counting sort instead of a device-wide sort.
+// Also decides how many of the heaviest tiles the compositing kernels launch as SPLIT work items (four workgroups of 4x4
+// sub-blocks instead of one of 8x8 quads): only as many as there are idle workgroup slots on the chip,
+// S = (slots - non-empty tiles) / 3 -- splitting shortens the serial chains of the longest lists (c2, 300 k Gaussians:
+// compositing forward 221 -> 160 us, backward 467 -> 352 us) but costs 1.9x their shading work, which only pays while
+// the SIMDs are not full (1 M Gaussians / 1080p: none).  meta[0] = S, meta[1] = non-empty tiles, meta[2] = longest list.
 __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order,
-                                                        int lpt, int snake) {
+                                                        uint32_t* __restrict__ meta, int split_slots, int lpt, int snake) {
     constexpr int BINS = 2048, SH = 2;                 // classes of 4 list entries; lists >= 8188 share the first class
     __shared__ uint32_t hist[BINS];
     __shared__ uint32_t wsum[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    if (!lpt) { for (int i = t; i < T; i += 1024) order[i] = (uint32_t)i; return; }
+    if (!lpt) {
+        for (int i = t; i < T; i += 1024) order[i] = (uint32_t)i;
+        if (t < VCR_BIN_META_WORDS) meta[t] = 0u;
+        return;
+    }
+    __shared__ uint32_t s_ne, s_max;
     hist[t] = 0; hist[t + 1024] = 0;
+    if (t == 0) { s_ne = 0; s_max = 0; }
     __syncthreads();
-    for (int i = t; i < T; i += 1024)
-        atomicAdd(&hist[BINS - 1 - min((ranges[i].y - ranges[i].x) >> SH, (uint32_t)(BINS - 1))], 1u);   // bin 0 = longest
+    uint32_t ne = 0, mx = 0;
+    for (int i = t; i < T; i += 1024) {
+        const uint32_t len = ranges[i].y - ranges[i].x;
+        ne += len > 0; mx = max(mx, len);
+        atomicAdd(&hist[BINS - 1 - min(len >> SH, (uint32_t)(BINS - 1))], 1u);   // bin 0 = longest
+    }
+    for (int o = 32; o > 0; o >>= 1) { ne += (uint32_t)__shfl_xor((int)ne, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
+    if (lane == 0) { atomicAdd(&s_ne, ne); atomicMax(&s_max, mx); }
     __syncthreads();
+    if (t == 0) {
+        const int idle = split_slots - (int)s_ne;
+        int S = idle <= 0 ? 0 : min(min(idle / 3, (int)s_ne), VCR_SPLIT_MAX);
+        if (S < 16) S = 0;                               // (a handful of split items only shifts the launch order of the rest)
+        meta[0] = (uint32_t)S; meta[1] = s_ne; meta[2] = s_max;
+    }
     // exclusive scan of the 2048 classes: 2 per lane, wave scan, 16 wave totals
     const uint32_t h0 = hist[2 * t], h1 = hist[2 * t + 1];
     uint32_t inc = h0 + h1;
@@ -275,8 +299,19 @@ int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, 
     return 0;
 }
 
-int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, bool lpt, bool snake, hipStream_t st) {
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, T, ranges, order, lpt ? 1 : 0, snake ? 1 : 0);
+int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, uint32_t* meta, bool lpt, bool snake, hipStream_t st) {
+    // workgroup slots of the compositing kernels on the chip: 5 resident 256-thread workgroups per CU (VCR_SPLIT_SLOTS overrides;
+    // 0 disables the split work items)
+    static const int slots = [] {
+        const char* e = getenv("VCR_SPLIT_SLOTS");
+        if (e) return atoi(e);
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        return 5 * cus;
+    }();
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, T, ranges, order, meta, slots, lpt ? 1 : 0, snake ? 1 : 0);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }

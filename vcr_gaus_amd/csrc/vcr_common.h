@@ -74,20 +74,25 @@ struct GeomState {
     }
 };
 
+#define VCR_BIN_META_WORDS 16
+#define VCR_SPLIT_MAX 256          // at most this many tiles are split (one band of the launch order)
 struct BinState {
     uint32_t* point_list;  // [R] Gaussian ids, (tile, depth, id)-ordered
     uint2* ranges;         // [T] per-tile [begin,end)
     uint32_t* tile_order;  // [T] tile ids, longest list first (block scheduling order)
+    uint32_t* meta;        // [VCR_BIN_META_WORDS] written by tile_order: [0] number S of heaviest tiles launched as split work
+                           //     items (composite.hip), [1] non-empty tiles, [2] longest tile list
     static size_t bytes(int64_t R, int T) {
         return vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1)) + vcr_align(sizeof(uint2) * (size_t)T) +
-               vcr_align(sizeof(uint32_t) * (size_t)T);
+               vcr_align(sizeof(uint32_t) * (size_t)T) + vcr_align(sizeof(uint32_t) * VCR_BIN_META_WORDS);
     }
     static BinState view(void* p, int64_t R, int T) {
         BinState b;
         char* c = (char*)p;
         b.point_list = (uint32_t*)c;  c += vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1));
         b.ranges = (uint2*)c;         c += vcr_align(sizeof(uint2) * (size_t)T);
-        b.tile_order = (uint32_t*)c;
+        b.tile_order = (uint32_t*)c;  c += vcr_align(sizeof(uint32_t) * (size_t)T);
+        b.meta = (uint32_t*)c;
         return b;
     }
 };
@@ -153,15 +158,15 @@ int vcr_depth_sort(int N, const uint32_t* depth_key, uint32_t* tmp_k, uint32_t* 
 int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const uint32_t* ids_sorted,
                            unsigned long long* status, int64_t R, int tile_bits, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_t, uint32_t* vals_t, uint32_t* keys_b, uint32_t* point_list, uint2* ranges,
-                           uint32_t* tile_order, int num_tiles, uint32_t* totals, void* temp, size_t temp_bytes,
-                           hipStream_t st);
+                           uint32_t* tile_order, uint32_t* meta, int num_tiles, uint32_t* totals, void* temp,
+                           size_t temp_bytes, hipStream_t st);
 // radix_sort.hip: hand-written stable radix sort of (u32 key, u32 value) pairs and the block-scheduling order
 #define VCR_SORT_TOTALS_WORDS 1024            // 4 passes x 256 digit totals, zero on entry
 size_t vcr_sort_scratch_bytes(int64_t n);
 int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_tmp, uint32_t* vals_tmp,
                    uint32_t* keys_out, uint32_t* vals_out, int begin_bit, int end_bit, uint32_t* hist, uint32_t* totals,
                    hipStream_t st);
-int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, bool lpt, bool snake, hipStream_t st);
+int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, uint32_t* meta, bool lpt, bool snake, hipStream_t st);
 int vcr_launch_composite_forward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o,
                                  hipStream_t st);
 int vcr_launch_composite_backward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
