@@ -37,18 +37,18 @@ class _FusedLosses(torch.autograd.Function):
         st = _lib.stream_of(o)
         base = o.data_ptr()
         n2, n3, n9 = lib.vcr_sums_elems(2), lib.vcr_sums_elems(3), lib.vcr_sums_elems(9)
-        # ONE buffer for all reductions and the six results (+ the weighted total), which live in its tail.  It is reused
+        # ONE buffer for all reductions.  It is reused
         # from step to step: the finalize kernel leaves the slots zeroed again (a fresh zero-filled one only if the previous
         # forward's backward has not run yet).
         ent = _SUMS.get(dev)
-        if ent is not None and not ent[1] and ent[0].numel() == n2 + n3 + n9 + 4:
+        if ent is not None and not ent[1] and ent[0].numel() == n2 + n3 + n9:
             sums = ent[0]
         else:
-            sums = torch.zeros(n2 + n3 + n9 + 4, dtype=torch.float64, device=dev)
+            sums = torch.zeros(n2 + n3 + n9, dtype=torch.float64, device=dev)
             ent = _SUMS[dev] = [sums, False]
         ent[1] = torch.is_grad_enabled() and ent[0] is sums
         ctx.sums_entry = ent if ent[0] is sums else None
-        res8 = sums[n2 + n3 + n9:].view(torch.float32)
+        res8 = torch.empty(8, dtype=torch.float32, device=dev)      # (fresh per call: the returned loss values must not alias the reused buffer)
         res, total = res8[:6], torch.empty((), device=dev)       # (not a view: a view output costs a select_backward)
         s_ssim, s_scale, s_nrm = sums.data_ptr(), sums.data_ptr() + 8 * n2, sums.data_ptr() + 8 * (n2 + n3)
         rp = lambda k: res.data_ptr() + 4 * k
