@@ -17,6 +17,16 @@ n, views, W, H, focal, sem = synthetic.WORKLOADS[wl]
 raw = synthetic.make_gaussians(n, seed=0, sem_channels=sem)
 cams = synthetic.make_cameras(8, W, H, focal, device=dev)
 tr = BenchTrainer(raw, cams, dev)
+import contextlib
+hp = torch.cuda.Stream(device=dev, priority=-1) if os.environ.get("AB_HIGHPRIO") else None
+ctx = (lambda: torch.cuda.stream(hp)) if hp is not None else contextlib.nullcontext
+if hp is not None:
+    hp.wait_stream(torch.cuda.current_stream(dev))
+_step = tr.step
+def step(i):
+    with ctx():
+        _step(i)
+tr.step = step
 tr.prime()
 for i in range(10):
     tr.step(i)
