@@ -264,3 +264,55 @@ def test_empty_model_and_single_gaussian(device):
                                     opacities=one["opac"], scales=one["scales"] * 20, rotations=one["rots"],
                                     normals_precomp=one["normals"], dirs=dirs.to(device))
     assert torch.isfinite(out1).all()
+
+
+def _fwd_bwd_vs_oracle(device, cam, inp, dirs, bg, seed=0, fwd_budget=None):
+    (ref, rradii, st), rl = util.oracle_forward(cam, inp, dirs, bg, dtype=torch.float64, requires_grad=True)
+    (out, radii), hl = util.hip_forward(cam, inp, dirs, bg, device, requires_grad=True)
+    assert torch.equal(radii.cpu(), rradii)
+    bad = util.bad_pixels(out, ref)
+    assert bad <= (util.pixel_budget(ref) if fwd_budget is None else fwd_budget), f"{bad} mismatching pixels"
+    wgt = torch.randn(ref.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
+    (ref * wgt).sum().backward()
+    (out * wgt.float().to(device)).sum().backward()
+    return out, ref, hl, rl, st
+
+
+def test_edge_tiny_image_and_few_gaussians(device):
+    """A single partial tile (7x5 pixels) and N = 1, 2, 3 Gaussians: ragged everything."""
+    for n, (W, H) in [(1, (7, 5)), (2, (7, 5)), (3, (17, 9)), (37, (33, 16))]:
+        cam, inp, dirs = util.make_case(n, W, H, 12.0, seed=50 + n, scale_mult=40.0)
+        inp["opac"] = inp["opac"].clamp(min=0.3)
+        out, ref, hl, rl, st = _fwd_bwd_vs_oracle(device, cam, inp, dirs, torch.tensor([0.2, 0.4, 0.6]), fwd_budget=1)
+        for k in ["means3D", "opac", "scales", "rots", "shs"]:
+            if float(rl[k].grad.abs().max()) > 0:
+                util.assert_grads_close(hl[k].grad, rl[k].grad, f"n={n}:{k}", p999_tol=1e-1)
+
+
+def test_edge_screen_filling_gaussians(device):
+    """Gaussians far larger than the image (radius >> W: every tile of every one; tiles_touched = whole grid) mixed with
+    small ones: the load-balanced instance emission and the culling rectangles at their limits."""
+    cam, inp, dirs = util.make_case(300, 96, 64, 80.0, seed=61, scale_mult=6.0)
+    inp["scales"][:12] = inp["scales"][:12] * 200.0              # a dozen giants
+    inp["opac"][:12] = 0.08
+    out, ref, hl, rl, st = _fwd_bwd_vs_oracle(device, cam, inp, dirs, torch.tensor([0.1, 0.1, 0.1]))
+    assert st["R"] >= 12 * 24                                    # the giants really cover all 6 x 4 tiles
+    for k in ["means3D", "opac", "scales", "rots", "shs", "normals"]:
+        util.assert_grads_close(hl[k].grad, rl[k].grad, k)
+
+
+def test_edge_equal_depths_and_opacity_extremes(device):
+    """Exact depth ties (duplicated Gaussians: order = index order, U7), opacities below 1/255 (never contribute),
+    opacities ~1 (alpha clamps at 0.99) and a saturating stack (T < 1e-4 early termination)."""
+    cam, inp, dirs = util.make_case(600, 96, 64, 80.0, seed=62, scale_mult=8.0)
+    for k in ["means3D", "scales", "rots", "normals"]:
+        inp[k][300:600] = inp[k][0:300]                          # second half = exact copies (same depth, same footprint)
+    inp["shs"][300:600] = -inp["shs"][0:300]                     # ... with different colours, so the order matters
+    inp["opac"][:100] = 0.999
+    inp["opac"][100:150] = 0.0035                                # < 1/255
+    inp["opac"][300:400] = 0.999
+    out, ref, hl, rl, st = _fwd_bwd_vs_oracle(device, cam, inp, dirs, torch.tensor([0.0, 0.5, 1.0]))
+    assert float(hl["opac"].grad[100:150].abs().max()) == 0.0 and float(rl["opac"].grad[100:150].abs().max()) == 0.0
+    assert float(ref[7].max()) > 0.999                            # saturated pixels exist
+    for k in ["means3D", "opac", "scales", "rots", "shs", "normals"]:
+        util.assert_grads_close(hl[k].grad, rl[k].grad, k)
