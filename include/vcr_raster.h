@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 10
+#define VCR_ABI_VERSION 11
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -84,6 +84,8 @@ typedef struct VcrRasterArgs {
                                    the sort chain and ahead of the colour evaluation */
     void* colour_stream_hook_user;
     const VcrShUpdate* sh_update;   /* optional, with colour_stream: see VcrShUpdate */
+    void* sort_stream;          /* optional third HIP stream: the depth keys and the depth sort of the N Gaussians run there,
+                                   beside the projection, and are joined before the tile instances are emitted */
 } VcrRasterArgs;
 
 /* Forward outputs.  `out`, `radii`, counters are caller-allocated. */

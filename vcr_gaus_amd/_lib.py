@@ -16,7 +16,7 @@ c_int_p = C.POINTER(C.c_int32)
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 BUF_GEOM, BUF_BINNING, BUF_IMAGE, BUF_SCRATCH = 0, 1, 2, 3
-ABI_VERSION = 10         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
+ABI_VERSION = 11         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
 
 
 class VcrShUpdate(C.Structure):
@@ -48,7 +48,7 @@ class VcrRasterArgs(C.Structure):
         ("means3D", C.c_void_p), ("shs", C.c_void_p), ("shs_rest", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("normals_precomp", C.c_void_p), ("semantics_precomp", C.c_void_p), ("opacities", C.c_void_p),
         ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("dirs", C.c_void_p),
-        ("colour_stream", C.c_void_p), ("colour_stream_hook", C.c_void_p), ("colour_stream_hook_user", C.c_void_p), ("sh_update", C.c_void_p),
+        ("colour_stream", C.c_void_p), ("colour_stream_hook", C.c_void_p), ("colour_stream_hook_user", C.c_void_p), ("sh_update", C.c_void_p), ("sort_stream", C.c_void_p),
     ]
 
 

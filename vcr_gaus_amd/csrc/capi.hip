@@ -87,9 +87,10 @@ Readback* pinned_readback() {
     return p;
 }
 
-// events of the optional colour stream (VcrRasterArgs.colour_stream): geometry ready -> colours ready
+// events of the optional streams: [0] geometry ready -> [1] colours ready (VcrRasterArgs.colour_stream);
+// [2] inputs ready -> [3] depth order ready (VcrRasterArgs.sort_stream)
 hipEvent_t colour_event(int k) {
-    static thread_local hipEvent_t e[2] = {nullptr, nullptr};
+    static thread_local hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
     if (!e[k] && hipEventCreateWithFlags(&e[k], hipEventDisableTiming) != hipSuccess) e[k] = nullptr;
     return e[k];
 }
@@ -219,44 +220,69 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         uint32_t* totals_tile = totals_depth + VCR_SORT_TOTALS_WORDS;
         void* temp1 = s1 + 5 * nb + ctr_bytes + status_bytes;
         VCR_HIP_CHECK(hipMemsetAsync(ctr, 0, ctr_bytes + status_bytes, st));
+        // Work launched on the optional streams must be joined on EVERY exit (the scratch buffers go back to the caller's
+        // stream-ordered allocator when this call returns): error returns go through join_streams().
+        bool sort_launched = false, colour_launched = false;
+        auto join_streams = [&]() {
+            if (sort_launched) (void)hipStreamWaitEvent(st, colour_event(3), 0);
+            if (colour_launched) (void)hipStreamWaitEvent(st, colour_event(1), 0);
+            return 1;
+        };
+        // optional sort stream: depth keys + depth sort of the N Gaussians start now, beside the projection
+        const bool split_sort = a.sort_stream && a.sort_stream != stream;
+        if (split_sort) {
+            hipEvent_t e_in = colour_event(2), e_sorted = colour_event(3);
+            if (!e_in || !e_sorted) { vcr_set_error("hipEventCreate for the sort stream failed"); return 1; }
+            hipStream_t ss = (hipStream_t)a.sort_stream;
+            VCR_HIP_CHECK(hipEventRecord(e_in, st));
+            VCR_HIP_CHECK(hipStreamWaitEvent(ss, e_in, 0));
+            int rc = vcr_launch_depth_keys(a, depth_key, ss);
+            if (!rc) {
+                StageTimer tm(ST_DEPTHSORT, ss);
+                rc = vcr_depth_sort(N, depth_key, ids, tmp_v, key_sorted, ids_sorted, totals_depth, temp1, ss);
+            }
+            VCR_HIP_CHECK(hipEventRecord(e_sorted, ss));
+            sort_launched = true;
+            if (rc) return join_streams();
+        }
         // two-stream form: geometry here, SH -> RGB on the colour stream behind whatever the caller queued there
         const bool split_colour = a.colour_stream && a.colour_stream != stream && a.shs && !a.colors_precomp;
-        if (a.sh_update && !split_colour) { vcr_set_error("sh_update needs colour_stream and SH colours"); return 1; }
+        if (a.sh_update && !split_colour) { vcr_set_error("sh_update needs colour_stream and SH colours"); return join_streams(); }
         {
             StageTimer tm(ST_PREPROCESS, st);
-            if (vcr_launch_preprocess(a, g, out->radii, depth_key, ids, vis_counter, !split_colour, st)) return 1;
+            if (vcr_launch_preprocess(a, g, out->radii, split_sort ? nullptr : depth_key, ids, vis_counter, !split_colour, st))
+                return join_streams();
         }
         if (split_colour) {
             hipEvent_t e_geo = colour_event(0), e_col = colour_event(1);
-            if (!e_geo || !e_col) { vcr_set_error("hipEventCreate for the colour stream failed"); return 1; }
+            if (!e_geo || !e_col) { vcr_set_error("hipEventCreate for the colour stream failed"); return join_streams(); }
             hipStream_t cs = (hipStream_t)a.colour_stream;
             VCR_HIP_CHECK(hipEventRecord(e_geo, st));
             VCR_HIP_CHECK(hipStreamWaitEvent(cs, e_geo, 0));
             if (a.colour_stream_hook) a.colour_stream_hook(a.colour_stream_hook_user);
-            if (a.sh_update ? vcr_launch_sh_update_colour(a, g, cs) : vcr_launch_colour(a, g, cs)) return 1;
+            const int rc = a.sh_update ? vcr_launch_sh_update_colour(a, g, cs) : vcr_launch_colour(a, g, cs);
             VCR_HIP_CHECK(hipEventRecord(e_col, cs));
+            colour_launched = true;
+            if (rc) return join_streams();
         }
         // R and V go back to the host now; the depth sort and the offsets scan do not need them and keep the GPU busy
         // while the host wakes up, sizes the instance buffers and enqueues the rest
         Readback* rb = pinned_readback();
         Published* pub = pinned_published();
         hipEvent_t ev = readback_event();
-        if (!rb || !pub || !ev) { vcr_set_error("hipHostMalloc / hipEventCreate for the readback failed"); return 1; }
+        if (!rb || !pub || !ev) { vcr_set_error("hipHostMalloc / hipEventCreate for the readback failed"); return join_streams(); }
         static thread_local uint32_t seq_counter = 0;
         const uint32_t seq = ++seq_counter ? seq_counter : ++seq_counter;      // never 0
         hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(256), 0, st, vis_counter, pub, seq);
         VCR_HIP_CHECK(hipGetLastError());
         VCR_HIP_CHECK(hipEventRecord(ev, st));
-        {
+        if (!split_sort) {
             StageTimer tm(ST_DEPTHSORT, st);
-            if (vcr_depth_sort(N, depth_key, ids, tmp_v, key_sorted, ids_sorted, totals_depth, temp1, st)) {
-                if (split_colour) (void)hipStreamWaitEvent(st, colour_event(1), 0);
-                return 1;
-            }
+            if (vcr_depth_sort(N, depth_key, ids, tmp_v, key_sorted, ids_sorted, totals_depth, temp1, st)) return join_streams();
         }
         // From here on the colour stream may already be running work that consumed the caller's pending SH update: every
         // error return below first joins it (the caller's retry / error handling must not see an un-joined stream).
-        auto fail_joined = [&]() { if (split_colour) (void)hipStreamWaitEvent(st, colour_event(1), 0); return 1; };
+        auto fail_joined = join_streams;
         {   // spin on the published sequence number for at most ~2 ms of wall time, then sleep in the event (which also
             // surfaces a device fault or a failed launch as an error instead of a hang)
             const auto t_spin = std::chrono::steady_clock::now();
@@ -287,6 +313,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         const size_t rbts = vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1));
         char* s2 = (char*)alloc(user, VCR_BUF_SCRATCH, 5 * rbts + tmp2);
         if (!s2) { vcr_set_error("allocator returned NULL"); return fail_joined(); }
+        if (split_sort) VCR_HIP_CHECK(hipStreamWaitEvent(st, colour_event(3), 0));       // the depth order is needed from here on
         {
             StageTimer tm(ST_BINNING, st);
             if (vcr_duplicate_and_sort(a, g, out->radii, ids_sorted, dup_status, R, tbits, (uint32_t*)s2, (uint32_t*)(s2 + rbts),

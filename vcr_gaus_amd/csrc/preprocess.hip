@@ -205,11 +205,10 @@ __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const
                                                    uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
                                                    const float* s_sh, int i) {
     if (i >= a.N) return 0;
-    ids[i] = i;
     radii[i] = 0;
     g.tiles[i] = 0;
     g.rect[i] = make_uint2(0u, 0u);
-    depth_key[i] = 0xFFFFFFFFu;
+    if (depth_key) depth_key[i] = 0xFFFFFFFFu;        // (NULL: the keys come from depth_key_kernel on the sort stream)
 
     const Cam cam = load_cam(a);
     const float p[3] = {a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2]};
@@ -294,7 +293,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const
     g.tiles[i] = (uint32_t)ntiles;
     g.rect[i] = make_uint2((uint32_t)xmin | ((uint32_t)ymin << 16), (uint32_t)(xmax - xmin) | ((uint32_t)(ymax - ymin) << 16));
     radii[i] = (int32_t)rad;
-    depth_key[i] = __float_as_uint(pr.t[2]);
+    if (depth_key) depth_key[i] = __float_as_uint(pr.t[2]);
     return (uint32_t)ntiles;
 }
 
@@ -853,6 +852,26 @@ extern "C" int vcr_sh_grad_from_rgb(int N, int sh_degree, int nviews, const floa
     if (sh_degree < 0 || sh_degree > 3 || nviews <= 0) { vcr_set_error("vcr_sh_grad_from_rgb: bad degree/views"); return 1; }
     hipLaunchKernelGGL(sh_grad_from_rgb_kernel, dim3((N + 255) / 256), dim3(256), 256 * SH_ROW * sizeof(float),
                        (hipStream_t)stream, N, sh_degree, nviews, xyz, campos_all, drgb_all, d_features_dc, d_features_rest);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// View depth of every Gaussian as a radix-sortable key, without the rest of the projection: lets the depth sort start on
+// its own stream before (and beside) preprocess_fwd.  Same project() as preprocess_one, so the keys are bit-identical;
+// Gaussians that the projection culls for other reasons keep a real key here, which is harmless (they emit no instances).
+__global__ void __launch_bounds__(256) depth_key_kernel(VcrRasterArgs a, uint32_t* __restrict__ depth_key) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.N) return;
+    const Cam cam = load_cam(a);
+    const float p[3] = {a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2]};
+    Proj pr;
+    project(a, cam, p, pr);
+    depth_key[i] = pr.t[2] > VCR_NEAR ? __float_as_uint(pr.t[2]) : 0xFFFFFFFFu;
+}
+
+int vcr_launch_depth_keys(const VcrRasterArgs& a, uint32_t* depth_key, hipStream_t st) {
+    if (a.N == 0) return 0;
+    hipLaunchKernelGGL(depth_key_kernel, dim3((a.N + 255) / 256), dim3(256), 0, st, a, depth_key);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }

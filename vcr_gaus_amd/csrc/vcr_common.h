@@ -145,6 +145,7 @@ void vcr_set_error(const char* fmt, ...);
 #define VCR_VIS_SLOTS 1024                    // counter slots for visible Gaussians / tile instances
 int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key,
                           uint32_t* ids, uint32_t* vis_slots, bool colour, hipStream_t st);
+int vcr_launch_depth_keys(const VcrRasterArgs& a, uint32_t* depth_key, hipStream_t st);
 int vcr_launch_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st);
 int vcr_launch_sh_update_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st);   // a.sh_update + colour in one pass
 int vcr_side_grid(int N);     // workgroups of a side-stream kernel (one per CU up to 3 M Gaussians, two above; VCR_SIDE_GRID)

@@ -73,22 +73,23 @@ last_drgb = {}          # "drgb" [N,3] and "dirs" [N,3] (unit view directions) o
 COLOUR_STREAM = None    # torch.cuda.Stream: f_count = 0 forwards evaluate SH -> RGB there (VcrRasterArgs.colour_stream)
 COLOUR_HOOK = None      # callable(): enqueue caller work on COLOUR_STREAM ahead of the colour evaluation (colour_stream_hook)
 COLOUR_SH_UPDATE = None  # callable() -> (_lib.VcrShUpdate, keep-alive) or None: SH Adam step fused into the colour evaluation
+SORT_STREAM = None      # torch.cuda.Stream: depth keys + depth sort of f_count = 0 forwards run there, beside the projection
 
 
 import contextlib
 
 
 @contextlib.contextmanager
-def modes(sh_grad="full", colour_stream=None, colour_hook=None, colour_sh_update=None):
+def modes(sh_grad="full", colour_stream=None, colour_hook=None, colour_sh_update=None, sort_stream=None):
     """Scoped setting of SH_GRAD_MODE / COLOUR_STREAM / COLOUR_HOOK / COLOUR_SH_UPDATE for the forwards issued inside the
     block (the backward of such a forward keeps the mode it was recorded with)."""
-    global SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE
-    old = (SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE)
-    SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE = sh_grad, colour_stream, colour_hook, colour_sh_update
+    global SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE, SORT_STREAM
+    old = (SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE, SORT_STREAM)
+    SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE, SORT_STREAM = sh_grad, colour_stream, colour_hook, colour_sh_update, sort_stream
     try:
         yield
     finally:
-        SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE = old
+        SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE, SORT_STREAM = old
 
 
 NUM_DIST = 0      # trailing channels, the fork's compile-time `NUM_DIST` (README.md:155): 0, 1 = distortion, 2 = sum w d, sum w d^2
@@ -122,6 +123,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                rotations=_ptr(t["rots"]), cov3D_precomp=_ptr(t["cov"]), dirs=_ptr(t["dirs"]))
         fc = int(rs.f_count)
         hook = upd = None
+        if SORT_STREAM is not None and fc == 0 and N > 0:
+            a.sort_stream = SORT_STREAM.cuda_stream
         if COLOUR_STREAM is not None and fc == 0 and t["shs"] is not None:
             a.colour_stream = COLOUR_STREAM.cuda_stream
             if COLOUR_SH_UPDATE is not None and t["shs_rest"] is not None and N > 0:
