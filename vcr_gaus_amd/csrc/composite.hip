@@ -111,10 +111,21 @@ __device__ __forceinline__ void live_box(unsigned long long live, float X0, floa
 #ifndef VCR_KO
 #define VCR_KO 0
 #endif
+#ifndef VCR_BWD_WAVES
+#define VCR_BWD_WAVES 4          // waves per SIMD the backward is compiled for: 4 (no spills) 540 us, 5 (5 spills) 560 us, 6 657 us, 3 539 us at 1 M / 1080p
+#endif
 
 
+#ifndef VCR_FWD_WAVES
+#define VCR_FWD_WAVES 0          // 0: compiler's choice (79 VGPRs, 6 waves per SIMD)
+#endif
+#if VCR_FWD_WAVES > 0
+#define VCR_FWD_ATTR __attribute__((amdgpu_waves_per_eu(VCR_FWD_WAVES)))
+#else
+#define VCR_FWD_ATTR
+#endif
 template <int S, bool ISECT, int FC, int ND>
-__global__ void __launch_bounds__(256) composite_fwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
+__global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
                                                                const float* __restrict__ semv,
                                                                const uint32_t* __restrict__ point_list,
                                                                const uint2* __restrict__ ranges,
@@ -309,7 +320,7 @@ _Pragma("unroll")                                                               
 }
 
 template <int S, bool ISECT, int ND>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 0 && ND == 0) ? 5 : 4))) composite_bwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 0 && ND == 0) ? VCR_BWD_WAVES : 4))) composite_bwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
                                                                const float* __restrict__ semv,
                                                                const uint32_t* __restrict__ point_list,
                                                                const uint2* __restrict__ ranges,
