@@ -206,10 +206,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    # VCR_DIST_BACKEND=gloo lets several ranks share one GPU (a functional check of the multi-rank path on a 1-GPU box;
+    # RCCL refuses two ranks on one device).  The driver's runs use the default: one rank per GPU over RCCL.
+    backend = os.environ.get("VCR_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=dev) if backend == "nccl" else dist.init_process_group(backend)
 
     from vcr_gaus_amd import _lib, synthetic
     from vcr_gaus_amd.graphics_utils import get_all_px_dir
