@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--focal", type=float, default=300.0)
     ap.add_argument("--views", type=int, default=24)
     ap.add_argument("--iters", type=int, default=1500)
-    ap.add_argument("--preset", default="dtu")
+    ap.add_argument("--preset", default="dtu_c3")
     args = ap.parse_args()
     from vcr_gaus_amd import synthetic
     from vcr_gaus_amd.gaussian_renderer import render

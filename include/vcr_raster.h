@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 11
+#define VCR_ABI_VERSION 12
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -277,6 +277,14 @@ size_t vcr_rows_plan_bytes(int N);
 int vcr_rows_plan(int N, const uint8_t* mask, uint32_t* offsets, void* stream);
 int vcr_rows_move(int N, const uint8_t* mask, const uint32_t* offsets, const VcrRowArrays* arrays, int mode, int copies,
                   void* stream);
+/* Semantic loss (gaussian_renderer/__init__.py:146-148 + trainer.py:304-307): 1x1-conv classifier on the rendered feature
+ * planes sem [S,P] + F.cross_entropy(logits, labels) / log(K) in one pass each way.  W [K,S] / b [K]: the classifier's
+ * parameters (device); labels: device int64 [P]; S <= 4, 2 <= K <= 8.  The backward writes d(sem) [S,P] and the
+ * classifier's gradients dW [K,S], db [K] (device). */
+int vcr_semantic_ce_forward(long long P, int S, int K, const float* sem, const float* W, const float* b,
+                            const long long* labels, double* sums1, float* loss, void* stream);
+int vcr_semantic_ce_backward(long long P, int S, int K, const float* sem, const float* W, const float* b,
+                             const long long* labels, const float* gout, float* dsem, float* dW, float* db, void* stream);
 /* Depth -> TSDF input (tools/graphics_utils.py:134-141 depth2point, tools/depth2mesh.py:37-52): depth_out = depth, zeroed
  * where gt_alpha < 0.5 (gt_alpha may be NULL), alpha < alpha_thres (alpha may be NULL) or the back-projected world point
  * is outside the normalised bounding box |(p - trans) / scale| < 1 (trans NULL: no box test); xyz_cam / xyz_world

@@ -178,6 +178,46 @@ def tsdf_input_cases():
     save("g8_tsdf_input.npz", **out)
 
 
+def config_cases():
+    """The reference's EFFECTIVE configurations (`configs/config.py` resolving `_parent_` chains of `configs/*.yaml`) for the
+    three dataset presets, reduced to the keys of the hot path."""
+    import json
+    tc = types.ModuleType("termcolor")
+    tc.colored = lambda s, *a, **k: s
+    sys.modules.setdefault("termcolor", tc)
+    from configs.config import Config
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        out = {}
+        for tag, path in {"dtu": "configs/dtu/dtu_scan24.yaml", "tnt": "configs/tnt/Barn.yaml", "360": "configs/360_v2/base.yaml"}.items():
+            c = Config(path)
+            o, m = c.optim, c.model
+            out[tag] = dict(
+                loss_weight={k: float(v) for k, v in dict(o.loss_weight).items()},
+                exp_t=float(o.exp_t), mask_depth_thr=float(o.mask_depth_thr), random_background=bool(o.random_background),
+                normal_from_iter=int(o.normal_from_iter), dnormal_from_iter=int(o.dnormal_from_iter),
+                consistent_normal_from_iter=int(o.consistent_normal_from_iter), close_depth_from_iter=int(o.close_depth_from_iter),
+                densify_large=dict(percent_dense=float(o.densify_large.percent_dense),
+                                   sample_cams=dict(random=bool(o.densify_large.sample_cams.random), num=int(o.densify_large.sample_cams.num))),
+                prune=dict(iterations=[int(i) for i in o.prune.iterations], percent=float(o.prune.percent), decay=float(o.prune.decay),
+                           v_pow=float(o.prune.v_pow)),
+                iterations=int(o.iterations), position_lr_init=float(o.position_lr_init), position_lr_final=float(o.position_lr_final),
+                position_lr_delay_mult=float(o.position_lr_delay_mult), position_lr_max_steps=int(o.position_lr_max_steps),
+                feature_lr=float(o.feature_lr), opacity_lr=float(o.opacity_lr), scaling_lr=float(o.scaling_lr),
+                rotation_lr=float(o.rotation_lr), percent_dense=float(o.percent_dense),
+                densification_interval=int(o.densification_interval), opacity_reset_interval=int(o.opacity_reset_interval),
+                densify_from_iter=int(o.densify_from_iter), densify_until_iter=int(o.densify_until_iter),
+                densify_grad_threshold=float(o.densify_grad_threshold),
+                sh_degree=int(m.sh_degree), white_background=bool(m.white_background), depth_type=str(m.depth_type),
+                cls_lr=float(getattr(o, "cls_lr", 5e-4)))
+    finally:
+        os.chdir(cwd)
+    with open(os.path.join(HERE, "g9_effective_configs.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote g9_effective_configs.json")
+
+
 def _load_reference_gaussian_model():
     """Import /root/reference/scene/gaussian_model.py on the CPU: stub the absent third-party modules, keep `scene/__init__`
     (dataset readers, PIL, cv2 ...) from running, and route the hard-coded device="cuda" allocations to the CPU."""
@@ -342,7 +382,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = dict(g1=depth_cases, g2=image_cases, g3=sh_cases, g4=camera_cases, g5=misc_cases, g7=misc_grad_cases, g8=tsdf_input_cases, g6=densify_cases)
+    todo = dict(g1=depth_cases, g2=image_cases, g3=sh_cases, g4=camera_cases, g5=misc_cases, g7=misc_grad_cases, g8=tsdf_input_cases, g9=config_cases, g6=densify_cases)
     for k, fn in todo.items():          # g6 last: it monkey-patches torch.zeros / torch.cuda for the reference model
         if not a.only or k in a.only.split(","):
             fn()

@@ -293,3 +293,27 @@ def test_eval_sh_matches_reference_vectors():
     for deg in range(4):
         rgb = torch.clamp_min(eval_sh(deg, g["sh"], g["dirs"]) + 0.5, 0.0)
         assert torch.allclose(rgb, g[f"rgb_deg{deg}"], atol=1e-6)
+
+
+def test_presets_equal_the_reference_effective_configs():
+    """vcr_gaus_amd.config presets dtu / tnt / 360 vs the configurations the reference's own loader resolves (g9)."""
+    import json
+    from vcr_gaus_amd.config import make_config
+    want = json.load(open(os.path.join(G, "g9_effective_configs.json")))
+
+    def flat(d, pre=""):
+        out = {}
+        for k, v in d.items():
+            if isinstance(v, dict):
+                out.update(flat(v, pre + k + "."))
+            else:
+                out[pre + k] = v
+        return out
+
+    for tag in ("dtu", "tnt", "360"):
+        cfg = make_config(tag)
+        got = flat({k: v for k, v in cfg.optim.items()})
+        got.update({"sh_degree": cfg.model.sh_degree, "white_background": cfg.model.white_background, "depth_type": cfg.model.depth_type})
+        for k, v in flat(want[tag]).items():
+            assert k in got, (tag, k)
+            assert got[k] == v or (isinstance(v, float) and abs(got[k] - v) <= 1e-12 * abs(v)), (tag, k, got[k], v)

@@ -16,7 +16,7 @@ c_int_p = C.POINTER(C.c_int32)
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 BUF_GEOM, BUF_BINNING, BUF_IMAGE, BUF_SCRATCH = 0, 1, 2, 3
-ABI_VERSION = 11         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
+ABI_VERSION = 12         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
 
 
 class VcrShUpdate(C.Structure):
@@ -111,6 +111,8 @@ SYMBOLS = {
     "vcr_rows_plan_bytes": (C.c_size_t, [C.c_int]),
     "vcr_rows_plan": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vcr_rows_move": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(VcrRowArrays), C.c_int, C.c_int, C.c_void_p]),
+    "vcr_semantic_ce_forward": (C.c_int, [C.c_longlong, C.c_int, C.c_int] + [C.c_void_p] * 7),
+    "vcr_semantic_ce_backward": (C.c_int, [C.c_longlong, C.c_int, C.c_int] + [C.c_void_p] * 9),
     "vcr_tsdf_depth_input": (C.c_int, [C.c_int, C.c_int] + [C.c_float] * 4 + [C.POINTER(C.c_float)] + [C.c_void_p] * 4
                              + [C.c_float] + [C.c_void_p] * 4 + [C.c_void_p]),
     "vcr_edge_aware_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5),

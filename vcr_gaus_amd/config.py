@@ -26,7 +26,7 @@ _BASE = {
     "optim": {
         "iterations": 30000, "position_lr_init": 0.00016, "position_lr_final": 0.0000016,
         "position_lr_delay_mult": 0.01, "position_lr_max_steps": 30000, "feature_lr": 0.0025, "opacity_lr": 0.05,
-        "scaling_lr": 0.005, "rotation_lr": 0.001, "percent_dense": 0.01, "densification_interval": 100,
+        "scaling_lr": 0.005, "rotation_lr": 0.001, "cls_lr": 0.0005, "percent_dense": 0.01, "densification_interval": 100,
         "opacity_reset_interval": 3000, "densify_from_iter": 500, "densify_until_iter": 15000,
         "densify_grad_threshold": 0.0005, "random_background": False, "mask_depth_thr": 0.0, "exp_t": 0.01,
         "normal_from_iter": 0, "dnormal_from_iter": 0, "consistent_normal_from_iter": 0, "close_depth_from_iter": 0,
@@ -39,20 +39,28 @@ _BASE = {
     "pipline": {"convert_SHs_python": False, "compute_cov3D_python": False, "debug": False},
 }
 
+# The reference's EFFECTIVE configurations (configs/config.py resolving configs/{dtu/dtu_scan24,tnt/Barn,360_v2/base}.yaml over
+# reconstruct.yaml and config_base.yaml), pinned by tests/golden/g9_effective_configs.json (test_oracle_cpu.py).
 _PRESETS = {
-    # D-Normal + normal-consistency explicitly on (BASELINE config 3)
     "dtu": {"optim": {"exp_t": 0.01, "mask_depth_thr": 0.0, "random_background": False,
-                      "loss_weight": {"depth_normal": 0.015, "consistent_normal": 0.05, "mono_normal": 0.01},
+                      "consistent_normal_from_iter": 15000, "close_depth_from_iter": 15000,
+                      "loss_weight": {"depth_normal": 0.0, "consistent_normal": 0.05, "mono_normal": 0.01, "distortion": 1000.0},
                       "densify_large": {"percent_dense": 1e-2, "sample_cams": {"random": False, "num": 30}},
                       "prune": {"iterations": [15000, 25000]}}},
     "tnt": {"optim": {"exp_t": 0.005, "mask_depth_thr": 0.8, "random_background": True,
-                      "loss_weight": {"depth_normal": 0.015, "consistent_normal": 0.0, "mono_normal": 0.01},
+                      "loss_weight": {"depth_normal": 0.015, "consistent_normal": 0.0, "mono_normal": 0.01, "semantic": 0.005},
                       "densify_large": {"percent_dense": 2e-3, "sample_cams": {"random": True, "num": 200}},
                       "prune": {"iterations": [15000, 25000]}}},
     "360": {"optim": {"exp_t": 0.01, "mask_depth_thr": 1.0, "random_background": True,
                       "loss_weight": {"depth_normal": 0.01, "consistent_normal": 0.0, "mono_normal": 0.01},
                       "densify_large": {"percent_dense": 5e-2, "sample_cams": {"random": False, "num": 100}},
                       "prune": {"iterations": [15000, 25000]}}},
+    # BASELINE.json config 3 ("DTU-shape scene, full training loop with D-Normal + normal-consistency losses"): the dtu preset
+    # with both normal losses on from the first iteration and the late-phase distortion loss off
+    "dtu_c3": {"optim": {"exp_t": 0.01, "mask_depth_thr": 0.0, "random_background": False,
+                         "loss_weight": {"depth_normal": 0.015, "consistent_normal": 0.05, "mono_normal": 0.01},
+                         "densify_large": {"percent_dense": 1e-2, "sample_cams": {"random": False, "num": 30}},
+                         "prune": {"iterations": [15000, 25000]}}},
 }
 
 

@@ -1024,3 +1024,121 @@ extern "C" int vcr_tsdf_depth_input(int H, int W, float fx, float fy, float cx, 
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// ---------------- semantic loss (gaussian_renderer/__init__.py:146-148, trainer.py:304-307) ------------------------------------
+// The reference pushes the rendered semantic feature planes through a 1x1 Conv2d classifier and takes
+// F.cross_entropy(logits, labels) / log(num_cls).  Both are per-pixel arithmetic on S <= 4 features and K <= 8 classes, so
+// classifier + log-softmax + NLL run in one streaming kernel each way (the backward also yields the classifier's gradient).
+// sums layout: [1 result][VCR_NSLOT slots] for the forward; the backward accumulates K*(S+1) fp32 sums by block reduction +
+// atomics into dW [K,S] and db [K] (zeroed here).
+namespace {
+constexpr int SEM_MAX_S = 4, SEM_MAX_K = 8;
+
+struct SemCls { float W[SEM_MAX_K * SEM_MAX_S]; float b[SEM_MAX_K]; };
+
+__device__ __forceinline__ void sem_logits(const SemCls& c, int S, int K, const float* __restrict__ sem, size_t P, size_t p,
+                                           float f[SEM_MAX_S], float l[SEM_MAX_K], float& lse) {
+    for (int s = 0; s < S; ++s) f[s] = sem[s * P + p];
+    float m = -3.4e38f;
+    for (int k = 0; k < K; ++k) {
+        float v = c.b[k];
+        for (int s = 0; s < S; ++s) v += c.W[k * S + s] * f[s];
+        l[k] = v; m = fmaxf(m, v);
+    }
+    float z = 0.f;
+    for (int k = 0; k < K; ++k) z += __expf(l[k] - m);
+    lse = m + __logf(z);
+}
+
+__device__ __forceinline__ void load_cls(SemCls& c, int S, int K, const float* __restrict__ W, const float* __restrict__ b) {
+    for (int i = 0; i < K * S; ++i) c.W[i] = W[i];           // wave-uniform loads of <= 40 numbers
+    for (int i = 0; i < K; ++i) c.b[i] = b[i];
+}
+
+__global__ void __launch_bounds__(256) sem_ce_fwd_kernel(size_t P, int S, int K, const float* __restrict__ Wd,
+                                                         const float* __restrict__ bd, const float* __restrict__ sem,
+                                                         const long long* __restrict__ labels, double* __restrict__ sums) {
+    SemCls c;
+    load_cls(c, S, K, Wd, bd);
+    float v[1] = {0.f};
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (size_t)gridDim.x * 256) {
+        float f[SEM_MAX_S], l[SEM_MAX_K], lse;
+        sem_logits(c, S, K, sem, P, p, f, l, lse);
+        const int t = (int)labels[p];
+        v[0] += lse - (t >= 0 && t < K ? l[t] : lse);
+    }
+    block_accumulate<1>(sums + 1, v);
+}
+
+__global__ void __launch_bounds__(256) sem_ce_bwd_kernel(size_t P, int S, int K, const float* __restrict__ Wd,
+                                                         const float* __restrict__ bd, const float* __restrict__ sem,
+                                                         const long long* __restrict__ labels, const float* __restrict__ gout,
+                                                         float scale, float* __restrict__ dsem, float* __restrict__ dW,
+                                                         float* __restrict__ db) {
+    __shared__ float s_red[4][SEM_MAX_K * (SEM_MAX_S + 1)];
+    SemCls c;
+    load_cls(c, S, K, Wd, bd);
+    float acc[SEM_MAX_K * (SEM_MAX_S + 1)];
+    const int NV = K * (S + 1);
+    for (int i = 0; i < SEM_MAX_K * (SEM_MAX_S + 1); ++i) acc[i] = 0.f;
+    const float g = gout[0] * scale;
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (size_t)gridDim.x * 256) {
+        float f[SEM_MAX_S], l[SEM_MAX_K], lse;
+        sem_logits(c, S, K, sem, P, p, f, l, lse);
+        const int t = (int)labels[p];
+        float ds[SEM_MAX_S] = {0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < K) {
+            for (int k = 0; k < K; ++k) {
+                const float dl = g * (__expf(l[k] - lse) - (k == t ? 1.f : 0.f));
+                for (int s = 0; s < S; ++s) { ds[s] += dl * c.W[k * S + s]; acc[k * (S + 1) + s] += dl * f[s]; }
+                acc[k * (S + 1) + S] += dl;
+            }
+        }
+        for (int s = 0; s < S; ++s) dsem[s * P + p] = ds[s];
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = 0; i < NV; ++i) {
+        const float t = wave_sum(acc[i]);
+        if (lane == 0) s_red[wv][i] = t;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NV) {
+        const int i = threadIdx.x, k = i / (S + 1), s = i - k * (S + 1);
+        const float t = s_red[0][i] + s_red[1][i] + s_red[2][i] + s_red[3][i];
+        if (t != 0.f) atomicAdd(s < S ? dW + k * S + s : db + k, t);
+    }
+}
+}  // namespace
+
+// sem: [S,P] feature planes (rows of the rasterizer output), W [K,S] and b [K]: the classifier's parameters (device),
+// labels: device int64 [P].  loss (device float[1]) = mean_p CE(p) / log(K).
+extern "C" int vcr_semantic_ce_forward(long long P, int S, int K, const float* sem, const float* W, const float* b,
+                                       const long long* labels, double* sums1, float* loss, void* stream) {
+    if (P <= 0 || S < 1 || S > SEM_MAX_S || K < 2 || K > SEM_MAX_K || !sem || !W || !b || !labels || !sums1 || !loss) {
+        vcr_set_error("vcr_semantic_ce_forward: bad arguments (S <= %d, 2 <= K <= %d)", SEM_MAX_S, SEM_MAX_K); return 1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    VCR_HIP_CHECK(hipMemsetAsync(sums1, 0, (1 + VCR_NSLOT) * sizeof(double), st));
+    const int blocks = (int)((P + 255) / 256 < 4096 ? (P + 255) / 256 : 4096);
+    hipLaunchKernelGGL(sem_ce_fwd_kernel, dim3(blocks), dim3(256), 0, st, (size_t)P, S, K, W, b, sem, labels, sums1);
+    hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, st, 1, sums1, 0, 1.0 / ((double)P * log((double)K)), loss);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// dsem [S,P], dW [K,S], db [K] (device, fp32; dW / db are zeroed here)
+extern "C" int vcr_semantic_ce_backward(long long P, int S, int K, const float* sem, const float* W, const float* b,
+                                        const long long* labels, const float* gout, float* dsem, float* dW, float* db,
+                                        void* stream) {
+    if (P <= 0 || S < 1 || S > SEM_MAX_S || K < 2 || K > SEM_MAX_K || !sem || !W || !b || !labels || !gout || !dsem || !dW || !db) {
+        vcr_set_error("vcr_semantic_ce_backward: bad arguments"); return 1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    VCR_HIP_CHECK(hipMemsetAsync(dW, 0, sizeof(float) * K * S, st));
+    VCR_HIP_CHECK(hipMemsetAsync(db, 0, sizeof(float) * K, st));
+    const int blocks = (int)((P + 255) / 256 < 2048 ? (P + 255) / 256 : 2048);
+    hipLaunchKernelGGL(sem_ce_bwd_kernel, dim3(blocks), dim3(256), 0, st, (size_t)P, S, K, W, b, sem, labels, gout,
+                       (float)(1.0 / ((double)P * log((double)K))), dsem, dW, db);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -44,15 +44,23 @@ class _RenderOut(dict):
     """The reference's return dictionary; with `lazy_mask` the [N] `visibility_filter` (radii > 0) is only materialised
     when somebody reads it (the fused trainer hands `radii` to the densification-statistics kernel instead)."""
 
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.lazy = {}                      # key -> thunk: entries materialised on first read (e.g. render_sem)
+
     def __missing__(self, key):
         if key == "visibility_filter":
             v = self["radii"] > 0
             self[key] = v
             return v
+        if key in self.lazy:
+            v = self.lazy.pop(key)()
+            self[key] = v
+            return v
         raise KeyError(key)
 
     def __contains__(self, key):
-        return key == "visibility_filter" or dict.__contains__(self, key)
+        return key == "visibility_filter" or key in self.lazy or dict.__contains__(self, key)
 
 
 def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_color=None, return_normal=True,
@@ -89,7 +97,8 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
         dir_pp = pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
         sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp / dir_pp.norm(dim=1, keepdim=True))
         shs, shs_rest, colors_precomp = None, None, torch.clamp_min(sh2rgb + 0.5, 0.0)
-    sem_feats = pc.get_objects.squeeze(1) if cfg.optim.loss_weight.semantic > 0 else None
+    with_sem = cfg.optim.loss_weight.semantic > 0 and getattr(pc, "enable_semantic", False) and pc.get_objects.numel() > 0
+    sem_feats = pc.get_objects.squeeze(1) if with_sem else None
 
     rendered_out, radii = rasterizer(
         means3D=pc.get_xyz, means2D=screenspace_points, means2D_densify=screenspace_points_densify, shs=shs,
@@ -120,9 +129,13 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
                       "mask_static": cam_mask, "radii": radii, "render_out": rendered_out})
     if not lazy_mask:
         out["visibility_filter"] = radii > 0
-    if cfg.optim.loss_weight.semantic > 0:
+    if with_sem:
         sem = rendered_out[8:8 + cfg.model.ch_sem_feat]
-        out["render_sem"] = pc.classifier(sem[None])[0].permute(1, 2, 0)
+        out["sem_planes"] = sem                          # the trainer's fused semantic loss consumes these directly
+        if lazy_mask:
+            out.lazy["render_sem"] = lambda: pc.classifier(sem[None])[0].permute(1, 2, 0)
+        else:
+            out["render_sem"] = pc.classifier(sem[None])[0].permute(1, 2, 0)
     if want_var:                                    # gaussian_renderer/__init__.py:154-158
         d1, d2 = rendered_out[-2:-1], rendered_out[-1:]
         out["depth_var"] = d2 / rendered_alpha - (d1 / rendered_alpha) ** 2

@@ -264,3 +264,43 @@ def psnr(img1, img2):
     """`tools/image_utils.py:17-19`."""
     mse = ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
     return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
+
+class _SemanticCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sem_planes, weight, bias, labels):
+        lib = _lib.load()
+        sem = sem_planes.detach().contiguous().float()
+        S, H, W = sem.shape
+        K = weight.shape[0]
+        w = weight.detach().reshape(K, S).contiguous().float()
+        b = bias.detach().contiguous().float()
+        lab = labels.detach().reshape(-1).contiguous().long()
+        sums = torch.empty(lib.vcr_sums_elems(1), dtype=torch.float64, device=sem.device)
+        loss = torch.empty(1, dtype=torch.float32, device=sem.device)
+        _lib.check(lib.vcr_semantic_ce_forward(H * W, S, K, sem.data_ptr(), w.data_ptr(), b.data_ptr(), lab.data_ptr(),
+                                               sums.data_ptr(), loss.data_ptr(), _lib.stream_of(sem)))
+        ctx.save_for_backward(sem, lab, w, b)
+        ctx.shapes = (weight.shape, bias.shape)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        sem, lab, w, b = ctx.saved_tensors
+        S, H, W = sem.shape
+        K = w.shape[0]
+        dsem = torch.empty_like(sem)
+        dW = torch.empty(K, S, dtype=torch.float32, device=sem.device)
+        db = torch.empty(K, dtype=torch.float32, device=sem.device)
+        go = gout.contiguous().float().reshape(1)
+        _lib.check(lib.vcr_semantic_ce_backward(H * W, S, K, sem.data_ptr(), w.data_ptr(), b.data_ptr(), lab.data_ptr(),
+                                                go.data_ptr(), dsem.data_ptr(), dW.data_ptr(), db.data_ptr(), _lib.stream_of(sem)))
+        return dsem, dW.view(ctx.shapes[0]), db.view(ctx.shapes[1]), None
+
+
+def semantic_loss(sem_planes, classifier, labels):
+    """`F.cross_entropy(classifier(sem)[0].permute(1, 2, 0).view(-1, K), labels.view(-1)) / log(K)`
+    (`gaussian_renderer/__init__.py:146-148`, `trainer.py:304-307`) with the 1x1-conv classifier, the log-softmax and the
+    NLL fused: sem_planes [S,H,W] = rows 8..8+S of the rasterizer output, classifier = the model's Conv2d(S, K, 1)."""
+    return _SemanticCE.apply(sem_planes, classifier.weight, classifier.bias, labels)

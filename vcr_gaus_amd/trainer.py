@@ -19,7 +19,8 @@ import torch.distributed as dist
 
 from .gaussian_model import GaussianModel
 from .gaussian_renderer import count_render, render, visi_acc_render
-from .loss_utils import curv_loss, edge_aware_mean, entropy_regulariser, l1_ssim, normal_loss, scale_regulariser
+from .loss_utils import (curv_loss, edge_aware_mean, entropy_regulariser, l1_ssim, normal_loss, scale_regulariser,
+                         semantic_loss)
 
 
 class Trainer:
@@ -169,10 +170,8 @@ class Trainer:
             L["distortion"] = edge_aware_mean(gt_image, data["distortion"])
         if "depth_var" in self.weights and it > cfg.optim.close_depth_from_iter and "depth_var" in data:
             L["depth_var"] = edge_aware_mean(gt_image, data["depth_var"])
-        if "semantic" in self.weights and "render_sem" in data:
-            logits = data["render_sem"].reshape(-1, self.model.num_cls)
-            L["semantic"] = torch.nn.functional.cross_entropy(logits, cam.mask.view(-1).long()) / \
-                torch.log(torch.tensor(float(self.model.num_cls)))
+        if "semantic" in self.weights and "sem_planes" in data:            # `trainer.py:304-307`, classifier + CE in one kernel
+            L["semantic"] = semantic_loss(data["sem_planes"], self.model.classifier, cam.mask)
         self.losses = L
         names = [k for k in self.weights if k in L]
         wvec = self._weight_vector(names)
@@ -446,6 +445,8 @@ def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_
     cfg = make_config(preset, **overrides)
     sem = "obj_dc" in raw
     cfg.model.enable_semantic = sem
+    if not sem:
+        cfg.optim.loss_weight.semantic = 0.0          # (the tnt preset trains semantics; a scene without object ids cannot)
     if sem:
         cfg.model.ch_sem_feat = raw["obj_dc"].shape[-1]
         cfg.model.num_cls = 2
