@@ -95,7 +95,8 @@ class _FusedLosses(torch.autograd.Function):
         dout = torch.empty_like(o)
         dbase = dout.data_ptr()
         if C > 8 or (C > 7 and not nbits):
-            dout[7:].zero_()                                       # (the alpha plane is zeroed by the normal-loss backward)
+            dout[7:].zero_()                                       # (the alpha plane is zeroed by the normal-loss backward; the
+                                                                   #  semantic planes get their gradient from semantic_loss)
         _lib.check(lib.vcr_l1_ssim_backward(H, W, o.data_ptr(), gi.data_ptr(), part.data_ptr(), gp(0), gp(1), dbase, st))
         base = o.data_ptr()
         if nbits:

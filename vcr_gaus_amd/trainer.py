@@ -138,11 +138,14 @@ class Trainer:
 
     # ---- losses (`trainer.py:233-321`) -------------------------------------------------------------------
     def _compute_loss(self, data, cam):
-        extra = [k for k in ("distortion", "depth_var", "semantic", "entropy", "mono_depth", "curv") if k in self.weights]
+        extra = [k for k in ("distortion", "depth_var", "entropy", "mono_depth", "curv") if k in self.weights]
         if not extra and "render_out" in data and getattr(self, "use_fused_losses", True):
             from .fused_losses import fused_losses          # one autograd node for the whole image-space loss
             total, vals = fused_losses(data["render_out"], self.model, cam, self.weights, self.current_iteration,
                                        self.cfg.optim, self.extent, mask=data.get("mask_static"))
+            if "semantic" in self.weights and "sem_planes" in data:          # `trainer.py:304-307`, its own fused kernel
+                vals["semantic"] = semantic_loss(data["sem_planes"], self.model.classifier, cam.mask)
+                total = torch.add(total, vals["semantic"], alpha=float(self.weights["semantic"]))
             vals["total"] = total
             self.losses = vals
             return total
@@ -374,7 +377,7 @@ class Trainer:
         cam = self.cameras[self._next_cameras()[self.rank]]
         bg = self.bg_table[it % self.bg_table.shape[0]] if cfg.optim.random_background else self.background
         fused = getattr(self, "use_fused_losses", True) and not any(
-            k in self.weights for k in ("distortion", "depth_var", "semantic", "entropy", "mono_depth", "curv"))
+            k in self.weights for k in ("distortion", "depth_var", "entropy", "mono_depth", "curv"))
         from . import rasterizer
         overlap = self.overlap_sh and m._xyz.shape[0] >= self.overlap_min_gaussians
         self.factorised_sh = self._factorised_base or overlap
