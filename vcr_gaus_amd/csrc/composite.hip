@@ -99,6 +99,15 @@ __device__ __forceinline__ void live_box(unsigned long long live, float X0, floa
 // out-of-range lanes read record 0 (never used) so that no select-of-pointers / scratch is generated.
 #define VCR_LOAD_ID(POS, END, ID, VALID) \
     do { const uint32_t _p = (POS); VALID = _p < (END); ID = VALID ? point_list[_p] : 0u; } while (0)
+// semantic features of the entry (S <= 4 floats from semv[N,S]); staged with the record so that the shading loops read them
+// from LDS instead of issuing a dependent global load per survivor (S = 2: forward 0.55 -> ms)
+#define VCR_GATHER_SEM(ID, QS)                                                                   \
+    do {                                                                                         \
+        if (S > 0) {                                                                             \
+            const float* _sp = semv + (size_t)(ID) * S;                                          \
+            QS.x = _sp[0]; QS.y = S > 1 ? _sp[1] : 0.f; QS.z = S > 2 ? _sp[2] : 0.f; QS.w = S > 3 ? _sp[3] : 0.f; \
+        }                                                                                        \
+    } while (0)
 #define VCR_GATHER_REC(ID, Q0, Q1, Q2, Q3)                                          \
     do {                                                                            \
         const float4* _src = reinterpret_cast<const float4*>(rec + (ID));           \
@@ -141,8 +150,11 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
     const uint2 range = ranges[tile];
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ float4 s_rec_all[4 * 256];                 // per wave: 4 planes x 64 slots x 16 B (conflict-free b128 writes)
-    float4* const srec = s_rec_all + wv * 256;
+    // S <= 2 without count mode: the semantic features come with the record (GeomRec pad slots) and take the place of the id
+    constexpr bool SEM_IN_REC = S > 0 && S <= 2 && FC == 0;
+    constexpr int WREC = (S > 0 && !SEM_IN_REC) ? 320 : 256;   // per wave: 4 (+1 with semantics) planes x 64 slots x 16 B
+    __shared__ float4 s_rec_all[4 * WREC];                // (conflict-free b128 writes)
+    float4* const srec = s_rec_all + wv * WREC;
 #ifdef VCR_TIMING
     const long long t_start = wall_clock64();
     int n_surv = 0, n_hit = 0, n_chunks = 0;
@@ -165,14 +177,16 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
     bool done = !pm.inside;
 
     uint32_t pos = range.x;
-    uint32_t id, nid; float4 q0, q1, q2, q3; bool valid, nvalid;
+    uint32_t id, nid; float4 q0, q1, q2, q3, qs = {0.f, 0.f, 0.f, 0.f}; bool valid, nvalid;
     VCR_LOAD_ID(pos + lane, range.y, id, valid);
     VCR_GATHER_REC(id, q0, q1, q2, q3);
+    if (!SEM_IN_REC) VCR_GATHER_SEM(id, qs);
     VCR_LOAD_ID(pos + 64 + lane, range.y, nid, nvalid);
     while (pos < range.y) {
-        uint32_t nnid; float4 nq0, nq1, nq2, nq3; bool nnvalid;
+        uint32_t nnid; float4 nq0, nq1, nq2, nq3, nqs = {0.f, 0.f, 0.f, 0.f}; bool nnvalid;
         const uint32_t npos = pos + 64;
         VCR_GATHER_REC(nid, nq0, nq1, nq2, nq3);                     // records of the next chunk
+        if (!SEM_IN_REC) VCR_GATHER_SEM(nid, nqs);
         VCR_LOAD_ID(npos + 64 + lane, range.y, nnid, nnvalid);       // ids of the chunk after that
 #ifdef VCR_TIMING
         t_mark = wall_clock64();
@@ -193,7 +207,8 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
             srec[0 * 64 + lane] = make_float4(q0.x, q0.y, -VCR_L2E * q1.x, -VCR_L2E * q1.z);
             srec[1 * 64 + lane] = make_float4(-VCR_L2E * q1.y, __builtin_amdgcn_logf(q0.w), q0.z, q1.w);   // v_log_f32 = log2
             srec[2 * 64 + lane] = make_float4(q2.x, q2.y, q2.z, q3.x);
-            srec[3 * 64 + lane] = make_float4(q3.y, q3.z, __uint_as_float(id), 0.f);
+            srec[3 * 64 + lane] = SEM_IN_REC ? make_float4(q3.y, q3.z, q2.w, q3.w) : make_float4(q3.y, q3.z, __uint_as_float(id), 0.f);
+            if (S > 0 && !SEM_IN_REC) srec[4 * 64 + lane] = qs;
         }
         __builtin_amdgcn_wave_barrier();          // same wave, DS ops execute in order: no s_barrier needed
         // Shading of one survivor whose staged record sits in R0..R3 (a macro, not a lambda: captured-by-reference bools
@@ -239,9 +254,10 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
                 M1 += w * md; M2 += w * md * md;                                                                         \
             }                                                                                                            \
             if (S > 0) {                                                                                                 \
-                const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(r3.z));               \
+                const float4 r4_ = SEM_IN_REC ? make_float4(r3.z, r3.w, 0.f, 0.f) : R##4;                                \
+                const float sv_[4] = {r4_.x, r4_.y, r4_.z, r4_.w};                                                       \
 _Pragma("unroll")                                                                                                        \
-                for (int k = 0; k < S; ++k) SM[k] += w * semv[(size_t)gid * S + k];                                      \
+                for (int k = 0; k < S; ++k) SM[k] += w * sv_[k];                                                         \
             }                                                                                                            \
             T = hit ? test_T : T;                                                                                        \
             last = hit ? pos - range.x + (uint32_t)sb_ + 1u : last;                                                        \
@@ -251,10 +267,11 @@ _Pragma("unroll")                                                               
 #define VCR_LDS_FETCH(R, B)                                                                                   \
         do {                                                                                                  \
             R##0 = srec[(B)]; R##1 = srec[64 + (B)]; R##2 = srec[128 + (B)]; R##3 = srec[192 + (B)];          \
+            if (S > 0 && !SEM_IN_REC) R##4 = srec[256 + (B)];                                                 \
             asm volatile("" ::: "memory");                                                                    \
         } while (0)
         if (m && !(VCR_KO & 1)) {
-            float4 A0, A1, A2, A3, B0, B1, B2, B3;
+            float4 A0, A1, A2, A3, A4 = {0.f, 0.f, 0.f, 0.f}, B0, B1, B2, B3, B4 = {0.f, 0.f, 0.f, 0.f};
             int b = __builtin_ctzll(m);
             m &= m - 1;
             VCR_LDS_FETCH(A, b);
@@ -279,7 +296,7 @@ _Pragma("unroll")                                                               
         t_surv += wall_clock64() - t_mark;
 #endif
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;        // every pixel of the quad has T < 1e-4
-        pos = npos; id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; valid = nvalid; nid = nnid; nvalid = nnvalid;
+        pos = npos; id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; qs = nqs; valid = nvalid; nid = nnid; nvalid = nnvalid;
     }
 #ifdef VCR_TIMING
     if (lane == 0 && count) {       // experiment builds only: (start, end) wall-clock ticks per wave
@@ -338,8 +355,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 
     const uint2 range = ranges[tile];
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ float4 s_rec_all[4 * 256];                 // per wave: 4 planes x 64 slots x 16 B
-    float4* const srec = s_rec_all + wv * 256;
+    constexpr bool SEM_IN_REC = false;                    // (the backward needs the id for its atomics: semantics keep their plane)
+    constexpr int WREC = S > 0 ? 320 : 256;               // per wave: 4 (+1 with semantics) planes x 64 slots x 16 B
+    __shared__ float4 s_rec_all[4 * WREC];
+    float4* const srec = s_rec_all + wv * WREC;
     const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8 + (sub < 0 ? 0 : (sub & 1) * 4));
     const float Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8 + (sub < 0 ? 0 : (sub >> 1) * 4));
     const f2 fxy = {(float)pm.x, (float)pm.y};
@@ -370,14 +389,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 
     const f2 g01 = {g[0], g[1]}, g24 = {g[2], g[4]}, g56 = {g[5], g[6]}, ryz = {ry, rz};
 
     int chunk = (int)((maxc - 1) / 64);                    // chunks of 64 list entries, walked back to front
-    uint32_t id, nid; float4 q0, q1, q2, q3; bool valid, nvalid;
+    uint32_t id, nid; float4 q0, q1, q2, q3, qs = {0.f, 0.f, 0.f, 0.f}; bool valid, nvalid;
     const uint32_t lim = range.x + maxc;
     VCR_LOAD_ID(range.x + (uint32_t)chunk * 64u + lane, lim, id, valid);
     VCR_GATHER_REC(id, q0, q1, q2, q3);
+    VCR_GATHER_SEM(id, qs);
     VCR_LOAD_ID(chunk > 0 ? range.x + (uint32_t)(chunk - 1) * 64u + lane : lim, lim, nid, nvalid);
     for (; chunk >= 0; --chunk) {
-        uint32_t nnid; float4 nq0, nq1, nq2, nq3; bool nnvalid;
+        uint32_t nnid; float4 nq0, nq1, nq2, nq3, nqs = {0.f, 0.f, 0.f, 0.f}; bool nnvalid;
         VCR_GATHER_REC(nid, nq0, nq1, nq2, nq3);
+        VCR_GATHER_SEM(nid, nqs);
         VCR_LOAD_ID(chunk > 1 ? range.x + (uint32_t)(chunk - 2) * 64u + lane : lim, lim, nnid, nnvalid);
         float bx0, by0, bw, bh;
         live_box(__builtin_amdgcn_ballot_w64(lastc > (uint32_t)chunk * 64u), X0, Y0, bx0, by0, bw, bh);
@@ -388,6 +409,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 
             srec[1 * 64 + lane] = make_float4(-VCR_L2E * q1.y, __builtin_amdgcn_logf(q0.w), q0.z, q1.w);
             srec[2 * 64 + lane] = make_float4(q2.x, q2.y, q2.z, q3.x);
             srec[3 * 64 + lane] = make_float4(q3.y, q3.z, __uint_as_float(id), 0.f);
+            if (S > 0) srec[4 * 64 + lane] = qs;
         }
         __builtin_amdgcn_wave_barrier();
         // Shading + gradient of one survivor whose staged record sits in R0..R3 (see the forward kernel for the staging).
@@ -434,8 +456,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 
                     md = -zc_map * VCR_ZNEAR * idep;                                                                     \
                     fg += md * gm1 + md * md * gm2;                                                                      \
                 }                                                                                                        \
+                { const float4 r4_ = R##4; const float sv_[4] = {r4_.x, r4_.y, r4_.z, r4_.w};                            \
 _Pragma("unroll")                                                                                                        \
-                for (int k = 0; k < S; ++k) fg += semv[(size_t)gid * S + k] * g[8 + k];                                  \
+                for (int k = 0; k < S; ++k) fg += sv_[k] * g[8 + k]; }                                                   \
                 const float dL_dalpha = fmaf(T, fg, -Bsuf * inv1ma);                                                     \
                 Bsuf = fmaf(w, fg, Bsuf);                                                                                \
                 const float pw = ah * dL_dalpha;                                                                         \
@@ -474,7 +497,7 @@ _Pragma("unroll")                                                               
             }                                                                                                            \
         } while (0)
         if (m && !(VCR_KO & 1)) {
-            float4 A0, A1, A2, A3, B0, B1, B2, B3;
+            float4 A0, A1, A2, A3, A4 = {0.f, 0.f, 0.f, 0.f}, B0, B1, B2, B3, B4 = {0.f, 0.f, 0.f, 0.f};
             int b = 63 - __builtin_clzll(m);
             m &= ~(1ull << b);
             VCR_LDS_FETCH(A, b);
@@ -495,7 +518,7 @@ _Pragma("unroll")                                                               
                 b = nb;
             }
         }
-        id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; valid = nvalid; nid = nnid; nvalid = nnvalid;
+        id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; qs = nqs; valid = nvalid; nid = nnid; nvalid = nnvalid;
     }
 }
 

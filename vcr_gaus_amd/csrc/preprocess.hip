@@ -284,7 +284,9 @@ __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const
     } else {
         rec.nx = rec.ny = rec.nz = 0.f; rec.plane = 0.f;
     }
-    rec.pad0 = 0.f; rec.pad1 = 0.f;
+    // the first two semantic features ride in the record's pad slots: the forward compositing of S <= 2 reads them from there
+    rec.pad0 = a.S > 0 ? a.semantics_precomp[(size_t)i * a.S] : 0.f;
+    rec.pad1 = a.S > 1 ? a.semantics_precomp[(size_t)i * a.S + 1] : 0.f;
     float4* dst = reinterpret_cast<float4*>(g.rec + i);
     const float4* src = reinterpret_cast<const float4*>(&rec);
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
@@ -359,7 +361,7 @@ __global__ void __launch_bounds__(256) colour_fwd_kernel(VcrRasterArgs a, GeomSt
         if (c0 < 0.f) { c0 = 0.f; clampbits |= 1; }
         if (c1 < 0.f) { c1 = 0.f; clampbits |= 2; }
         if (c2 < 0.f) { c2 = 0.f; clampbits |= 4; }
-        reinterpret_cast<float4*>(g.rec + i)[2] = make_float4(c0, c1, c2, 0.f);
+        { float* q2_ = &g.rec[i].r; q2_[0] = c0; q2_[1] = c1; q2_[2] = c2; }      // (pad0 keeps the semantic feature)
         g.clamped[i] = clampbits;
     }
 }
@@ -803,7 +805,7 @@ __global__ void __launch_bounds__(256) sh_update_colour_kernel(VcrRasterArgs a, 
             if (c0 < 0.f) { c0 = 0.f; clampbits |= 1; }
             if (c1 < 0.f) { c1 = 0.f; clampbits |= 2; }
             if (c2 < 0.f) { c2 = 0.f; clampbits |= 4; }
-            reinterpret_cast<float4*>(g.rec + i)[2] = make_float4(c0, c1, c2, 0.f);
+            { float* q2_ = &g.rec[i].r; q2_[0] = c0; q2_[1] = c1; q2_[2] = c2; }      // (pad0 keeps the semantic feature)
             g.clamped[i] = clampbits;
         }
     }
