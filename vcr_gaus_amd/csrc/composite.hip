@@ -489,10 +489,11 @@ _Pragma("unroll")                                                               
                 const int k = 8 * (lane >> 5) + 4 * ((lane >> 4) & 1) + sub;                                             \
                 if ((VCR_KO & 2) ? val == 1.2345e-30f : val != 0.f) atomicAdd(reinterpret_cast<float*>(sgrad + gid) + k, val); \
             }                                                                                                            \
+            if (S > 0) {     /* semantic gradients: DPP row sums only (no cross-row ds_bpermute round trips); the four row   */ \
+                float ts = 0.f;  /* totals of feature k sit in lanes 16 r + k and go out as ONE atomic instruction            */ \
 _Pragma("unroll")                                                                                                        \
-            for (int k = 0; k < S; ++k) {                                                                                \
-                const float t = wave_sum(vs[k]);                                                                         \
-                if (lane == 0 && t != 0.f) atomicAdd(sgrad_sem + (size_t)gid * S + k, t);                                \
+                for (int k = 0; k < S; ++k) { const float t = row_sum16(vs[k]); ts = (lane & 15) == k ? t : ts; }            \
+                if ((lane & 15) < S && ts != 0.f) atomicAdd(sgrad_sem + (size_t)gid * S + (lane & 15), ts);              \
             }                                                                                                            \
             }                                                                                                            \
         } while (0)
