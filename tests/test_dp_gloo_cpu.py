@@ -70,9 +70,15 @@ def worker(rank, world, port, out):
         picks.append(cams)
         data = view_data(cams[rank], tr.model)
         tr._allreduce_grads()
-        tr._densify_stats(data)
+        tr._densify_stats(data)                    # rank-local deltas, no collective ...
+        if step == 1:
+            tr.sync_densify_stats()                # ... folded in on demand (here once mid-way and once at the end)
         if step < 2:
             tr.model._xyz.grad = None
+    local_only = tr.model.denom.clone()
+    tr.sync_densify_stats()
+    assert tr._stats_delta is None and not torch.equal(local_only, tr.model.denom)
+    tr.sync_densify_stats()                        # idempotent once clean
     if rank == 0:
         torch.save(dict(picks=picks, gx=tr.model._xyz.grad, go=tr.model._opacity.grad, acc=tr.model.xyz_gradient_accum,
                         den=tr.model.denom, mr=tr.model.max_radii2D, scale=tr.model.optimizer.grad_scale), out)

@@ -34,6 +34,7 @@ def _worker(rank, world, port, out, overlap):
         picks.append(list(tr._picked))
         exch.append(tr.last_exchange)
     tr.join_side()
+    tr.sync_densify_stats()                # (statistics are rank-local between the points where they are read)
     torch.cuda.synchronize()
     m = tr.model
     torch.save(dict(losses=losses, picks=picks, exch=exch, n=m._xyz.shape[0],

@@ -42,6 +42,7 @@ class Trainer:
         self.bg_table = torch.rand(4096, 3, generator=self.gen).to(device)
         self.view_order = []
         self.visi_list = None
+        self._stats_delta, self._visi_delta, self._stats_dirty = None, None, False     # data parallel: see _densify_stats
         self.last_stats = {}
         self._picked = []
         # DP: exchange dL/drgb (12 B/Gaussian/view, all-gather) instead of all-reducing the 192 B/Gaussian SH gradients
@@ -307,24 +308,48 @@ class Trainer:
         return d_dc, d_rest
 
     def _densify_stats(self, data):
+        """`add_densification_stats` + `max_radii2D` (`scene/gaussian_model.py:669-671`, `trainer.py:345`).  Data parallel: the
+        rank accumulates ITS view into rank-local deltas (no collective per step); `sync_densify_stats` folds the deltas of all
+        ranks into the replicated accumulators right before anything reads or re-indexes them.  Sums and maxima commute with
+        the accumulation over steps, so the values every rank then holds are those of a per-step reduction."""
         m = self.model
         vp = data["viewspace_points_densify"]
         if self.world == 1 and not getattr(self, "force_collectives", False):
             m.add_densification_stats(vp, None, radii=data["radii"])
             return
         N = m._xyz.shape[0]
-        acc, den, mr = torch.zeros(N, 1, device=self.device), torch.zeros(N, 1, device=self.device), torch.zeros(N, device=self.device)
-        keep = (m.xyz_gradient_accum, m.denom, m.max_radii2D)
-        m.xyz_gradient_accum, m.denom, m.max_radii2D = acc, den, mr
-        m.add_densification_stats(vp, None, radii=data["radii"])
-        m.xyz_gradient_accum, m.denom, m.max_radii2D = keep
-        pair = torch.cat([acc, den], 1)
-        w1 = dist.all_reduce(pair, op=dist.ReduceOp.SUM, async_op=True)
-        w2 = dist.all_reduce(mr, op=dist.ReduceOp.MAX, async_op=True)
-        w1.wait(); w2.wait()
+        if self._stats_delta is None or self._stats_delta[0].shape[0] != N:
+            assert self._stats_delta is None or not self._stats_dirty, "densification statistics not synchronised before row surgery"
+            self._stats_delta = (torch.zeros(N, 1, device=self.device), torch.zeros(N, 1, device=self.device))
+        keep = (m.xyz_gradient_accum, m.denom)
+        m.xyz_gradient_accum, m.denom = self._stats_delta
+        try:
+            m.add_densification_stats(vp, None, radii=data["radii"])     # (max_radii2D: running maximum, local until the sync)
+        finally:
+            m.xyz_gradient_accum, m.denom = keep
+        if "countlist" in data and self.current_iteration > self.cfg.optim.densify_from_iter:        # `trainer.py:350-356`
+            cl = data["countlist"]
+            self._visi_delta = cl.clone() if self._visi_delta is None else self._visi_delta + cl
+        self._stats_dirty = True
+
+    def sync_densify_stats(self):
+        """Data parallel: sum the rank-local statistic deltas (and maximise `max_radii2D`) over the ranks.  Called before
+        densify / prune / any row surgery and before a checkpoint; a no-op on one GPU or when nothing was accumulated."""
+        if not self._stats_dirty:
+            return
+        m = self.model
+        pair = torch.cat(self._stats_delta, 1)
+        works = [dist.all_reduce(pair, op=dist.ReduceOp.SUM, async_op=True),
+                 dist.all_reduce(m.max_radii2D, op=dist.ReduceOp.MAX, async_op=True)]
+        if self._visi_delta is not None:
+            works.append(dist.all_reduce(self._visi_delta, op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
         m.xyz_gradient_accum += pair[:, :1]
         m.denom += pair[:, 1:]
-        torch.maximum(m.max_radii2D, mr, out=m.max_radii2D)
+        if self._visi_delta is not None:
+            self.visi_list = self._visi_delta if self.visi_list is None else self.visi_list + self._visi_delta
+        self._stats_delta, self._visi_delta, self._stats_dirty = None, None, False
 
     # ---- visibility / importance passes (`tools/prune.py:6-69`, `trainer.py:688-702`), camera-sharded ------------
     @torch.no_grad()
@@ -409,12 +434,12 @@ class Trainer:
             self._exchange_grads(overlap, surgery)
             if it < cfg.optim.densify_until_iter:
                 self._densify_stats(data)
-                if it > cfg.optim.densify_from_iter and "countlist" in data:        # `trainer.py:350-356`
-                    cl = data["countlist"]
-                    if self.world > 1:
-                        cl = cl.clone()
-                        dist.all_reduce(cl, op=dist.ReduceOp.SUM)
+                if it > cfg.optim.densify_from_iter and "countlist" in data and not self._stats_dirty:        # `trainer.py:350-356`
+                    cl = data["countlist"]                # (data parallel: `_densify_stats` accumulated it with the other deltas)
                     self.visi_list = cl if self.visi_list is None else self.visi_list + cl
+            if surgery:
+                self.sync_densify_stats()                 # (data parallel; before anything reads or re-indexes the statistics)
+            if it < cfg.optim.densify_until_iter:
                 if it > cfg.optim.densify_from_iter and it % cfg.optim.densification_interval == 0:
                     size_threshold = 20 if it > cfg.optim.opacity_reset_interval else None
                     visi = None
@@ -522,6 +547,7 @@ class BenchTrainer:
                 getattr(m, k).data.copy_(v)
         m.optimizer.state = {}
         m.optimizer.zero_grad(set_to_none=True)
+        tr._stats_delta, tr._visi_delta, tr._stats_dirty = None, None, False
         tr.current_iteration, rng_state, tr.view_order, lrs, m.active_sh_degree = host
         tr.rng.setstate(rng_state)
         for g, (name, lr) in zip(m.optimizer.param_groups, lrs):
