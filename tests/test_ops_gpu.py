@@ -309,6 +309,7 @@ def test_rccl_exchange_path_single_rank_group(device):
             assert tr.last_exchange == {(False, False): "none", (True, False): "factorised",
                                         (True, True): "factorised-deferred"}[(coll, overlap)]
             tr.join_side()
+            tr.sync_densify_stats()            # (collective runs: the statistics are rank-local deltas until they are read)
             torch.cuda.synchronize()
             finals.append({k: getattr(tr.model, k).detach().clone() for k in ["_features_rest", "_xyz", "_scaling"]})
             stats = (tr.model.xyz_gradient_accum.clone(), tr.model.denom.clone(), tr.model.max_radii2D.clone())
