@@ -8,8 +8,9 @@ Per iteration (same order as `Trainer.train_step`, `trainer.py:323-392`):
 
 Data parallelism: one process per GPU; every rank holds a full replica (parameters, Adam moments,
 densification statistics), renders ITS OWN camera of the step's batch of `world` cameras, and the
-gradients are summed across ranks and scaled by 1/world inside the fused Adam kernel.  All schedule
-decisions depend only on all-reduced quantities, so replicas stay in lock-step without broadcasts.
+gradients are summed across ranks and scaled by 1/world inside the fused Adam kernel.  The densification
+statistics accumulate per rank and are reduced where they are read (`sync_densify_stats`).  All schedule
+decisions depend only on reduced quantities, so replicas stay in lock-step without broadcasts.
 """
 import os
 import random
