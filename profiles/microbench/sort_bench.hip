@@ -1,6 +1,6 @@
 // Correctness + timing of csrc/radix_sort.hip against rocPRIM radix_sort_pairs and std::stable_sort, at the two sizes
 // the rasterizer sorts (1e6 x 32-bit depth keys, 3e6 x 13-bit tile keys).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../vcr-gaus_amd/csrc sort_bench.hip ../../vcr-gaus_amd/csrc/radix_sort.hip -o sort_bench
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../vcr_gaus_amd/csrc sort_bench.hip ../../vcr_gaus_amd/csrc/radix_sort.hip -o sort_bench
 #include "vcr_common.h"
 #include <rocprim/device/device_radix_sort.hpp>
 #include <algorithm>
@@ -67,16 +67,16 @@ int main() {
     std::vector<uint2> rg(T);
     std::mt19937 rng(7);
     for (int i = 0; i < T; ++i) { rg[i].x = 0; rg[i].y = (rng() % 100 < 84) ? 0 : rng() % 3000; }
-    uint2* drg; uint32_t* dord; hipMalloc(&drg, T * 8); hipMalloc(&dord, T * 4);
+    uint2* drg; uint32_t *dord, *dmeta; hipMalloc(&drg, T * 8); hipMalloc(&dord, T * 4); hipMalloc(&dmeta, VCR_BIN_META_WORDS * 4);
     hipMemcpy(drg, rg.data(), T * 8, hipMemcpyHostToDevice);
     hipMemset(dord, 0xFF, T * 4);
-    vcr_launch_tile_order(T, drg, dord, true, false, 0);
+    vcr_launch_tile_order(T, drg, dord, dmeta, true, false, 0);
     std::vector<uint32_t> ord(T);
     hipMemcpy(ord.data(), dord, T * 4, hipMemcpyDeviceToHost);
     std::vector<int> seen(T, 0); int badp = 0, inv = 0;
     for (int i = 0; i < T; ++i) { if (ord[i] >= (uint32_t)T || seen[ord[i]]++) ++badp; }
     for (int i = 1; i < T && !badp; ++i) inv += ((rg[ord[i]].y >> 2) > (rg[ord[i - 1]].y >> 2));
-    vcr_launch_tile_order(T, drg, dord, true, true, 0);
+    vcr_launch_tile_order(T, drg, dord, dmeta, true, true, 0);
     hipMemcpy(ord.data(), dord, T * 4, hipMemcpyDeviceToHost);
     std::fill(seen.begin(), seen.end(), 0); int badp2 = 0;
     for (int i = 0; i < T; ++i) { if (ord[i] >= (uint32_t)T || seen[ord[i]]++) ++badp2; }
