@@ -317,3 +317,19 @@ def test_presets_equal_the_reference_effective_configs():
         for k, v in flat(want[tag]).items():
             assert k in got, (tag, k)
             assert got[k] == v or (isinstance(v, float) and abs(got[k] - v) <= 1e-12 * abs(v)), (tag, k, got[k], v)
+
+
+def test_missing_library_is_a_loud_error_not_a_fallback(tmp_path):
+    """The product path has no CPU fallback: without the HIP library every entry point fails at load time with a message that
+    says so (checked in a fresh interpreter, because the handle is cached per process)."""
+    import subprocess
+    import sys
+    code = ("import torch\n"
+            "from vcr_gaus_amd import _lib, loss_utils\n"
+            "try:\n"
+            "    loss_utils.l1_ssim(torch.rand(3, 8, 8, requires_grad=True), torch.rand(3, 8, 8))\n"
+            "except ImportError as e:\n"
+            "    print('LOUD', 'No CPU fallback' in str(e))\n")
+    env = dict(os.environ, VCR_LIB=str(tmp_path / "absent.so"), PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "LOUD True" in out.stdout, out.stdout + out.stderr
