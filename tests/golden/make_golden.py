@@ -38,13 +38,14 @@ def save(name, **arrs):
 def depth_cases():
     g = torch.Generator().manual_seed(0)
     out = {}
-    for tag, (H, W) in {"a": (48, 64), "b": (37, 53)}.items():
+    for tag, (H, W) in {"a": (48, 64), "b": (37, 53), "c": (256, 256)}.items():     # c: SURVEY 8(c)'s 256 x 256 case
         K = RG.getIntrinsic(1.1, 0.9, H, W)
         yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
         plane = 2.0 + 0.01 * xx + 0.02 * yy
         sphere = 3.0 - torch.sqrt(torch.clamp(1.0 - ((xx - W / 2) / W) ** 2 - ((yy - H / 2) / H) ** 2, min=0.05))
         rnd = 1.5 + torch.rand(H, W, generator=g)
-        for dn, d in {"plane": plane, "sphere": sphere, "rand": rnd}.items():
+        kinds = {"plane": plane, "sphere": sphere, "rand": rnd} if tag != "c" else {"sphere": sphere + 0.02 * (rnd - 2.0)}
+        for dn, d in kinds.items():
             d = d[None].clone().requires_grad_(True)
             n = RN.compute_normals(d, K)
             gt = torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1)
@@ -218,6 +219,74 @@ def config_cases():
     print("wrote g9_effective_configs.json")
 
 
+def _scene_stub():
+    """`scene` as a bare namespace package, so that `scene.cameras` imports without running `scene/__init__` (dataset readers)."""
+    if "scene" not in sys.modules:
+        pkg = types.ModuleType("scene")
+        pkg.__path__ = [os.path.join(REF, "scene")]
+        sys.modules["scene"] = pkg
+
+
+def bb_camera_cases():
+    """`tools/camera_utils.py:315-401` (`bb_camera`) in every placement mode, on a vector `trans` and on a 4x4 world -> box
+    transform; the 'random' placements are seeded through the global RNG the reference draws from."""
+    _scene_stub()
+    from tools import camera_utils as RC
+    out = {}
+    A = torch.tensor([[0.0, 0.0, 1.0], [0.0, -1.0, 0.0], [1.0, 0.0, 0.0]])       # world -> box: axes permuted, up flipped
+    T4 = torch.eye(4)
+    T4[:3, :3], T4[:3, 3] = A, torch.tensor([0.2, -0.1, 0.4])
+    boxes = {"vec": (torch.tensor([0.3, -0.2, 0.5]), torch.tensor([1.5, 1.0, 0.8])), "mat": (T4, torch.tensor([1.2, 0.7, 2.0]))}
+    cases = {
+        "random_around": dict(n=17, up=False, around=True, sample_mode="random"),
+        "random_up": dict(n=9, up=True, around=False, sample_mode="random"),
+        "random_both": dict(n=40, up=True, around=True, sample_mode="random", bidirect=True),
+        "grid_both": dict(n=60, up=True, around=True, sample_mode="grid"),
+        "grid_around": dict(n=50, up=False, around=True, sample_mode="grid"),
+        "grid_up": dict(n=30, up=True, around=False, sample_mode="grid"),
+        "grid_bidirect": dict(n=80, up=False, around=True, sample_mode="grid", bidirect=True),
+        "grid_bidirect_up": dict(n=90, up=True, around=True, sample_mode="grid", bidirect=True),
+        "grid_direction": dict(n=70, up=True, around=True, sample_mode="grid", look_mode="direction"),
+        "random_direction": dict(n=21, up=True, around=True, sample_mode="random", look_mode="direction"),
+        "grid_opengl_target": dict(n=45, up=False, around=True, sample_mode="grid", opengl=True, target=np.array([[0.1, 0.2, -0.3]], dtype=np.float32)),
+    }
+    import json
+    meta = {}
+    for bname, (trans, scale) in boxes.items():
+        out[f"{bname}_trans"], out[f"{bname}_scale"] = trans, scale
+        for cname, kw in cases.items():
+            kw = dict(kw)
+            n = kw.pop("n")
+            seed = 100 + len(meta)
+            torch.manual_seed(seed)
+            out[f"{bname}_{cname}"] = RC.bb_camera(n, trans, scale, None, **kw)
+            meta[f"{bname}_{cname}"] = dict(n=n, seed=seed, **{k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+    out["meta"] = np.array(json.dumps(meta))
+    # SampleCam matrices of `Trainer.sample_cameras` (`trainer.py:621-634`: 1500 x 1500, FoV 2.5 rad) for two of them
+    from scene.cameras import SampleCam
+    for k in ("vec_random_around", "mat_grid_both"):
+        cam = SampleCam(out[k][1], 1500, 1500, 2.5, 2.5, device="cpu")
+        out[f"{k}_cam_view"], out[f"{k}_cam_full"], out[f"{k}_cam_center"] = cam.world_view_transform, cam.full_proj_transform, cam.camera_center
+    save("g11_bb_camera.npz", **out)
+
+
+def prune_score_cases():
+    """`tools/prune.py:6-22` (`calculate_v_imp_score`) and the percentile threshold of `GaussianModel.prune_gaussians` inputs."""
+    gr = types.ModuleType("gaussian_renderer")
+    gr.count_render = gr.visi_acc_render = None
+    sys.modules.setdefault("gaussian_renderer", gr)
+    from tools import prune as RP
+    g = torch.Generator().manual_seed(12)
+    out = {}
+    for tag, n in {"a": 1000, "b": 37}.items():
+        scaling = torch.exp(torch.randn(n, 3, generator=g) - 3.0)
+        imp = torch.rand(n, generator=g) * (torch.rand(n, generator=g) > 0.2)
+        for v_pow in (0.1, 0.5):
+            out[f"{tag}_v{int(v_pow * 10)}"] = RP.calculate_v_imp_score(types.SimpleNamespace(get_scaling=scaling), imp, v_pow)
+        out[f"{tag}_scaling"], out[f"{tag}_imp"] = scaling, imp
+    save("g12_v_imp_score.npz", **out)
+
+
 def _load_reference_gaussian_model():
     """Import /root/reference/scene/gaussian_model.py on the CPU: stub the absent third-party modules, keep `scene/__init__`
     (dataset readers, PIL, cv2 ...) from running, and route the hard-coded device="cuda" allocations to the CPU."""
@@ -263,10 +332,74 @@ def _load_reference_gaussian_model():
     return mod
 
 
+_RGM = None
+
+
+def _ref_model_module():
+    global _RGM
+    if _RGM is None:
+        _RGM = _load_reference_gaussian_model()
+    return _RGM
+
+
+def checkpoint_cases():
+    """The reference's checkpoint wire format -- `torch.save((model.capture(), iteration), "chkpntN.pth")`
+    (`trainer.py:425-430`, `scene/gaussian_model.py:88-123`) -- written by the reference's own GaussianModel and
+    torch.optim.Adam after three real optimizer steps, plus what ONE MORE step from that state gives (gradients in,
+    parameters out), so that a restore can be checked by continuing the run."""
+    RGM = _ref_model_module()
+    N = 48
+    cfgm = types.SimpleNamespace(sh_degree=3, max_mem=22, use_decoupled_appearance=False, enable_semantic=True, ch_sem_feat=2,
+                                 num_cls=2)
+    targs = types.SimpleNamespace(percent_dense=0.01, densify_large=types.SimpleNamespace(percent_dense=2e-3),
+                                  position_lr_init=1.6e-4, position_lr_final=1.6e-6, position_lr_delay_mult=0.01,
+                                  position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05, scaling_lr=5e-3,
+                                  rotation_lr=1e-3, cls_lr=5e-4)
+    g = torch.Generator().manual_seed(21)
+    torch.manual_seed(21)                                  # (the classifier's Conv2d initialisation)
+    m = RGM.GaussianModel(cfgm)
+    shapes = dict(_xyz=(N, 3), _features_dc=(N, 1, 3), _features_rest=(N, 15, 3), _opacity=(N, 1), _scaling=(N, 3),
+                  _rotation=(N, 4), _objects_dc=(N, 1, 2))
+    for a, shp in shapes.items():
+        setattr(m, a, torch.nn.Parameter(torch.randn(shp, generator=g).requires_grad_(True)))
+    m.max_radii2D = torch.zeros(N)
+    m.spatial_lr_scale = 2.5
+    m.training_setup(targs)
+
+    def one_step(it):
+        m.update_learning_rate(it)
+        grads = {}
+        for grp in m.optimizer.param_groups:
+            for k, p in enumerate(grp["params"]):
+                p.grad = 1e-2 * torch.randn(p.shape, generator=g) * (torch.rand(p.shape, generator=g) > 0.1)
+                grads[grp["name"] if len(grp["params"]) == 1 else f"{grp['name']}.{k}"] = p.grad.clone()
+        m.optimizer.step()
+        m.optimizer.zero_grad(set_to_none=True)
+        return grads
+
+    for it in (1, 2, 3):
+        one_step(it)
+    m.active_sh_degree = 2
+    m.xyz_gradient_accum = 1e-3 * torch.rand(N, 1, generator=g)
+    m.denom = torch.randint(0, 3, (N, 1), generator=g).float()
+    m.max_radii2D = 30.0 * torch.rand(N, generator=g)
+    cls0 = [p.detach().clone() for p in m.classifier.parameters()]
+    torch.save((m.capture(), 3), os.path.join(HERE, "g10_chkpnt3.pth"))
+    print("wrote g10_chkpnt3.pth")
+    grads = one_step(4)
+    out = {f"grad_{k}": v for k, v in grads.items()}
+    for grp in m.optimizer.param_groups:
+        for k, p in enumerate(grp["params"]):
+            out["after_" + (grp["name"] if len(grp["params"]) == 1 else f"{grp['name']}.{k}")] = p.detach().clone()
+        out[f"lr_{grp['name']}"] = np.array(grp["lr"])
+    out["classifier_weight"], out["classifier_bias"] = cls0
+    save("g10_chkpnt3_next_step.npz", **out)
+
+
 def densify_cases():
     """`scene/gaussian_model.py:361-364,425-671` executed by the reference's own GaussianModel on seeded inputs: the
     state (parameters, Adam moments, densification statistics) before and after each operation."""
-    RGM = _load_reference_gaussian_model()
+    RGM = _ref_model_module()
     out = {}
     N, extent = 320, 3.3
     names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "obj_dc"]
@@ -382,7 +515,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = dict(g1=depth_cases, g2=image_cases, g3=sh_cases, g4=camera_cases, g5=misc_cases, g7=misc_grad_cases, g8=tsdf_input_cases, g9=config_cases, g6=densify_cases)
-    for k, fn in todo.items():          # g6 last: it monkey-patches torch.zeros / torch.cuda for the reference model
+    todo = dict(g1=depth_cases, g2=image_cases, g3=sh_cases, g4=camera_cases, g5=misc_cases, g7=misc_grad_cases, g8=tsdf_input_cases, g9=config_cases, g11=bb_camera_cases, g12=prune_score_cases,
+                g6=densify_cases, g10=checkpoint_cases)
+    for k, fn in todo.items():          # g6 / g10 last: it monkey-patches torch.zeros / torch.cuda for the reference model
         if not a.only or k in a.only.split(","):
             fn()

@@ -17,14 +17,14 @@ def load(name):
     return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, name)).items()}
 
 
-@pytest.mark.parametrize("tag", ["a_plane", "a_sphere", "a_rand", "b_plane", "b_sphere", "b_rand"])
+@pytest.mark.parametrize("tag", ["a_plane", "a_sphere", "a_rand", "b_plane", "b_sphere", "b_rand", "c_sphere"])
 def test_depth_normal_and_dnormal_loss_vs_reference_vectors(device, tag):
     from vcr_gaus_amd.loss_utils import normal_loss
     from vcr_gaus_amd.normal_utils import compute_normals
     g = load("g1_depth_normal.npz")
     d = g[f"{tag}_depth"].to(device).requires_grad_(True)
     n = compute_normals(d, g[f"{tag}_K"])
-    assert torch.allclose(n.cpu(), g[f"{tag}_normal"], atol=5e-5)      # fp32 tolerance
+    assert torch.allclose(n.cpu(), g[f"{tag}_normal"], atol=5e-5 if tag[0] != "c" else 1.5e-4)      # fp32 tolerance (c: see test_oracle_cpu)
     loss = normal_loss(n, g[f"{tag}_gt"].to(device), weight_src=g[f"{tag}_rn"].to(device), exp_t=0.01,
                        mask=g[f"{tag}_mask"].to(device))
     ref = float(g[f"{tag}_loss"])

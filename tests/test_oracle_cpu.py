@@ -28,12 +28,14 @@ def test_sh_colour_rule_matches_reference():
         assert torch.allclose(rgb, g[f"rgb_deg{deg}"], atol=1e-6)
 
 
-@pytest.mark.parametrize("tag", ["a_plane", "a_sphere", "a_rand", "b_plane", "b_sphere", "b_rand"])
+@pytest.mark.parametrize("tag", ["a_plane", "a_sphere", "a_rand", "b_plane", "b_sphere", "b_rand", "c_sphere"])
 def test_depth_normal_chain_matches_reference(tag):
     g = load("g1_depth_normal.npz")
     d = g[f"{tag}_depth"].double().requires_grad_(True)
     n = OL.compute_normals(d, g[f"{tag}_K"])
-    assert torch.allclose(n.float(), g[f"{tag}_normal"], atol=2e-5)
+    # (c: 256 x 256 -- neighbouring back-projected points differ by ~1e-2 of their magnitude, so the fp32 differences of the
+    # reference's own torch.gradient carry ~3e-5 of rounding noise in the unit normal; measured 3.4e-5 against fp64)
+    assert torch.allclose(n.float(), g[f"{tag}_normal"], atol=2e-5 if tag[0] != "c" else 1e-4)
     loss = OL.masked_weighted_normal_loss(n, g[f"{tag}_gt"].double(), g[f"{tag}_rn"].double(), 0.01, g[f"{tag}_mask"])
     assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-5 * max(1.0, abs(float(g[f"{tag}_loss"])))
     loss.backward()

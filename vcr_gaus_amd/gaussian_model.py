@@ -207,15 +207,65 @@ class FusedAdam:
                 elif p.grad is not None:
                     p.grad.zero_()
 
+    # ---- checkpoint wire format: `torch.optim.Adam.state_dict()` layout (`scene/gaussian_model.py:88-123` stores it in
+    # `capture()`, `trainer.py:170-172,425-430` writes / reads `chkpntN.pth`).  `state` is keyed by the parameter's running
+    # index over all groups, `step` is a float32 scalar tensor, every group lists its `params` indices and carries torch's
+    # hyper-parameter keys; the 1x1-conv classifier is ONE group named "classifier" with two parameters there, kept here
+    # as two single-tensor groups "classifier.weight" / "classifier.bias" and merged / split on the way out / in. ----
+    @staticmethod
+    def _wire_name(name):
+        return name.split(".", 1)[0] if name.startswith("classifier.") else name
+
     def state_dict(self):
-        return dict(state={k: dict(v) for k, v in self.state.items()},
-                    param_groups=[dict(name=g["name"], lr=g["lr"]) for g in self.param_groups])
+        template = torch.optim.Adam([torch.zeros(1)], lr=0.0, eps=self.eps, betas=self.betas).param_groups[0]
+        state, groups, idx = {}, [], 0
+        for g in self.param_groups:
+            wire = self._wire_name(g["name"])
+            if groups and groups[-1]["name"] == wire:          # second tensor of the classifier group
+                wg = groups[-1]
+            else:
+                wg = {k: v for k, v in template.items() if k != "params"}
+                wg.update(lr=g["lr"], name=wire, params=[])
+                groups.append(wg)
+            wg["params"].append(idx)
+            st = self.state.get(g["name"])
+            if st is not None:
+                state[idx] = dict(step=torch.tensor(float(st["step"])), exp_avg=st["exp_avg"], exp_avg_sq=st["exp_avg_sq"])
+            idx += 1
+        return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):
-        self.state = {k: dict(v) for k, v in sd["state"].items()}
-        lrs = {g["name"]: g["lr"] for g in sd["param_groups"]}
+        """Accepts what the reference's `torch.optim.Adam.state_dict()` holds (and, for older files of this repo, the
+        name-keyed form).  Groups are matched by name; moments land on the device of the parameter they belong to."""
+        by_wire = {}
         for g in self.param_groups:
-            g["lr"] = lrs.get(g["name"], g["lr"])
+            by_wire.setdefault(self._wire_name(g["name"]), []).append(g)
+        self.state = {}
+        if sd["state"] and not all(isinstance(k, int) for k in sd["state"]):          # legacy: state keyed by group name
+            for k, v in sd["state"].items():
+                self.state[k] = dict(step=int(v["step"]), exp_avg=v["exp_avg"], exp_avg_sq=v["exp_avg_sq"])
+            lrs = {g["name"]: g["lr"] for g in sd["param_groups"]}
+            for g in self.param_groups:
+                g["lr"] = lrs.get(g["name"], g["lr"])
+            return
+        for wg in sd["param_groups"]:
+            mine = by_wire.get(wg.get("name"))
+            if mine is None:
+                continue                                       # (e.g. the appearance network: not part of this model)
+            if len(mine) != len(wg["params"]):
+                raise ValueError(f"optimizer group {wg.get('name')!r}: {len(wg['params'])} tensors saved, {len(mine)} here")
+            for g, i in zip(mine, wg["params"]):
+                g["lr"] = float(wg["lr"])
+                st = sd["state"].get(i)
+                if st is None:
+                    continue
+                p = g["params"][0]
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state of {g['name']!r} has shape {tuple(st['exp_avg'].shape)}, "
+                                     f"parameter {tuple(p.shape)}")
+                mv = lambda t: t.detach().to(device=p.device, dtype=torch.float32).contiguous()
+                self.state[g["name"]] = dict(step=int(round(float(st["step"]))), exp_avg=mv(st["exp_avg"]),
+                                             exp_avg_sq=mv(st["exp_avg_sq"]))
 
 
 class GaussianModel:
@@ -653,9 +703,28 @@ class GaussianModel:
                 self._opacity, self._objects_dc, self.max_radii2D, self.xyz_gradient_accum, self.denom,
                 self.optimizer.state_dict(), self.spatial_lr_scale)
 
-    def restore(self, model_args, training_args):
-        (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
-         self._opacity, self._objects_dc, self.max_radii2D, acc, den, opt, self.spatial_lr_scale) = model_args
+    def restore(self, model_args, training_args, device=None):
+        """`scene/gaussian_model.py:102-123`.  `model_args` is the tuple of `capture()` -- this repo's or the reference's
+        (the first element of a `chkpntN.pth`, `trainer.py:170-172`); `device`: where the model shall live (default: where
+        the checkpoint's tensors are)."""
+        (self.active_sh_degree, xyz, f_dc, f_rest, scaling, rotation, opacity, obj_dc, radii, acc, den, opt,
+         self.spatial_lr_scale) = model_args
+        dev = torch.device(device) if device is not None else xyz.device
+        mk = lambda t: torch.nn.Parameter(t.detach().to(device=dev, dtype=torch.float32).contiguous().requires_grad_(True))
+        self._xyz, self._features_dc, self._features_rest = mk(xyz), mk(f_dc), mk(f_rest)
+        self._scaling, self._rotation, self._opacity = mk(scaling), mk(rotation), mk(opacity)
+        if obj_dc is not None and obj_dc.numel() > 0:
+            self.enable_semantic = True
+            self._objects_dc = mk(obj_dc)
+            self.ch_sem_feat = int(obj_dc.shape[-1])
+            self.num_cls = self.num_cls or 2
+            if self.classifier is None:          # (its weights travel in the reference's model.pth, not in the checkpoint)
+                self.classifier = torch.nn.Conv2d(self.ch_sem_feat, self.num_cls, kernel_size=1)
+            self.classifier = self.classifier.to(dev)
+        else:
+            self._objects_dc = torch.empty(0, device=dev)
+        self.max_radii2D = radii.detach().to(dev).float()
+        self.trans, self.scale = self.trans.to(dev), self.scale.to(dev)
         self.training_setup(training_args)
-        self.xyz_gradient_accum, self.denom = acc, den
+        self.xyz_gradient_accum, self.denom = acc.detach().to(dev).float(), den.detach().to(dev).float()
         self.optimizer.load_state_dict(opt)

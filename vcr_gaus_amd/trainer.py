@@ -334,8 +334,9 @@ class Trainer:
         self._stats_dirty = True
 
     def sync_densify_stats(self):
-        """Data parallel: sum the rank-local statistic deltas (and maximise `max_radii2D`) over the ranks.  Called before
-        densify / prune / any row surgery and before a checkpoint; a no-op on one GPU or when nothing was accumulated."""
+        """Data parallel: sum the rank-local statistic deltas (and maximise `max_radii2D`) over the ranks.  `train_step`
+        calls it before densify / prune / any row surgery, `Trainer.capture` before a checkpoint is taken (use that, not
+        `model.capture()`, while training data-parallel); a no-op on one GPU or when nothing was accumulated."""
         if not self._stats_dirty:
             return
         m = self.model
@@ -351,6 +352,31 @@ class Trainer:
         if self._visi_delta is not None:
             self.visi_list = self._visi_delta if self.visi_list is None else self.visi_list + self._visi_delta
         self._stats_delta, self._visi_delta, self._stats_dirty = None, None, False
+
+    # ---- checkpoints (`trainer.py:170-172,425-430`): `torch.save((model.capture(), iteration), "chkpntN.pth")` ----------
+    def capture(self):
+        """-> `(model.capture(), current_iteration)`, the tuple the reference saves.  First applies a still-pending SH
+        update (two-stream form) and folds the rank-local densification statistics into the replicated accumulators, so
+        that a run resumed from the file densifies exactly like the uninterrupted one.  Data parallel: a COLLECTIVE --
+        every rank must call it at the same iteration (all ranks then hold the same tuple; rank 0 writes the file)."""
+        self.join_side()
+        self.sync_densify_stats()
+        return (self.model.capture(), self.current_iteration)
+
+    def save_checkpoint(self, path):
+        state = self.capture()
+        if self.rank == 0:
+            torch.save(state, path)
+
+    def load_checkpoint(self, path):
+        """Resume from a `chkpntN.pth` written by `save_checkpoint` or by the reference's trainer."""
+        self.join_side()
+        model_params, first_iter = torch.load(path, map_location="cpu", weights_only=False)
+        self.model.restore(model_params, self.cfg.optim, device=self.device)
+        self.model.extent = self.extent
+        self.current_iteration = int(first_iter)
+        self._stats_delta, self._visi_delta, self._stats_dirty = None, None, False
+        self._pending_sh, self.visi_list = None, None
 
     # ---- visibility / importance passes (`tools/prune.py:6-69`, `trainer.py:688-702`), camera-sharded ------------
     @torch.no_grad()
@@ -387,10 +413,9 @@ class Trainer:
         return [self.cameras[self.rng.randrange(len(self.cameras))] for _ in range(sc.num)]
 
     def v_imp_score(self, imp, v_pow):
-        """`tools/prune.py:6-22`."""
-        vol = torch.prod(self.model.get_scaling, dim=1)
-        kth = torch.sort(vol, descending=True)[0][int(len(vol) * 0.9)]
-        return torch.pow(vol / kth, v_pow) * imp
+        """`tools/prune.py:6-22` (fixture g12)."""
+        from .prune import calculate_v_imp_score
+        return calculate_v_imp_score(self.model, imp, v_pow)
 
     # ---- one iteration ------------------------------------------------------------------------------------------
     def train_step(self):
