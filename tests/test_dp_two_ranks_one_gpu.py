@@ -58,3 +58,92 @@ def test_two_ranks_on_one_gpu_stay_identical(device, tmp_path, overlap):
     assert r0["losses"] != r1["losses"]                                                      # (each rank saw its own view)
     want = "factorised-deferred" if overlap else "factorised"
     assert want in r0["exch"] and r0["exch"] == r1["exch"], r0["exch"]
+
+
+# ---- equivalence: two real-kernel ranks == one process that accumulates the same two cameras ------------------------------
+GROUPS = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling",
+          "rotation": "_rotation"}
+
+
+def _scene(dev):
+    from vcr_gaus_amd import synthetic
+    raw = synthetic.make_gaussians(5000, seed=22)
+    raw["scaling"] = raw["scaling"] + 1.2
+    return raw, synthetic.make_cameras(4, 128, 96, 110.0, device=dev)
+
+
+NO_SURGERY = {"densify_from_iter": 10 ** 9, "prune": {"iterations": []}}
+
+
+def _worker_one_step(rank, world, port, out, overlap):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    from vcr_gaus_amd.trainer import make_synthetic_trainer
+    raw, cams = _scene(dev)
+    tr = make_synthetic_trainer(raw, cams, dev, world=world, rank=rank, preset="tnt", overlap_sh=overlap, overlap_min_gaussians=0,
+                                optim=NO_SURGERY)
+    m = tr.model
+    grads = {}
+    real_step = m.optimizer.step
+
+    def capture(*a, **k):                  # the REDUCED gradients, as the optimizer sees them (SH groups step first)
+        for g in m.optimizer.param_groups:
+            p = g["params"][0]
+            if p.grad is not None and g["name"] not in grads:
+                grads[g["name"]] = p.grad.detach().cpu().clone()
+        return real_step(*a, **k)
+
+    m.optimizer.step = capture
+    tr.train_step()
+    tr.join_side()
+    torch.cuda.synchronize()
+    torch.save(dict(picks=list(tr._picked), grads=grads, scale=m.optimizer.grad_scale, exch=tr.last_exchange,
+                    params={k: getattr(m, a).detach().cpu() for k, a in GROUPS.items()}), out + f".{rank}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_ranks_equal_one_process_accumulating_the_same_cameras(device, tmp_path, overlap):
+    """SURVEY 8(e) semantics: a world-2 step is gradient accumulation over the step's two cameras with the mean applied.
+    Two ranks with the real kernels (each renders ITS camera, factorised exchange: all-gather of dL/drgb + bucket
+    all-reduce, serial and deferred form) against ONE process that renders both cameras, lets autograd sum the
+    gradients and steps the fused Adam with grad_scale = 1/2.  Differences: the order of the fp32 atomics only."""
+    from tests import util
+    from vcr_gaus_amd import fused_losses
+    from vcr_gaus_amd.gaussian_renderer import render
+    from vcr_gaus_amd.trainer import make_synthetic_trainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "dp1.pt")
+    mp.spawn(_worker_one_step, args=(2, port, out, overlap), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["picks"] == r1["picks"] and len(set(r0["picks"])) == 2 and r0["scale"] == 0.5
+    assert r0["exch"] == ("factorised-deferred" if overlap else "factorised")
+    # one process, both cameras, summed gradients
+    raw, cams = _scene(device)
+    tr = make_synthetic_trainer(raw, cams, device, preset="tnt", overlap_sh=False, optim=NO_SURGERY)
+    m = tr.model
+    tr.current_iteration = 1
+    m.update_learning_rate(1)
+    bg = tr.bg_table[1 % tr.bg_table.shape[0]]
+    for ci in r0["picks"]:
+        data = render(cams[ci], m, tr.cfg, bg, dirs=tr.dirs, lazy_mask=True, geometry=False)
+        loss = tr._compute_loss(data, cams[ci])
+        loss.backward(fused_losses.unit_seed(loss.device))
+    acc = {k: getattr(m, a).grad.detach().cpu().clone() for k, a in GROUPS.items()}
+    m.optimizer.grad_scale = 0.5
+    m.optimizer.step()
+    torch.cuda.synchronize()
+    lrs = {g["name"]: g["lr"] for g in m.optimizer.param_groups}
+    for k, a in GROUPS.items():
+        if k in r0["grads"]:               # (the deferred form never materialises the SH gradients)
+            assert torch.equal(r0["grads"][k], r1["grads"][k])
+            util.assert_grads_close(r0["grads"][k], acc[k], f"dp-sum:{k}", maxnorm_tol=2e-5, p99_tol=2e-4, p999_tol=2e-3)
+        else:
+            assert overlap and k in ("f_dc", "f_rest")
+        one, two = getattr(m, a).detach().cpu(), r0["params"][k]
+        assert torch.equal(two, r1["params"][k])
+        sig = acc[k].abs() > 1e-3 * acc[k].abs().max()        # first Adam step = -lr * sign(g): compare where g is not ~0
+        assert float((one - two).abs()[sig].max()) <= 2e-2 * lrs[k], (k, float((one - two).abs()[sig].max()), lrs[k])
+        assert float((one - two).abs().max()) <= 2.0 * lrs[k] * 1.001

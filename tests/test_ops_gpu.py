@@ -163,6 +163,31 @@ def test_visibility_and_importance_passes(device):
     assert bool(((cnt > 0) >= vis).all())      # visible & inside implies counted
     assert float(imp.min()) >= 0.0 and float(imp.max()) > 0.0
     assert tr.v_imp_score(imp, 0.1).shape[0] == 5000
+    # the remaining wrappers of the reference's renderer module and its tools/prune.py surface
+    from vcr_gaus_amd.gaussian_renderer import count_render, render, render_fast, visi_render
+    from vcr_gaus_amd.prune import get_visi_list, prune_list
+    full = render(cams[0], tr.model, tr.cfg, tr.background, dirs=None)
+    fast = render_fast(cams[0], tr.model, tr.cfg, tr.background)
+    assert set(fast) == {"render", "viewspace_points", "visibility_filter", "radii"}
+    assert torch.equal(fast["render"], full["render"]) and torch.equal(fast["radii"], full["radii"])
+    fast["render"].sum().backward()
+    assert tr.model._features_dc.grad is not None and fast["viewspace_points"].grad is not None
+    tr.model.optimizer.zero_grad()
+    vr, cr = visi_render(cams[1], tr.model, tr.cfg.pipline, tr.background), count_render(cams[1], tr.model, tr.cfg.pipline, tr.background)
+    assert torch.equal(vr["countlist"], cr["gaussians_count"]) and torch.equal(vr["important_score"], cr["important_score"])
+    c2, i2 = prune_list(tr.model, list(cams), tr.cfg.pipline, tr.background)
+    assert torch.equal(c2, cnt) and torch.allclose(i2, imp, rtol=1e-5, atol=1e-6)
+    assert torch.equal(get_visi_list(tr.model, list(cams), tr.cfg.pipline, tr.background)["visi"] & tr.model.get_inside_gaus_normalized()[0], vis)
+    # GaussianModel.get_normal (`scene/gaussian_model.py:168-192`): zero rows outside the bounding box unless is_all
+    m = tr.model
+    m.scale = torch.full((3,), 0.5, device=device)
+    inside = m.get_inside_gaus_normalized()[0]
+    act = OM.activations({k: getattr(m, a).detach().cpu() for k, a in dict(xyz="_xyz", f_dc="_features_dc", f_rest="_features_rest", opacity="_opacity", scaling="_scaling", rotation="_rotation").items()})
+    want = OM.get_normal(act["rotation"], act["scaling"])
+    n_all, n_in = m.get_normal(is_all=True).cpu(), m.get_normal().cpu()
+    assert 0 < int(inside.sum()) < inside.numel()
+    assert torch.allclose(n_all, want.float(), atol=1e-5)
+    assert torch.equal(n_in[~inside.cpu()], torch.zeros_like(n_in[~inside.cpu()])) and torch.equal(n_in[inside.cpu()], n_all[inside.cpu()])
 
 
 def test_scale_regulariser_and_fused_depth_mask(device):

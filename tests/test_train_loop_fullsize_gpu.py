@@ -1,0 +1,75 @@
+"""BASELINE config c3 AT ITS OWN SIZE: `Trainer.train_step` on the DTU-shape scene (300 k Gaussians, 800 x 600, preset
+`dtu_c3`: l1 + ssim + l1_scale + mono-normal + D-Normal + normal-consistency) through a COMPRESSED schedule that visits
+every branch of `trainer.py:323-392` within 160 iterations -- five densification steps (clone + deterministic split +
+prune, with the training-camera visibility passes of `densify_large`), the screen-size rule after the first opacity reset,
+two opacity resets, one importance-pruning iteration -- and then checks the model that comes out against the fp64 oracle
+on sampled tiles (forward and gradients), i.e. parity of the rasterizer on a TRAINED-shape scene rather than on the
+random initialisation.  Runs once in the serial form (what 300 k Gaussians select) and once with the two-stream form
+forced (what bench.py times from 400 k Gaussians)."""
+import pytest
+import torch
+
+from oracle import model_torch as OM
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+SCHEDULE = {"densify_from_iter": 20, "densification_interval": 25, "densify_until_iter": 140, "opacity_reset_interval": 55,
+            "prune": {"iterations": [150]}}
+
+
+@pytest.mark.parametrize("two_stream", [False, True])
+def test_c3_training_loop_at_size_then_oracle_parity(device, two_stream):
+    from vcr_gaus_amd import synthetic
+    from vcr_gaus_amd.trainer import make_synthetic_trainer
+    n, views, W, H, focal, sem = synthetic.WORKLOADS["c2_dtu_300k_800x600"]
+    raw = synthetic.make_gaussians(n, seed=0)
+    cams = synthetic.make_cameras(8, W, H, focal, device=device)
+    tr = make_synthetic_trainer(raw, cams, device, preset="dtu_c3", overlap_sh=two_stream, overlap_min_gaussians=0,
+                                optim=SCHEDULE)
+    m = tr.model
+    counts, totals = [n], []
+    for it in range(1, 161):
+        before = m._xyz.shape[0]
+        tr.train_step()
+        totals.append(tr.losses["total"])                  # (device scalars: no sync inside the loop)
+        now = m._xyz.shape[0]
+        densify = 20 < it < 140 and it % 25 == 0
+        if densify or it == 150:
+            assert now != before, f"iteration {it}: surgery left N unchanged"
+            counts.append(now)
+            # statistics / optimizer state follow the rows
+            assert m.xyz_gradient_accum.shape == (now, 1) and m.denom.shape == (now, 1) and m.max_radii2D.shape == (now,)
+            if densify:
+                assert float(m.denom.abs().max()) == 0.0 and float(m.max_radii2D.abs().max()) == 0.0
+            for g in m.optimizer.param_groups:
+                st = m.optimizer.state[g["name"]]
+                assert st["exp_avg"].shape == g["params"][0].shape == st["exp_avg_sq"].shape and g["params"][0].shape[0] == now
+        else:
+            assert now == before
+        if it in (55, 110):
+            assert float(torch.sigmoid(m._opacity).max()) <= 0.0100001      # `reset_opacity`
+        if it == 59:
+            assert float(m.denom.max()) == 9.0                              # 9 iterations since the densification at 50
+    tr.join_side()
+    torch.cuda.synchronize()
+    totals = torch.stack([t.detach().float() for t in totals]).cpu()
+    assert bool(torch.isfinite(totals).all())
+    assert float(totals[45:54].mean()) < float(totals[:9].mean())           # training reduces the loss before the first reset
+    assert counts[-1] <= 0.51 * counts[-2]              # importance pruning removed >= percent = 0.5 (ties at score 0 go too)
+    assert max(counts) > n
+    for a in ["_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"]:
+        assert bool(torch.isfinite(getattr(m, a)).all()), a
+    assert all(m.optimizer.state[g["name"]]["step"] == 160 for g in m.optimizer.param_groups)      # surgery keeps `step`
+    # ---- oracle parity of a render of the trained-shape model (sampled tiles, forward + gradients)
+    rawc = {k: getattr(m, a).detach().cpu() for k, a in dict(xyz="_xyz", f_dc="_features_dc", f_rest="_features_rest",
+                                                               opacity="_opacity", scaling="_scaling", rotation="_rotation").items()}
+    cam = synthetic.make_cameras(8, W, H, focal)[1]
+    act = OM.activations(rawc)
+    ncam = OM.camera_normals(OM.get_normal(act["rotation"], act["scaling"]), act["xyz"], cam.camera_center, cam.R_w2c)
+    inp = dict(means3D=act["xyz"], shs=act["shs"], normals=ncam.contiguous(), opac=act["opacity"], scales=act["scaling"],
+               rots=act["rotation"], sem=None)
+    from vcr_gaus_amd.graphics_utils import get_all_px_dir
+    info = util.sampled_tile_parity(device, cam, inp, get_all_px_dir(cam.intr, H, W), torch.tensor([0.15, 0.05, 0.3]), 37, 2000,
+                                    "c3-trained", min_alpha=0.05)
+    assert info["subset"] > 500

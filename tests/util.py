@@ -109,23 +109,58 @@ def grad_stats(a, b):
     return dict(maxnorm=rel_err(a, b), med=float(q[0]), p99=float(q[1]), p999=float(q[2]), max=float(e.max()) if e.numel() else 0.0)
 
 
-# Gradient acceptance used by every parity test: max-norm relative error < 1e-3 AND element-wise (abs+rel, see elem_err)
-# error < 1e-3 on 99 % and < 1e-2 on 99.9 % of the entries.  (Max-norm: measured 6e-7 .. 5.7e-4 over the parity cases; the
-# largest values belong to a Gaussian under a flipped pixel and move with the order of the fp32 atomics, which depends on
-# how the tiles are launched, hence 1e-3 rather than the 5e-4 of round 1.)  (A pixel whose alpha >= 1/255 or T < 1e-4 decision flips between fp32 and fp64
-# moves the gradients of the few Gaussians under it discretely -- those are the tolerated 0.1 %; the measured table is
-# committed as profiles/r2_grad_error_table.txt.)
+# Gradient acceptance used by every parity test, PER TENSOR: (max-norm relative error, element-wise p99, element-wise
+# p99.9; see elem_err) must stay below 3x the error of the ORACLE ITSELF run in fp32 against its fp64 self on the parity
+# cases -- the yardstick columns of profiles/r2_grad_error_table.txt, worst case over its six rows per tensor -- i.e. the
+# HIP path may be at most 3x as noisy as a plain fp32 evaluation of the same algorithm.  Floors: 2e-5 / 2e-5 / 2e-4
+# (below that the figure is a handful of fp32 ulps of a sum of ~100 terms).  Two tensors get 6x instead of 3x: the
+# gradients of the scales and the rotations pass through the Sigma2D -> Sigma3D -> (s, q) adjoint, which amplifies the
+# rounding of the three conic-gradient sums the compositing backward accumulates with fp32 atomics in arbitrary order
+# (measured 2 - 2.5x the oracle-fp32 figure; the oracle sums them pairwise in index order).
+# (A pixel whose alpha >= 1/255 or T < 1e-4 decision flips between fp32 and fp64 moves the gradients of the few
+# Gaussians under it discretely -- those are the tolerated 0.1 %.)
+_YARDSTICK = {                 # oracle-fp32 vs oracle-fp64: max-norm, p99, p99.9 (worst of the committed cases)
+    "means3D": (2.2e-4, 1.1e-4, 4.9e-4),
+    "shs": (3.3e-5, 3.6e-5, 5.1e-4),
+    "normals": (3.6e-4, 2.9e-5, 2.2e-4),
+    "opac": (3.0e-4, 1.1e-4, 1.3e-3),
+    "scales": (1.3e-4, 1.2e-4, 1.0e-3),
+    "rots": (4.0e-4, 1.1e-4, 7.4e-4),
+    "m2": (2.0e-4, 7.3e-5, 4.5e-4),
+    "m2d": (8.7e-5, 3.1e-5, 1.0e-4),
+    "sem": (4.5e-7, 2.6e-6, 3.9e-5),
+}
+_FACTOR = {"scales": 6.0, "rots": 6.0}
+_FLOOR = (2e-5, 2e-5, 2e-4)
+# raw-parameter gradients of the whole-step tests go through the activation chain of the same tensors
+_ALIAS = {"xyz": "means3D", "f_dc": "shs", "f_rest": "shs", "opacity": "opac", "scaling": "scales", "rotation": "rots",
+          "means2D_densify": "m2d", "means2D": "m2", "obj_dc": "sem", "col": "shs", "cov": "scales", "op": "opac", "nrm": "normals"}
+GRAD_TOL = {k: tuple(max(_FACTOR.get(k, 3.0) * y, f) for y, f in zip(v, _FLOOR)) for k, v in _YARDSTICK.items()}
+# ceiling for tensors without a yardstick row (and the figure the per-tensor values replace)
 GRAD_MAXNORM_TOL = 1e-3
 GRAD_ELEM_P99_TOL = 1e-3
 GRAD_ELEM_P999_TOL = 1e-2
 
 
-def assert_grads_close(got, ref, name, maxnorm_tol=GRAD_MAXNORM_TOL, p999_tol=GRAD_ELEM_P999_TOL, p99_tol=None):
+def grad_tolerance(name):
+    """-> (max-norm, p99, p99.9) tolerance for the tensor called `name` ("deg2:shs", "xyz", ... resolve to their row)."""
+    key = name.split(":")[-1]
+    key = _ALIAS.get(key, key)
+    return GRAD_TOL.get(key, (GRAD_MAXNORM_TOL, GRAD_ELEM_P99_TOL, GRAD_ELEM_P999_TOL))
+
+
+def assert_grads_close(got, ref, name, maxnorm_tol=None, p999_tol=None, p99_tol=None, scale=1.0):
+    """`scale`: documented per-test widening factor on the tensor's own tolerances; explicit *_tol values replace them."""
     st = grad_stats(got, ref)
-    p99_tol = GRAD_ELEM_P99_TOL * (p999_tol / GRAD_ELEM_P999_TOL) if p99_tol is None else p99_tol
-    assert st["maxnorm"] < maxnorm_tol, f"grad {name}: max-norm rel err {st['maxnorm']:.2e} (stats {st})"
-    assert st["p99"] < p99_tol, f"grad {name}: element-wise p99 err {st['p99']:.2e} (stats {st})"
-    assert st["p999"] < p999_tol, f"grad {name}: element-wise p99.9 err {st['p999']:.2e} (stats {st})"
+    t_max, t_p99, t_p999 = (scale * t for t in grad_tolerance(name))
+    if p999_tol is not None and p99_tol is None:
+        p99_tol = GRAD_ELEM_P99_TOL * (p999_tol / GRAD_ELEM_P999_TOL)
+    maxnorm_tol = t_max if maxnorm_tol is None else maxnorm_tol
+    p99_tol = t_p99 if p99_tol is None else p99_tol
+    p999_tol = t_p999 if p999_tol is None else p999_tol
+    assert st["maxnorm"] < maxnorm_tol, f"grad {name}: max-norm rel err {st['maxnorm']:.2e} >= {maxnorm_tol:.1e} (stats {st})"
+    assert st["p99"] < p99_tol, f"grad {name}: element-wise p99 err {st['p99']:.2e} >= {p99_tol:.1e} (stats {st})"
+    assert st["p999"] < p999_tol, f"grad {name}: element-wise p99.9 err {st['p999']:.2e} >= {p999_tol:.1e} (stats {st})"
     return st
 
 
@@ -149,3 +184,60 @@ def flip_clean_mask(cam, inp, out, ref, bg, sh_degree=3):
             power = -0.5 * (pre["conic"][:, 0] * dx * dx + pre["conic"][:, 2] * dy * dy) - pre["conic"][:, 1] * dx * dy
             clean &= ~(pre["vis"] & (power <= 0) & (pre["opacity"] * torch.exp(power) >= 0.5 / 255.0))
     return clean, int(bad.sum())
+
+
+def sampled_tile_parity(device, cam, inp, dirs, bg, stride, min_inst, name, min_alpha=0.5):
+    """Oracle parity of ONE full-size render on sampled tiles (see tests/test_fullsize_sampled_gpu.py): the HIP path renders
+    the whole scene `inp`; the fp64 oracle composites every `stride`-th tile from exactly the Gaussians that touch those
+    tiles.  Compared: sampled pixels, radii of the subset, gradients of a random loss restricted to the sampled tiles
+    (zero outside the subset).  Gaussians under a flipped pixel (< 5 %, asserted) are left out of the gradient check."""
+    n = inp["means3D"].shape[0]
+    H, W = cam.image_height, cam.image_width
+    (out, radii), hl = hip_forward(cam, inp, dirs, bg, device, requires_grad=True)
+    s = settings_for(cam, bg, OR.Settings)
+    with torch.no_grad():
+        pre = OR.preprocess(s, inp["means3D"], torch.zeros(n, 3), inp["shs"], None, inp["normals"], inp["sem"], inp["opac"],
+                            inp["scales"], inp["rots"], None)
+    gx, gy = pre["grid"]
+    tiles = torch.arange(0, gx * gy, stride)
+    hit = torch.zeros(n, dtype=torch.bool)
+    tmask = torch.zeros(gy * 16, gx * 16, dtype=torch.bool)
+    inst = 0
+    for t in tiles.tolist():
+        x, y = t % gx, t // gx
+        h = pre["vis"] & (pre["xmin"] <= x) & (x < pre["xmax"]) & (pre["ymin"] <= y) & (y < pre["ymax"])
+        inst += int(h.sum())
+        hit |= h
+        tmask[y * 16:(y + 1) * 16, x * 16:(x + 1) * 16] = True
+    tmask = tmask[:H, :W]
+    assert inst >= min_inst, f"sample too light: {inst} tile instances"
+    spx, spy, scon, sop = pre["px"][hit], pre["py"][hit], pre["conic"][hit], pre["opacity"][hit]
+    del pre
+    sub = {k: (None if v is None else v[hit]) for k, v in inp.items()}
+    (ref, rradii, _), rl = oracle_forward(cam, sub, dirs, bg, dtype=torch.float64, requires_grad=True, tile_stride=stride)
+    mism = float((radii.cpu()[hit] != rradii).double().mean())
+    assert mism < 1e-4, f"radii differ for {mism:.2e} of the subset"
+    o, r = out.detach().cpu().double()[:, tmask], ref.detach()[:, tmask]
+    badmask = ((o - r).abs() > 2e-4 + 1e-4 * r.abs()).any(0)
+    bad = int(badmask.sum())
+    assert bad <= max(4, int(2e-3 * o.shape[1])), f"{bad} of {o.shape[1]} sampled pixels differ"
+    ys, xs = torch.nonzero(tmask, as_tuple=True)
+    clean = torch.ones(int(hit.sum()), dtype=torch.bool)          # Gaussians of the subset not covering a flipped pixel
+    for y, x in zip(ys[badmask].tolist(), xs[badmask].tolist()):
+        dx, dy = spx - x, spy - y
+        power = -0.5 * (scon[:, 0] * dx * dx + scon[:, 2] * dy * dy) - scon[:, 1] * dx * dy
+        clean &= ~((power <= 0) & (sop * torch.exp(power) >= 0.5 / 255.0))       # contributes (or nearly does) at that pixel
+    assert float((~clean).double().mean()) < 0.05
+    assert float(ref[7][tmask].max()) > min_alpha               # the sample sees real coverage
+    g = torch.Generator().manual_seed(stride)
+    wgt = torch.randn(ref.shape, generator=g, dtype=torch.float64) * tmask[None]
+    (ref * wgt).sum().backward()
+    (out * wgt.float().to(device)).sum().backward()
+    for k in ["means3D", "shs", "normals", "opac", "scales", "rots", "m2", "sem"]:
+        if rl.get(k) is None or hl[k] is None:
+            continue
+        gfull = hl[k].grad.cpu()
+        assert float(gfull[~hit].abs().max()) == 0.0 if (~hit).any() else True, f"{k}: gradient outside the sampled subset"
+        assert_grads_close(gfull[hit][clean], rl[k].grad[clean], f"{name}:{k}")
+    assert_grads_close(hl["m2d"].grad.cpu()[hit][clean][:, :2], rl["m2d"].grad[clean][:, :2], f"{name}:m2d")
+    return dict(instances=inst, flipped=bad, sampled_pixels=int(o.shape[1]), subset=int(hit.sum()))

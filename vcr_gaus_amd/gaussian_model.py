@@ -358,12 +358,24 @@ class GaussianModel:
     def get_objects(self):
         return self._objects_dc
 
-    def get_normal(self, is_all=True):
-        """World-space shortest-axis normal (`scene/gaussian_model.py:168-192`); off the hot path —
-        `render()` uses `fused_activate`, which also orients and rotates it."""
-        rots = build_rotation(self.get_rotation)
-        axis = torch.argmin(self.get_scaling, dim=-1)
-        return rots.gather(2, axis[:, None, None].expand(-1, 3, -1)).squeeze(-1)
+    def get_normal(self, valid=None, idx=None, refine_sign=True, is_all=False):
+        """World-space shortest-axis normal (`scene/gaussian_model.py:168-192`): column `argmin(scale)` of the rotation.
+        `valid` None + `is_all=False` (the reference's default): rows outside the normalised bounding box stay zero.
+        Off the hot path -- `render()` uses `fused_activate`, which also orients and rotates the normal."""
+        fill = valid is None and not is_all
+        if valid is None:
+            valid = (torch.ones(self._xyz.shape[0], dtype=torch.bool, device=self.device) if is_all
+                     else self.get_inside_gaus_normalized()[0])
+        rot, scaling = self.get_rotation[valid], self.get_scaling[valid]
+        if idx is not None:
+            rot, scaling = rot[idx], scaling[idx]
+        axis = torch.argmin(scaling, dim=-1)
+        normals = build_rotation(rot).gather(2, axis[:, None, None].expand(-1, 3, -1)).squeeze(-1)
+        if fill:
+            out = torch.zeros_like(self._xyz)
+            out[valid] = normals
+            return out
+        return normals
 
     def get_covariance(self, scaling_modifier=1):
         L = build_rotation(self._rotation) * (scaling_modifier * self.get_scaling)[:, None, :]

@@ -172,3 +172,37 @@ def visi_acc_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, 
     """f_count=3 (`gaussian_renderer/__init__.py:467-571`): per-Gaussian visibility count only."""
     (count, radii), sp = _forward_only(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, 3)
     return {"viewspace_points": sp, "visibility_filter": radii > 0, "radii": radii, "countlist": count}
+
+
+def visi_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+    """f_count=2 (`gaussian_renderer/__init__.py:358-464`): per-Gaussian visibility count + importance + image."""
+    (count, score, image, radii), sp = _forward_only(viewpoint_camera, pc, pipe, bg_color, scaling_modifier,
+                                                     override_color, 2)
+    return {"render": image, "viewspace_points": sp, "visibility_filter": radii > 0, "radii": radii,
+            "countlist": count, "important_score": score}
+
+
+def render_fast(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_color=None):
+    """Colour-only differentiable render (`gaussian_renderer/__init__.py:167-247`): no normals, no per-pixel ray
+    directions, settings built without `f_count`; returns the first three output channels."""
+    grad_on = torch.is_grad_enabled()
+    screenspace_points = _zero_holder(pc.get_xyz).detach().requires_grad_(grad_on)
+    rs = _settings(viewpoint_camera, pc, bg_color, scaling_modifier, cfg.pipline.debug, 0)
+    rasterizer = GaussianRasterizer(raster_settings=rs, num_dist=0)
+    scales, rotations, opacity = fused_activate(pc, viewpoint_camera.camera_center,
+                                                _cam_rotation(viewpoint_camera, pc.get_xyz.device), False)
+    cov3D_precomp = None
+    if cfg.pipline.compute_cov3D_python:
+        cov3D_precomp, scales, rotations = pc.get_covariance(scaling_modifier), None, None
+    shs, shs_rest, colors_precomp = (pc._features_dc, pc._features_rest, None) if override_color is None \
+        else (None, None, override_color)
+    if override_color is None and cfg.pipline.convert_SHs_python:
+        from .sh_utils import eval_sh
+        shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+        dir_pp = pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
+        sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp / dir_pp.norm(dim=1, keepdim=True))
+        shs, shs_rest, colors_precomp = None, None, torch.clamp_min(sh2rgb + 0.5, 0.0)
+    out, radii = rasterizer(means3D=pc.get_xyz, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp,
+                            opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
+                            shs_rest=shs_rest)
+    return {"render": out[:3], "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
