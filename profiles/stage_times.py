@@ -36,7 +36,8 @@ for ci, c in enumerate(cams[:4]):
             torch.cuda.synchronize()
             _lib.profile_enable(True)
             _lib.profile_read()
-        out = render(c, m, cfg, bg, dirs=dirs, geometry=False)["render_out"]
+        pkg = render(c, m, cfg, bg, dirs=dirs, geometry=False)
+        out = pkg["render_out"]
         out.square().sum().backward()
     torch.cuda.synchronize()
     pr = _lib.profile_read()
@@ -44,5 +45,5 @@ for ci, c in enumerate(cams[:4]):
     line = {k: v[0] / max(v[1], 1) for k, v in pr.items()}
     for k, v in line.items():
         tot[k] = tot.get(k, 0.0) + v / 4
-    print(f"cam{ci} R={rasterizer.last_stats['R']} " + " ".join(f"{k}={1e3 * v:.1f}us" for k, v in line.items()), flush=True)
+    print(f"cam{ci} R={pkg['raster'].R} " + " ".join(f"{k}={1e3 * v:.1f}us" for k, v in line.items()), flush=True)
 print(f"MEAN {wl} x{mult}: " + " ".join(f"{k}={1e3 * v:.1f}us" for k, v in tot.items()), flush=True)

@@ -15,9 +15,9 @@ dirs = get_all_px_dir(cams[0].intr, 1080, 1920)
 for c in cams[:3]:
     for rep in range(2):
         with torch.no_grad():
-            render(c, m, cfg, torch.zeros(3, device=dev), dirs=dirs)
+            pkg = render(c, m, cfg, torch.zeros(3, device=dev), dirs=dirs)
     torch.cuda.synchronize()
-    t4 = rasterizer.last_stats["timing"].view(torch.int64).view(-1, 4).cpu()
+    t4 = pkg["raster"].timing.view(torch.int64).view(-1, 4).cpu()
     t4 = t4[t4[:, 1] > 0]
     order = (t4[:, 1] - t4[:, 0]).argsort(descending=True)[:3]
     for o in order:

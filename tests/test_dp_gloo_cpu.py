@@ -134,7 +134,7 @@ class _Cam:
 def sh_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from vcr_gaus_amd import rasterizer
+    from vcr_gaus_amd.rasterizer import RasterRecord
     cfg = make_config("tnt")
     m = StubModel()
     m._features_dc = torch.nn.Parameter(torch.zeros(N, 1, 3))
@@ -143,7 +143,7 @@ def sh_worker(rank, world, port, out):
     m.optimizer.param_groups += [{"params": [m._features_dc], "lr": 0.1, "name": "f_dc"},
                                  {"params": [m._features_rest], "lr": 0.1, "name": "f_rest"}]
     tr = Trainer(cfg, m, [_Cam(i) for i in range(8)], 1.0, torch.device("cpu"), world=world, rank=rank, seed=3)
-    assert tr.factorised_sh and rasterizer.SH_GRAD_MODE == "full"      # the mode is scoped to the trainer's own renders
+    assert tr.factorised_sh
 
     def rebuild(drgb_all, campos_all):
         g = sum(_basis_outer(m._xyz.detach(), campos_all[v], drgb_all[v], 3) for v in range(drgb_all.shape[0]))
@@ -153,11 +153,12 @@ def sh_worker(rank, world, port, out):
     cams = tr._next_cameras()
     view_data(cams[rank], m)
     gen = torch.Generator().manual_seed(500 + cams[rank])
-    rasterizer.last_drgb["drgb"] = torch.randn(N, 3, generator=gen)
-    tr._allreduce_grads()
+    rec = RasterRecord()                                            # what this rank's backward leaves on ITS render's record
+    rec.drgb, rec.view_dirs = torch.randn(N, 3, generator=gen), torch.zeros(N, 3)
+    tr._allreduce_grads(rec=rec)
+    assert rec.drgb is None
     if rank == 0:
         torch.save(dict(cams=cams, dc=m._features_dc.grad, rest=m._features_rest.grad, gx=m._xyz.grad), out)
-    rasterizer.SH_GRAD_MODE = "full"
     dist.destroy_process_group()
 
 
@@ -220,7 +221,7 @@ def _sh_model():
 def deferred_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from vcr_gaus_amd import rasterizer
+    from vcr_gaus_amd.rasterizer import RasterRecord
     m = _sh_model()
     tr = Trainer(make_config("tnt"), m, [_Cam(i) for i in range(8)], 1.0, torch.device("cpu"), world=world, rank=rank, seed=3)
     hist = []
@@ -228,11 +229,11 @@ def deferred_worker(rank, world, port, out):
         cams = tr._next_cameras()
         view_data(cams[rank], m)                                   # geometry gradients of THIS rank's view
         gen = torch.Generator().manual_seed(500 + cams[rank])
-        rasterizer.last_drgb["drgb"] = torch.randn(N, 3, generator=gen)
-        rasterizer.last_drgb["dirs"] = torch.zeros(N, 3)
+        rec = RasterRecord()
+        rec.drgb, rec.view_dirs = torch.randn(N, 3, generator=gen), torch.zeros(N, 3)
         xyz_rendered = m._xyz.detach().clone()
-        tr._exchange_grads(True, False)                              # two-stream form, no surgery
-        assert tr._pending_sh is not None and tr._pending_sh[0] == "views" and not rasterizer.last_drgb
+        tr._exchange_grads(True, False, rec)                         # two-stream form, no surgery
+        assert tr._pending_sh is not None and tr._pending_sh[0] == "views" and rec.drgb is None
         m.optimizer.step()                                           # geometry Adam runs BEFORE the deferred SH update ...
         for g in m.optimizer.param_groups:
             g["params"][0].grad = None

@@ -237,22 +237,18 @@ def test_knn3_init_matches_bruteforce(device):
 def test_factorised_sh_path_trains_like_the_dense_path(device):
     """The DP exchange path (backward leaves dL/drgb, SH gradients rebuilt by vcr_sh_grad_from_rgb) run at world size 1
     must follow the same trajectory as the ordinary path."""
-    from vcr_gaus_amd import rasterizer, synthetic
+    from vcr_gaus_amd import synthetic
     from vcr_gaus_amd.trainer import make_synthetic_trainer
     raw = synthetic.make_gaussians(8000, seed=2)
     raw["scaling"] = raw["scaling"] + 1.0
     finals = []
-    try:
-        for force in (False, True):
-            cams = synthetic.make_cameras(3, 128, 96, 110.0, device=device)
-            tr = make_synthetic_trainer(raw, cams, device, preset="tnt", force_factorised=force, overlap_sh=False,
-                                        optim={"densify_from_iter": 10 ** 9})
-            for _ in range(12):
-                tr.train_step()
-            finals.append({k: getattr(tr.model, k).detach().clone() for k in ["_features_dc", "_features_rest", "_xyz", "_opacity"]})
-            rasterizer.SH_GRAD_MODE = "full"
-    finally:
-        rasterizer.SH_GRAD_MODE = "full"
+    for force in (False, True):
+        cams = synthetic.make_cameras(3, 128, 96, 110.0, device=device)
+        tr = make_synthetic_trainer(raw, cams, device, preset="tnt", force_factorised=force, overlap_sh=False,
+                                    optim={"densify_from_iter": 10 ** 9})
+        for _ in range(12):
+            tr.train_step()
+        finals.append({k: getattr(tr.model, k).detach().clone() for k in ["_features_dc", "_features_rest", "_xyz", "_opacity"]})
     for k in finals[0]:
         # a dozen steps amplify fp32 atomic-order noise, and right after the opacity reset (moments zeroed) Adam moves an entry
         # by +-lr whatever the size of its gradient, so an entry whose gradient is ~0 can land 2 lr per step apart in the two
@@ -267,35 +263,49 @@ def test_two_stream_sh_path_trains_like_the_serial_loop(device):
     """Single-GPU default: SH Adam (gradient formed on the fly from dL/drgb x basis, vcr_sh_adam_from_rgb) and the next
     iteration's SH -> RGB evaluation run on a second stream.  Same trajectory as the serial loop with the dense SH
     gradient + vcr_adam_step, including across a densification (surgery) step and an SH-degree bump."""
-    from vcr_gaus_amd import rasterizer, synthetic
+    from vcr_gaus_amd import synthetic
+    from vcr_gaus_amd.gaussian_renderer import render
     from vcr_gaus_amd.trainer import make_synthetic_trainer
     raw = synthetic.make_gaussians(8000, seed=5)
     raw["scaling"] = raw["scaling"] + 1.0
     finals = []
-    try:
-        for overlap in (False, True):
-            cams = synthetic.make_cameras(3, 128, 96, 110.0, device=device)
-            tr = make_synthetic_trainer(raw, cams, device, preset="tnt", overlap_sh=overlap, overlap_min_gaussians=0,
-                                        optim={"densify_from_iter": 10 ** 9, "opacity_reset_interval": 9})
-            assert tr.overlap_sh == overlap and rasterizer.COLOUR_STREAM is None and rasterizer.SH_GRAD_MODE == "full"
-            tr.model.active_sh_degree = 2
-            for it in range(14):
-                if it == 6:
-                    tr.model.active_sh_degree = 3
-                if it == 11:
-                    tr.overlap_min_gaussians = 10 ** 9       # model "shrank" below the threshold: back to one stream
-                tr.train_step()                              # iteration 9 resets the opacities (a surgery step)
-            tr.join_side()
-            torch.cuda.synchronize()
-            finals.append({k: getattr(tr.model, k).detach().clone()
-                           for k in ["_features_dc", "_features_rest", "_xyz", "_opacity", "_scaling", "_rotation"]})
-            st = tr.model.optimizer.state
-            finals[-1]["m_rest"] = st["f_rest"]["exp_avg"].clone()
-            finals[-1]["v_dc"] = st["f_dc"]["exp_avg_sq"].clone()
-            assert st["f_rest"]["step"] == 14 and st["xyz"]["step"] == 14
-    finally:
-        rasterizer.SH_GRAD_MODE = "full"
-        rasterizer.COLOUR_STREAM = None
+    for overlap in (False, True):
+        cams = synthetic.make_cameras(3, 128, 96, 110.0, device=device)
+        tr = make_synthetic_trainer(raw, cams, device, preset="tnt", overlap_sh=overlap, overlap_min_gaussians=0,
+                                    optim={"densify_from_iter": 10 ** 9, "opacity_reset_interval": 9})
+        assert tr.overlap_sh == overlap
+        tr.model.active_sh_degree = 2
+        real_exchange = tr._exchange_grads
+
+        def exchange_after_an_eval_render(ov, surgery, rec, tr=tr, cams=cams):
+            # an evaluation render (with its own backward, in "rgb" mode) between this step's backward and its gradient
+            # exchange: dL/drgb travels on the record of the render that produced it, so the step is unaffected
+            from vcr_gaus_amd.rasterizer import RasterOptions
+            if tr.current_iteration in (3, 4):
+                keep = {g["name"]: g["params"][0].grad for g in tr.model.optimizer.param_groups}
+                tr.join_side()
+                pkg = render(cams[2], tr.model, tr.cfg, tr.background, dirs=tr.dirs, raster_options=RasterOptions("rgb"))
+                (7.0 * pkg["render"]).sum().backward()
+                assert pkg["raster"].drgb is not None and pkg["raster"] is not rec
+                for g in tr.model.optimizer.param_groups:
+                    g["params"][0].grad = keep[g["name"]]
+            return real_exchange(ov, surgery, rec)
+
+        tr._exchange_grads = exchange_after_an_eval_render
+        for it in range(14):
+            if it == 6:
+                tr.model.active_sh_degree = 3
+            if it == 11:
+                tr.overlap_min_gaussians = 10 ** 9       # model "shrank" below the threshold: back to one stream
+            tr.train_step()                              # iteration 9 resets the opacities (a surgery step)
+        tr.join_side()
+        torch.cuda.synchronize()
+        finals.append({k: getattr(tr.model, k).detach().clone()
+                       for k in ["_features_dc", "_features_rest", "_xyz", "_opacity", "_scaling", "_rotation"]})
+        st = tr.model.optimizer.state
+        finals[-1]["m_rest"] = st["f_rest"]["exp_avg"].clone()
+        finals[-1]["v_dc"] = st["f_dc"]["exp_avg_sq"].clone()
+        assert st["f_rest"]["step"] == 14 and st["xyz"]["step"] == 14
     for k in finals[0]:
         # a dozen steps amplify fp32 atomic-order noise, and right after the opacity reset (moments zeroed) Adam moves an entry
         # by +-lr whatever the size of its gradient, so an entry whose gradient is ~0 can land 2 lr per step apart in the two
@@ -312,7 +322,7 @@ def test_rccl_exchange_path_single_rank_group(device):
     import os
     import socket
     import torch.distributed as dist
-    from vcr_gaus_amd import rasterizer, synthetic
+    from vcr_gaus_amd import synthetic
     from vcr_gaus_amd.trainer import make_synthetic_trainer
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -343,7 +353,6 @@ def test_rccl_exchange_path_single_rank_group(device):
             assert torch.allclose(finals[0][k], finals[1][k], rtol=5e-3, atol=1e-5), k      # fp32 atomics: run-to-run noise
             assert torch.allclose(finals[0][k], finals[2][k], rtol=5e-3, atol=1e-5), k
     finally:
-        rasterizer.SH_GRAD_MODE = "full"
         dist.destroy_process_group()
 
 
@@ -475,7 +484,8 @@ def test_weighted_total(device):
 def test_colour_stream_render_is_identical(device):
     """SH -> RGB on a second stream (VcrRasterArgs.colour_stream, with a hook that enqueues foreign work first) gives the
     same image and gradients as the single-stream call."""
-    from vcr_gaus_amd import rasterizer, synthetic
+    from vcr_gaus_amd import synthetic
+    from vcr_gaus_amd.rasterizer import RasterOptions
     from vcr_gaus_amd.config import make_config
     from vcr_gaus_amd.gaussian_model import GaussianModel
     from vcr_gaus_amd.gaussian_renderer import render
@@ -495,8 +505,7 @@ def test_colour_stream_render_is_identical(device):
         for p in (m._features_dc, m._features_rest, m._xyz):
             p.grad = None
         hook = (lambda: called.append(torch.zeros(1 << 20, device=device).add_(1.0))) if two else None
-        with rasterizer.modes("full", side if two else None, hook):
-            pkg = render(cams[1], m, cfg, bg, dirs=dirs)
+        pkg = render(cams[1], m, cfg, bg, dirs=dirs, raster_options=RasterOptions("full", side if two else None, hook))
         (pkg["render"].sum() + pkg["depth"].sum()).backward()
         torch.cuda.synchronize()
         outs.append((pkg["render_out"].detach().clone(), m._features_rest.grad.clone(), m._xyz.grad.clone()))
@@ -567,7 +576,8 @@ def test_fused_normal_losses_match_the_modular_operators(device, active):
 def test_fused_sh_update_and_colour_equals_separate_steps(device, views):
     """VcrRasterArgs.sh_update (SH Adam step fused into the colour evaluation on the colour stream; single-view and
     data-parallel multi-view form) == the stand-alone update kernel followed by an ordinary render."""
-    from vcr_gaus_amd import rasterizer, synthetic
+    from vcr_gaus_amd import synthetic
+    from vcr_gaus_amd.rasterizer import RasterOptions
     from vcr_gaus_amd.config import make_config
     from vcr_gaus_amd.gaussian_model import GaussianModel
     from vcr_gaus_amd.gaussian_renderer import render
@@ -595,8 +605,8 @@ def test_fused_sh_update_and_colour_equals_separate_steps(device, views):
         if fused:
             provider = (lambda: opt.make_sh_update(drgb, 3, xyz=xyz0, campos_all=campos_all)) if views else \
                 (lambda: opt.make_sh_update(drgb[0], 3, view_dirs=vdirs))
-            with torch.no_grad(), rasterizer.modes("full", side, None, provider):
-                out = render(cams[1], m, cfg, bg, dirs=dirs)["render_out"]
+            with torch.no_grad():
+                out = render(cams[1], m, cfg, bg, dirs=dirs, raster_options=RasterOptions("full", side, None, provider))["render_out"]
         else:
             if views:
                 opt.step_sh_from_rgb_views(drgb, xyz0, campos_all, 3)

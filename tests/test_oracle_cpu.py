@@ -252,7 +252,7 @@ def test_virtual_visibility_cameras_look_at_box_floor():
 
 def test_lazy_dictionaries_and_scoped_modes():
     """Host logic of the trimmed step: render / loss dictionaries materialise derived entries on read, rasterizer modes
-    are scoped, scratch sizes are rounded to 1/8-octave steps."""
+    travel with the call (no module state), scratch sizes are rounded to 1/8-octave steps."""
     from vcr_gaus_amd import rasterizer
     from vcr_gaus_amd.fused_losses import _LossVals
     from vcr_gaus_amd.gaussian_renderer import _RenderOut
@@ -264,13 +264,19 @@ def test_lazy_dictionaries_and_scoped_modes():
     v = _LossVals({"l1": torch.tensor(0.25)})
     v.ssim_index = torch.tensor(0.9)
     assert "ssim" in v and abs(float(v["ssim"]) - 0.1) < 1e-6 and set(v.keys()) == {"l1", "ssim"}
-    assert rasterizer.SH_GRAD_MODE == "full" and rasterizer.COLOUR_STREAM is None
-    with rasterizer.modes("rgb", colour_stream="S", colour_hook=len):
-        assert (rasterizer.SH_GRAD_MODE, rasterizer.COLOUR_STREAM, rasterizer.COLOUR_HOOK) == ("rgb", "S", len)
-        with rasterizer.modes():
-            assert rasterizer.SH_GRAD_MODE == "full" and rasterizer.COLOUR_STREAM is None
-        assert rasterizer.SH_GRAD_MODE == "rgb"
-    assert (rasterizer.SH_GRAD_MODE, rasterizer.COLOUR_STREAM, rasterizer.COLOUR_HOOK) == ("full", None, None)
+    # per-call options / records instead of module state: defaults are the reference's behaviour, a record gives its
+    # SH-gradient factors away exactly once
+    o = rasterizer.RasterOptions()
+    assert (o.sh_grad, o.colour_stream, o.colour_hook, o.colour_sh_update, o.sort_stream) == ("full", None, None, None, None)
+    with pytest.raises(ValueError):
+        rasterizer.RasterOptions(sh_grad="half")
+    assert not any(hasattr(rasterizer, n) for n in ("SH_GRAD_MODE", "COLOUR_STREAM", "last_drgb", "last_stats", "modes"))
+    rec = rasterizer.RasterRecord()
+    with pytest.raises(RuntimeError):
+        rec.take_sh_factors()
+    rec.drgb, rec.view_dirs = torch.ones(2, 3), torch.zeros(2, 3)
+    d, v = rec.take_sh_factors()
+    assert float(d.sum()) == 6.0 and rec.drgb is None and rec.view_dirs is None
 
 
 def test_oracle_trainer_pieces_match_reference_vectors():

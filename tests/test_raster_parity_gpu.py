@@ -27,12 +27,10 @@ def test_forward_matches_oracle(device, case):
     cam, inp, dirs = util.make_case(n, W, H, f, seed=3, scale_mult=sm, sem=sem)
     bg = torch.tensor([0.1, 0.3, 0.7])
     (ref, rradii, st), _ = util.oracle_forward(cam, inp, dirs, bg, dtype=torch.float64)
-    (out, radii), _ = util.hip_forward(cam, inp, dirs, bg, device)
+    (out, radii), hl = util.hip_forward(cam, inp, dirs, bg, device)
     assert out.shape == ref.shape
     assert torch.equal(radii.cpu(), rradii)
-    from vcr_gaus_amd import rasterizer
-    assert rasterizer.last_stats["R"] == st["R"]
-    assert rasterizer.last_stats["V"] == st["V"]
+    assert (hl["record"].R, hl["record"].V, hl["record"].N) == (st["R"], st["V"], n)
     bad = util.bad_pixels(out, ref)
     assert bad <= util.pixel_budget(ref), f"{bad} mismatching pixels"
 
@@ -157,7 +155,8 @@ def test_depth_moment_channels_forward_backward(device):
 def test_factorised_sh_gradient_exchange_equals_summed_full_gradients(device):
     """DP path: dL/drgb per view + vcr_sh_grad_from_rgb == sum over views of the full SH gradients."""
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-    from vcr_gaus_amd import _lib, rasterizer, synthetic
+    from vcr_gaus_amd import _lib, synthetic
+    from vcr_gaus_amd.rasterizer import RasterOptions
     n = 3001
     _, inp, _ = util.make_case(n, 96, 64, 80.0, seed=17, scale_mult=6.0)
     cams = synthetic.make_cameras(3, 96, 64, 80.0)
@@ -166,24 +165,22 @@ def test_factorised_sh_gradient_exchange_equals_summed_full_gradients(device):
     full_dc = full_rest = None
     drgbs = []
     for mode in ("full", "rgb"):
-        rasterizer.SH_GRAD_MODE = mode
-        try:
-            for cam in cams:
-                s = util.settings_for(cam, bg, GaussianRasterizationSettings, device=device, sh_degree=2)
-                dc = base["shs"][:, :1].contiguous().requires_grad_(True)
-                rest = base["shs"][:, 1:].contiguous().requires_grad_(True)
-                out, _ = GaussianRasterizer(s)(means3D=base["means3D"], means2D=torch.zeros(n, 3, device=device), shs=dc,
-                                               shs_rest=rest, opacities=base["opac"], scales=base["scales"],
-                                               rotations=base["rots"])
-                (out[:3] * torch.linspace(0.5, 1.5, 64 * 96, device=device).view(1, 64, 96)).sum().backward()
-                if mode == "full":
-                    full_dc = dc.grad.clone() if full_dc is None else full_dc + dc.grad
-                    full_rest = rest.grad.clone() if full_rest is None else full_rest + rest.grad
-                else:
-                    assert dc.grad is None and rest.grad is None
-                    drgbs.append(rasterizer.last_drgb.pop("drgb"))
-        finally:
-            rasterizer.SH_GRAD_MODE = "full"
+        for cam in cams:
+            s = util.settings_for(cam, bg, GaussianRasterizationSettings, device=device, sh_degree=2)
+            dc = base["shs"][:, :1].contiguous().requires_grad_(True)
+            rest = base["shs"][:, 1:].contiguous().requires_grad_(True)
+            rast = GaussianRasterizer(s, options=RasterOptions(sh_grad=mode))
+            out, _ = rast(means3D=base["means3D"], means2D=torch.zeros(n, 3, device=device), shs=dc, shs_rest=rest,
+                          opacities=base["opac"], scales=base["scales"], rotations=base["rots"])
+            (out[:3] * torch.linspace(0.5, 1.5, 64 * 96, device=device).view(1, 64, 96)).sum().backward()
+            if mode == "full":
+                full_dc = dc.grad.clone() if full_dc is None else full_dc + dc.grad
+                full_rest = rest.grad.clone() if full_rest is None else full_rest + rest.grad
+                assert rast.record.drgb is None
+            else:
+                assert dc.grad is None and rest.grad is None
+                drgbs.append(rast.record.take_sh_factors()[0])
+                assert rast.record.drgb is None
     drgb_all = torch.stack(drgbs).contiguous()
     campos = torch.stack([c.camera_center for c in cams]).float().to(device).contiguous()
     d_dc, d_rest = torch.empty(n, 1, 3, device=device), torch.empty(n, 15, 3, device=device)

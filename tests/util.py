@@ -49,7 +49,9 @@ def oracle_forward(cam, inp, dirs, bg, dtype=torch.float64, requires_grad=False,
     return res, leaf
 
 
-def hip_forward(cam, inp, dirs, bg, device, requires_grad=False, sh_degree=3, f_count=0, use_normals=True, num_dist=0):
+def hip_forward(cam, inp, dirs, bg, device, requires_grad=False, sh_degree=3, f_count=0, use_normals=True, num_dist=0,
+                options=None):
+    """-> (rasterizer result, leaves); leaves["record"] is the call's RasterRecord (N, V, R, ...)."""
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     s = settings_for(cam, bg, GaussianRasterizationSettings, sh_degree=sh_degree, f_count=f_count, device=device)
     leaf = {}
@@ -58,11 +60,12 @@ def hip_forward(cam, inp, dirs, bg, device, requires_grad=False, sh_degree=3, f_
     N = inp["means3D"].shape[0]
     leaf["m2"] = torch.zeros(N, 3, device=device, requires_grad=requires_grad)
     leaf["m2d"] = torch.zeros(N, 3, device=device, requires_grad=requires_grad)
-    rast = GaussianRasterizer(raster_settings=s, num_dist=num_dist)
+    rast = GaussianRasterizer(raster_settings=s, num_dist=num_dist, options=options)
     res = rast(means3D=leaf["means3D"], means2D=leaf["m2"], means2D_densify=leaf["m2d"] if f_count == 0 else None,
                shs=leaf["shs"], colors_precomp=None, normals_precomp=leaf["normals"] if use_normals else None,
                semantics_precomp=leaf["sem"], opacities=leaf["opac"], scales=leaf["scales"], rotations=leaf["rots"],
                cov3D_precomp=None, dirs=dirs.to(device) if (use_normals and dirs is not None) else None, inside=None)
+    leaf["record"] = rast.record
     return res, leaf
 
 

@@ -54,25 +54,32 @@ class _FusedLosses(torch.autograd.Function):
         rp = lambda k: res.data_ptr() + 4 * k
         gi = gt_image.detach().contiguous()
         part = torch.empty(9, H, W, device=dev)
-        _lib.check(lib.vcr_l1_ssim_forward(H, W, base, gi.data_ptr(), s_ssim, rp(0), part.data_ptr(), 3, st))
         sr, xz = scaling_raw.detach().contiguous(), xyz.detach().contiguous()
-        if active[2]:
-            _lib.check(lib.vcr_scale_reg_forward(sr.shape[0], sr.data_ptr(), xz.data_ptr(), trans.data_ptr(), scale.data_ptr(),
-                                                 s_scale, rp(2), 3, st))
         gn = None if gt_normal is None else gt_normal.detach().contiguous()
         m = None if mask is None else mask.detach().contiguous().view(-1).to(torch.uint8)
         nbits = (1 if active[3] else 0) | (2 if active[4] else 0) | (4 if active[5] else 0)
-        if nbits:      # mono_normal, depth_normal, consistent_normal: one kernel (+ one finalize) for all three
-            _lib.check(lib.vcr_normal_losses_forward(H, W, *intr, base + 3 * P * 4, base + 4 * P * 4,
-                                                     None if gn is None else gn.data_ptr(), None if m is None else m.data_ptr(),
-                                                     float(depth_max), float(exp_t), nbits, s_nrm, rp(3), 3, st))
+        try:
+            _lib.check(lib.vcr_l1_ssim_forward(H, W, base, gi.data_ptr(), s_ssim, rp(0), part.data_ptr(), 3, st))
+            if active[2]:
+                _lib.check(lib.vcr_scale_reg_forward(sr.shape[0], sr.data_ptr(), xz.data_ptr(), trans.data_ptr(), scale.data_ptr(),
+                                                     s_scale, rp(2), 3, st))
+            if nbits:      # mono_normal, depth_normal, consistent_normal: one kernel (+ one finalize) for all three
+                _lib.check(lib.vcr_normal_losses_forward(H, W, *intr, base + 3 * P * 4, base + 4 * P * 4,
+                                                         None if gn is None else gn.data_ptr(), None if m is None else m.data_ptr(),
+                                                         float(depth_max), float(exp_t), nbits, s_nrm, rp(3), 3, st))
+            # ONE finalize for all reductions; total = sum_k w_k L_k with the ssim entry meaning (1 - ssim): wvec[1] = -w_ssim,
+            # the constant +w_ssim is added in-kernel
+            _lib.check(lib.vcr_finalize_losses(H, W, s_ssim, s_scale if active[2] else None, s_nrm if nbits else None, res.data_ptr(),
+                                               wvec.data_ptr(), 1, total.data_ptr(), st))
+        except Exception:
+            # a kernel failed between the first accumulation and the finalize that re-zeroes the slots: the reused buffer may
+            # hold partial sums -- drop it, the next forward starts from a fresh zero-filled one
+            if _SUMS.get(dev) is ent:
+                del _SUMS[dev]
+            raise
         ctx.save_for_backward(o, gi, part, sums, sr, xz, gn, m, wvec, trans, scale)
         ctx.meta = (H, W, C, tuple(intr), tuple(active), float(exp_t), float(depth_max), n2, n3, nbits)
         ctx.scale_key = id(scaling_raw) if DEFER_SCALE_GRAD else None
-        # ONE finalize for all reductions; total = sum_k w_k L_k with the ssim entry meaning (1 - ssim): wvec[1] = -w_ssim,
-        # the constant +w_ssim is added in-kernel
-        _lib.check(lib.vcr_finalize_losses(H, W, s_ssim, s_scale if active[2] else None, s_nrm if nbits else None, res.data_ptr(),
-                                           wvec.data_ptr(), 1, total.data_ptr(), st))
         ctx.mark_non_differentiable(res)
         return total, res
 

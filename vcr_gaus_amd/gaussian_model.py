@@ -66,6 +66,8 @@ class _FusedActivate(torch.autograd.Function):
         keep = [None if t is None else t.contiguous().float() for t in (d_scales, d_rots, d_opac, d_nrm)]
         ds, dr, do = torch.empty_like(sr), torch.empty_like(rr), torch.empty_like(orr)
         extra = PENDING_SCALE_GRAD.pop(ctx.scale_key, None)
+        if extra is not None and tuple(extra.shape) != tuple(sr.shape):      # (a stale entry under a recycled id())
+            raise RuntimeError(f"pending l1_scale gradient has shape {tuple(extra.shape)}, the scaling parameter {tuple(sr.shape)}")
         _lib.check(lib.vcr_activate_backward(N, sr.data_ptr(), rr.data_ptr(), orr.data_ptr(), Rw.data_ptr(), aux.data_ptr(),
                                              *[None if t is None else t.data_ptr() for t in keep],
                                              None if extra is None else extra.data_ptr(),

@@ -64,10 +64,11 @@ class _RenderOut(dict):
 
 
 def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_color=None, return_normal=True,
-           is_all=True, dirs=None, mask_depth_thr=0.8, lazy_mask=False, geometry=True):
+           is_all=True, dirs=None, mask_depth_thr=0.8, lazy_mask=False, geometry=True, raster_options=None):
     """Background tensor (bg_color) must be on the GPU.  Returns the reference's dict:
     render[3,H,W] depth[1,H,W] normal[H,W,3] est_normal[H,W,3] alpha[1,H,W] viewspace_points[N,3]
-    viewspace_points_densify[N,3] visibility_filter[N] mask[H,W] radii[N] (+render_sem)."""
+    viewspace_points_densify[N,3] visibility_filter[N] mask[H,W] radii[N] (+render_sem); beyond the reference: "raster", the
+    call's `RasterRecord` (V, R; the SH-gradient factors after an `sh_grad="rgb"` backward).  `raster_options`: `RasterOptions`."""
     dev = pc.get_xyz.device
     # gradient holders for the 2D means (`:31-37`); leaves, so `.grad` is populated without the reference's `+ 0` copies
     grad_on = torch.is_grad_enabled()
@@ -79,7 +80,8 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
     lw = cfg.optim.loss_weight
     want_var = getattr(lw, "depth_var", 0) > 0
     want_dist = getattr(lw, "distortion", 0) > 0 and not want_var
-    rasterizer = GaussianRasterizer(raster_settings=rs, num_dist=2 if want_var else (1 if want_dist else None))
+    rasterizer = GaussianRasterizer(raster_settings=rs, num_dist=2 if want_var else (1 if want_dist else None),
+                                    options=raster_options)
 
     act = fused_activate(pc, viewpoint_camera.camera_center, _cam_rotation(viewpoint_camera, dev), return_normal)
     scales, rotations, opacity = act[:3]
@@ -126,7 +128,7 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
     out = _RenderOut({"render": rendered_image, "depth": rendered_depth, "normal": normal, "est_normal": est_normal,
                       "alpha": rendered_alpha, "viewspace_points": screenspace_points,
                       "viewspace_points_densify": screenspace_points_densify, "mask": mask,
-                      "mask_static": cam_mask, "radii": radii, "render_out": rendered_out})
+                      "mask_static": cam_mask, "radii": radii, "render_out": rendered_out, "raster": rasterizer.record})
     if not lazy_mask:
         out["visibility_filter"] = radii > 0
     if with_sem:

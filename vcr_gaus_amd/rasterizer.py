@@ -68,38 +68,58 @@ def _check(rc):
         raise RuntimeError("vcr_raster: " + _lib.last_error())
 
 
-SH_GRAD_MODE = "full"   # "rgb": backward skips the SH gradients and leaves dL/drgb [N,3] in `last_drgb` (DP exchange)
-last_drgb = {}          # "drgb" [N,3] and "dirs" [N,3] (unit view directions) of the most recent "rgb"-mode backward
-COLOUR_STREAM = None    # torch.cuda.Stream: f_count = 0 forwards evaluate SH -> RGB there (VcrRasterArgs.colour_stream)
-COLOUR_HOOK = None      # callable(): enqueue caller work on COLOUR_STREAM ahead of the colour evaluation (colour_stream_hook)
-COLOUR_SH_UPDATE = None  # callable() -> (_lib.VcrShUpdate, keep-alive) or None: SH Adam step fused into the colour evaluation
-SORT_STREAM = None      # torch.cuda.Stream: depth keys + depth sort of f_count = 0 forwards run there, beside the projection
+class RasterOptions:
+    """Per-call options of the f_count = 0 forward beyond the reference's keyword surface (all default to the reference's
+    behaviour).  They travel with the call -- `GaussianRasterizer(settings, options=...)`, `render(..., raster_options=...)`
+    -- and the backward of a forward keeps the options it was recorded with; nothing here is process-global.
+      sh_grad          "full": the backward writes dL/dshs.  "rgb": it skips the 192 B/Gaussian SH gradient and leaves
+                       dL/drgb [N,3] + the unit view directions [N,3] in the call's `RasterRecord` (data-parallel exchange
+                       and the two-stream SH update form the SH gradient from those two factors).
+      colour_stream    torch.cuda.Stream: SH -> RGB is evaluated there (VcrRasterArgs.colour_stream), joined before compositing.
+      colour_hook      callable(): enqueue caller work on `colour_stream` ahead of the colour evaluation.
+      colour_sh_update callable() -> (_lib.VcrShUpdate, keep-alive) or None: SH Adam step fused into the colour evaluation.
+      sort_stream      torch.cuda.Stream: depth keys + depth sort run there, beside the projection."""
+    __slots__ = ("sh_grad", "colour_stream", "colour_hook", "colour_sh_update", "sort_stream")
+
+    def __init__(self, sh_grad="full", colour_stream=None, colour_hook=None, colour_sh_update=None, sort_stream=None):
+        if sh_grad not in ("full", "rgb"):
+            raise ValueError("sh_grad must be 'full' or 'rgb'")
+        self.sh_grad, self.colour_stream, self.colour_hook = sh_grad, colour_stream, colour_hook
+        self.colour_sh_update, self.sort_stream = colour_sh_update, sort_stream
 
 
-import contextlib
+DEFAULT_OPTIONS = RasterOptions()
 
 
-@contextlib.contextmanager
-def modes(sh_grad="full", colour_stream=None, colour_hook=None, colour_sh_update=None, sort_stream=None):
-    """Scoped setting of SH_GRAD_MODE / COLOUR_STREAM / COLOUR_HOOK / COLOUR_SH_UPDATE for the forwards issued inside the
-    block (the backward of such a forward keeps the mode it was recorded with)."""
-    global SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE, SORT_STREAM
-    old = (SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE, SORT_STREAM)
-    SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE, SORT_STREAM = sh_grad, colour_stream, colour_hook, colour_sh_update, sort_stream
-    try:
-        yield
-    finally:
-        SH_GRAD_MODE, COLOUR_STREAM, COLOUR_HOOK, COLOUR_SH_UPDATE, SORT_STREAM = old
+class RasterRecord:
+    """What ONE rasterizer call leaves behind besides its return tuple: the work it did (N Gaussians, V visible, R tile
+    instances, longest tile list when `debug`) and, after the backward of an `sh_grad="rgb"` call, the two factors of its SH
+    gradient.  One object per call (`GaussianRasterizer.record`, `render()["raster"]`): a second render -- an evaluation
+    pass, another model -- between a backward and the gradient exchange cannot replace them."""
+    __slots__ = ("N", "V", "R", "max_tile_len", "drgb", "view_dirs", "timing")
+
+    def __init__(self):
+        self.N = self.V = self.R = 0
+        self.max_tile_len = -1
+        self.drgb = self.view_dirs = self.timing = None
+
+    def take_sh_factors(self):
+        """-> (dL/drgb [N,3], view directions [N,3]) of this call's backward; the record lets go of them."""
+        if self.drgb is None:
+            raise RuntimeError("vcr_raster: no dL/drgb recorded (the call was not made with sh_grad='rgb', or its backward has not run)")
+        out = (self.drgb, self.view_dirs)
+        self.drgb = self.view_dirs = None
+        return out
 
 
 NUM_DIST = 0      # trailing channels, the fork's compile-time `NUM_DIST` (README.md:155): 0, 1 = distortion, 2 = sum w d, sum w d^2
-last_stats = {}   # R / V of the most recent forward (for benchmarks; not part of the reference API)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, means2D_densify, sh, colors_precomp, normals_precomp,
-                semantics_precomp, opacities, scales, rotations, cov3Ds_precomp, dirs, rs, sh_rest=None, num_dist=0):
+                semantics_precomp, opacities, scales, rotations, cov3Ds_precomp, dirs, rs, sh_rest=None, num_dist=0,
+                opts=None, rec=None):
         lib = _lib.load()
         ctx.set_materialize_grads(False)          # (no zero-filled [N] gradient for the non-differentiable radii)
         dev = means3D.device
@@ -122,17 +142,19 @@ class _RasterizeGaussians(torch.autograd.Function):
                                semantics_precomp=_ptr(t["sem"]), opacities=_ptr(t["opac"]), scales=_ptr(t["scales"]),
                                rotations=_ptr(t["rots"]), cov3D_precomp=_ptr(t["cov"]), dirs=_ptr(t["dirs"]))
         fc = int(rs.f_count)
+        opts = DEFAULT_OPTIONS if opts is None else opts
+        rec = RasterRecord() if rec is None else rec
         hook = upd = None
-        if SORT_STREAM is not None and fc == 0 and N > 0:
-            a.sort_stream = SORT_STREAM.cuda_stream
-        if COLOUR_STREAM is not None and fc == 0 and t["shs"] is not None:
-            a.colour_stream = COLOUR_STREAM.cuda_stream
-            if COLOUR_SH_UPDATE is not None and t["shs_rest"] is not None and N > 0:
-                upd = COLOUR_SH_UPDATE()                          # (struct, tensors kept alive until the call returns)
+        if opts.sort_stream is not None and fc == 0 and N > 0:
+            a.sort_stream = opts.sort_stream.cuda_stream
+        if opts.colour_stream is not None and fc == 0 and t["shs"] is not None:
+            a.colour_stream = opts.colour_stream.cuda_stream
+            if opts.colour_sh_update is not None and t["shs_rest"] is not None and N > 0:
+                upd = opts.colour_sh_update()                     # (struct, tensors kept alive until the call returns)
                 if upd is not None:
                     a.sh_update = _ct.addressof(upd[0])
-            if COLOUR_HOOK is not None:
-                fn = COLOUR_HOOK
+            if opts.colour_hook is not None:
+                fn = opts.colour_hook
                 hook = _lib.HOOK_FN(lambda _user: fn())            # kept alive until the forward call returns
                 a.colour_stream_hook = _ct.cast(hook, _ct.c_void_p)
         C = 8 + S + int(num_dist)
@@ -142,20 +164,20 @@ class _RasterizeGaussians(torch.autograd.Function):
         import os as _os
         if fc == 0 and _os.environ.get("VCR_TIMING"):       # experiment builds only (-DVCR_TIMING)
             count = torch.zeros(((H + 15) // 16) * ((W + 15) // 16) * 32, dtype=torch.int32, device=dev)
-            last_stats["timing"] = count
+            rec.timing = count
         score = torch.zeros(N, dtype=torch.float32, device=dev) if fc in (1, 2) else None
         fo = _lib.VcrForwardOut(out=_ptr(out), radii=_ptr(radii), count=_ptr(count), score=_ptr(score))
         al = _Allocator(dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _check(lib.vcr_rasterize_forward(a, fo, al.cb, None, stream))
-        last_stats.update(R=int(fo.num_rendered), V=int(fo.num_visible), N=N, max_tile_len=int(fo.max_tile_len))
+        rec.R, rec.V, rec.N, rec.max_tile_len = int(fo.num_rendered), int(fo.num_visible), N, int(fo.max_tile_len)
         if fc == 0:
-            ctx.rs, ctx.args_t, ctx.state = rs, t, al.bufs
+            ctx.rs, ctx.args_t, ctx.state, ctx.rec = rs, t, al.bufs, rec
             ctx.num_rendered = int(fo.num_rendered)
             ctx.has = (means2D_densify is not None)
             ctx.num_dist = int(num_dist)
-            ctx.rgb_mode = SH_GRAD_MODE == "rgb" and t["shs"] is not None
+            ctx.rgb_mode = opts.sh_grad == "rgb" and t["shs"] is not None
             ctx.save_for_backward(radii)
             ctx.mark_non_differentiable(radii)
             return out, radii
@@ -166,7 +188,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out, _grad_radii=None):
         if grad_out is None:
-            return (None,) * 15
+            return (None,) * 17
         lib = _lib.load()
         rs, t = ctx.rs, ctx.args_t
         (radii,) = ctx.saved_tensors
@@ -212,16 +234,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(dev):
             _check(lib.vcr_rasterize_backward(a, io, al.cb, None, stream))
         if rgb_mode:
-            last_drgb["drgb"] = d_rgb
-            last_drgb["dirs"] = v_dirs
-        return (d_means3D, d_means2D, d_dens, d_shs, d_col, d_nrm, d_sem, d_opac, d_sc, d_rot, d_cov, None, None, d_shr, None)
+            ctx.rec.drgb, ctx.rec.view_dirs = d_rgb, v_dirs
+        return (d_means3D, d_means2D, d_dens, d_shs, d_col, d_nrm, d_sem, d_opac, d_sc, d_rot, d_cov, None, None, d_shr, None,
+                None, None)
 
 
 class GaussianRasterizer(nn.Module):
-    def __init__(self, raster_settings, num_dist=None):
+    def __init__(self, raster_settings, num_dist=None, options=None):
         super().__init__()
         self.raster_settings = raster_settings
         self.num_dist = NUM_DIST if num_dist is None else num_dist
+        self.options = options            # RasterOptions or None (the reference's behaviour)
+        self.record = None                # RasterRecord of the most recent call of THIS object
 
     def forward(self, means3D, means2D, opacities, means2D_densify=None, shs=None, colors_precomp=None,
                 normals_precomp=None, semantics_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
@@ -234,6 +258,7 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        self.record = RasterRecord()
         return _RasterizeGaussians.apply(means3D, means2D, means2D_densify, shs, colors_precomp, normals_precomp,
                                          semantics_precomp, opacities, scales, rotations, cov3D_precomp, dirs, rs, shs_rest,
-                                         self.num_dist if rs.f_count == 0 else 0)
+                                         self.num_dist if rs.f_count == 0 else 0, self.options, self.record)

@@ -207,19 +207,17 @@ class Trainer:
         return self._wvec
 
     # ---- gradient exchange ------------------------------------------------------------------------------------
-    def _allreduce_grads(self, early_feature_step=False, defer_sh=False):
+    def _allreduce_grads(self, early_feature_step=False, defer_sh=False, rec=None):
         """Sum the per-Gaussian gradients of all ranks (RCCL over xGMI).  One collective per parameter
         tensor, all in flight together; the 1/world scale is folded into the Adam kernel.  With the factorised SH
         exchange the all-gather of dL/drgb is awaited first, the SH gradients are rebuilt and (on iterations without
         densify / prune / opacity-reset surgery) their Adam update runs while the all-reduce of the remaining
-        44 B/Gaussian is still in flight."""
+        44 B/Gaussian is still in flight.  `rec`: the `RasterRecord` of THIS step's render (its backward left dL/drgb there)."""
         if self.world == 1 and not self.factorised_sh:
             self.model.optimizer.grad_scale = 1.0
             return
         if self.world == 1 and not getattr(self, "force_collectives", False):   # single-rank factorised path: no collectives
-            from . import rasterizer
-            drgb = rasterizer.last_drgb.pop("drgb").contiguous()
-            rasterizer.last_drgb.pop("dirs", None)
+            drgb = rec.take_sh_factors()[0].contiguous()
             campos = self.cameras[self._picked[0]].camera_center.float().reshape(1, 3).contiguous()
             self.model._features_dc.grad, self.model._features_rest.grad = self._sh_grads_from_rgb(drgb[None].contiguous(), campos)
             self.model.optimizer.grad_scale = 1.0
@@ -229,8 +227,7 @@ class Trainer:
         drgb_all = None
         self.model.optimizer.grad_scale = 1.0 / self.world
         if self.factorised_sh:
-            from . import rasterizer
-            drgb = rasterizer.last_drgb.pop("drgb").contiguous()
+            drgb = rec.take_sh_factors()[0].contiguous()
             flat = torch.empty((self.world * drgb.shape[0], 3), dtype=drgb.dtype, device=drgb.device)
             gather = dist.all_gather_into_tensor(flat, drgb, async_op=True)           # concatenated along dim 0
             drgb_all = flat.view(self.world, drgb.shape[0], 3)
@@ -260,11 +257,9 @@ class Trainer:
                 # nobody on this stream waits for the all-gather: the SH update (gradient formed on the fly from all views)
                 # is applied on the second stream from the next forward's hook, beside its sort chain.  xyz is snapshotted
                 # because the geometry update below runs first.
-                rasterizer.last_drgb.pop("dirs", None)
                 self._pending_sh = ("views", gather, drgb_all, self.model._xyz.detach().clone(), campos_all,
                                     int(self.model.active_sh_degree))
             else:
-                rasterizer.last_drgb.pop("dirs", None)
                 gather.wait()
                 self.model._features_dc.grad, self.model._features_rest.grad = self._sh_grads_from_rgb(drgb_all, campos_all)
                 if early_feature_step:
@@ -272,27 +267,26 @@ class Trainer:
         for w in works:
             w.wait()
 
-    def _exchange_grads(self, overlap, surgery):
+    def _exchange_grads(self, overlap, surgery, rec=None):
         """What happens between backward and the optimizer step.  Two-stream form (`overlap`, no surgery this iteration):
         single GPU -> the SH update is only stashed (applied from the next forward's colour stream); data parallel -> the
         geometry bucket is all-reduced now, dL/drgb is all-gathered asynchronously and the SH update of ALL views is left
         pending for the side stream (`defer_sh`).  Otherwise: the serial exchange."""
         m = self.model
         if overlap and not surgery:
-            from . import rasterizer
             for g in m.optimizer.param_groups:         # moments are created (zero-filled) on THIS stream, ahead of
                 if g["name"] in ("f_dc", "f_rest"):    # the projection the side stream will wait for
                     m.optimizer._state(g)
             if self.world > 1 or getattr(self, "force_collectives", False):
-                self._allreduce_grads(defer_sh=True)
+                self._allreduce_grads(defer_sh=True, rec=rec)
                 self.last_exchange = "factorised-deferred"      # bucket all-reduce now, all-view SH update on the side stream
             else:
                 self.last_exchange = "none"
                 m.optimizer.grad_scale = 1.0
-                self._pending_sh = (rasterizer.last_drgb.pop("drgb"), rasterizer.last_drgb.pop("dirs"), int(m.active_sh_degree))
+                self._pending_sh = rec.take_sh_factors() + (int(m.active_sh_degree),)
         else:
             self.join_side()
-            self._allreduce_grads(early_feature_step=not surgery)
+            self._allreduce_grads(early_feature_step=not surgery, rec=rec)
             collectives = self.world > 1 or getattr(self, "force_collectives", False)
             self.last_exchange = ("factorised" if self.factorised_sh else "dense") if collectives else "none"
 
@@ -429,35 +423,37 @@ class Trainer:
         bg = self.bg_table[it % self.bg_table.shape[0]] if cfg.optim.random_background else self.background
         fused = getattr(self, "use_fused_losses", True) and not any(
             k in self.weights for k in ("distortion", "depth_var", "entropy", "mono_depth", "curv"))
-        from . import rasterizer
+        from .rasterizer import RasterOptions
         overlap = self.overlap_sh and m._xyz.shape[0] >= self.overlap_min_gaussians
         self.factorised_sh = self._factorised_base or overlap
         if not overlap and self._pending_sh is not None:
             self.join_side()
         fuse = overlap and not os.environ.get("VCR_NO_FUSED_SH_COLOUR")
-        with rasterizer.modes("rgb" if self.factorised_sh else "full", self.side if overlap else None,
-                              self._launch_pending_sh if (overlap and not fuse) else None,
-                              self._pending_sh_update if fuse else None,
-                              self.sort_stream if (overlap and m._xyz.shape[0] >= self.sort_stream_min_gaussians) else None):
-            data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True, geometry=not fused)
+        opts = RasterOptions("rgb" if self.factorised_sh else "full", self.side if overlap else None,
+                             self._launch_pending_sh if (overlap and not fuse) else None,
+                             self._pending_sh_update if fuse else None,
+                             self.sort_stream if (overlap and m._xyz.shape[0] >= self.sort_stream_min_gaussians) else None)
+        data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True, geometry=not fused, raster_options=opts)
         if self._pending_sh is not None:         # the render did not go through the two-stream path (e.g. no Gaussians)
             self.join_side()
         from . import fused_losses, gaussian_model
         fused_losses.DEFER_SCALE_GRAD = True        # l1_scale's gradient joins the activation backward's kernel (same graph)
+        left, ok = None, False
         try:
             loss = self._compute_loss(data, cam)
             loss.backward(fused_losses.unit_seed(loss.device))
+            ok = True
         finally:
             fused_losses.DEFER_SCALE_GRAD = False
-        left = gaussian_model.PENDING_SCALE_GRAD.pop(id(m._scaling), None)
-        if left is not None:                        # (no activation backward consumed it: add it the ordinary way)
+            left = gaussian_model.PENDING_SCALE_GRAD.pop(id(m._scaling), None)     # never survives the step, also on errors
+        if ok and left is not None:                 # (no activation backward consumed it: add it the ordinary way)
             m._scaling.grad = left if m._scaling.grad is None else m._scaling.grad + left
         with torch.no_grad():
             surgery = (it < cfg.optim.densify_until_iter and it > cfg.optim.densify_from_iter
                        and it % cfg.optim.densification_interval == 0) \
                 or it % cfg.optim.opacity_reset_interval == 0 or it in cfg.optim.prune.iterations \
                 or (cfg.model.white_background and it == cfg.optim.densify_from_iter)
-            self._exchange_grads(overlap, surgery)
+            self._exchange_grads(overlap, surgery, data["raster"])
             if it < cfg.optim.densify_until_iter:
                 self._densify_stats(data)
                 if it > cfg.optim.densify_from_iter and "countlist" in data and not self._stats_dirty:        # `trainer.py:350-356`
@@ -581,15 +577,13 @@ class BenchTrainer:
         torch.cuda.synchronize()
 
     def step(self, i):
-        from . import rasterizer
-        self.tr.train_step()          # (no per-rank fallback: a rank that switched exchange algorithm alone would hang RCCL)
-        self.last_R, self.last_V = rasterizer.last_stats.get("R", 0), rasterizer.last_stats.get("V", 0)
+        rec = self.tr.train_step()["raster"]    # (no per-rank fallback: a rank that switched exchange algorithm alone would hang RCCL)
+        self.last_R, self.last_V = rec.R, rec.V
 
     @torch.no_grad()
     def scene_shape(self):
         """Untimed diagnostics of the workload: longest per-tile list and number of covered pixels (alpha > 0) of the last
         camera, from one extra render with `debug` set (that render synchronises)."""
-        from . import rasterizer
         tr = self.tr
         tr.join_side()
         cam = tr.cameras[tr._picked[tr.rank]] if tr._picked else tr.cameras[0]
@@ -599,8 +593,7 @@ class BenchTrainer:
             pkg = render(cam, tr.model, tr.cfg, tr.background, dirs=tr.dirs)
         finally:
             tr.cfg.pipline.debug = dbg
-        return {"max_tile_len": int(rasterizer.last_stats.get("max_tile_len", -1)),
-                "covered_pixels": int((pkg["alpha"] > 0).sum())}
+        return {"max_tile_len": int(pkg["raster"].max_tile_len), "covered_pixels": int((pkg["alpha"] > 0).sum())}
 
     @torch.no_grad()
     def dense_variant_roofline(self, scale_mult, peak_gbs, sem=0, reps=10):
@@ -608,7 +601,7 @@ class BenchTrainer:
         multiplied by `scale_mult` (R/N ~ 10 instead of ~ 3: what trained scenes look like).  -> achieved GB/s on
         algorithmic bytes / fraction, from `reps` forward renders; the model is restored afterwards."""
         import math
-        from . import _lib, rasterizer
+        from . import _lib
         tr, m = self.tr, self.tr.model
         tr.join_side()
         cam = tr.cameras[0]
@@ -619,13 +612,13 @@ class BenchTrainer:
                     torch.cuda.synchronize()
                     _lib.profile_enable(True, stages=["composite_fwd"])
                     _lib.profile_read()
-                render(cam, m, tr.cfg, tr.background, dirs=tr.dirs)
+                pkg = render(cam, m, tr.cfg, tr.background, dirs=tr.dirs)
             torch.cuda.synchronize()
             ms, cnt = _lib.profile_read()["composite_fwd"]
         finally:
             _lib.profile_enable(False)
             m._scaling.data -= math.log(scale_mult)
-        R, P = rasterizer.last_stats["R"], cam.image_height * cam.image_width
+        R, P = pkg["raster"].R, cam.image_height * cam.image_width
         alg = (60 + 4 * sem) * R + (4 * (8 + sem) + 20) * P
         avg = ms / max(cnt, 1)
         ach = alg / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
