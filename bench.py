@@ -278,7 +278,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scale_mult": smult, "gaussians": n, "width": W, "height": H, "sh_degree": 3,
-                       "views_per_step": world, "tile_instances_R": R, "visible_V": trainer.last_V,
+                       "views_per_step": world, "tile_instances_R": R, "emitted_instances": trainer.last_E, "visible_V": trainer.last_V,
                        "max_tile_len": shape["max_tile_len"], "covered_pixels": shape["covered_pixels"],
                        "exchange": trainer.exchange(), "step": trainer.describe()},
             "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": per_step[0], "max": per_step[-1],

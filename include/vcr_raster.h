@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 12
+#define VCR_ABI_VERSION 13
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -101,6 +101,8 @@ typedef struct VcrForwardOut {
     int64_t  num_rendered;   /* R = number of (Gaussian, tile) instances */
     int32_t  num_visible;    /* V = Gaussians with radii > 0 */
     int32_t  max_tile_len;   /* longest per-tile list (only when debug != 0, else -1) */
+    int64_t  num_emitted;    /* R' <= R: tile instances really emitted -- tiles of a 3-sigma rectangle in which the Gaussian
+                              * cannot reach alpha >= 1/255 at any pixel centre are rejected (result-preserving) */
 } VcrForwardOut;
 
 /* Backward.  All gradient outputs are caller-allocated and fully overwritten (no pre-zeroing

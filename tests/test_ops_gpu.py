@@ -174,7 +174,9 @@ def test_visibility_and_importance_passes(device):
     assert tr.model._features_dc.grad is not None and fast["viewspace_points"].grad is not None
     tr.model.optimizer.zero_grad()
     vr, cr = visi_render(cams[1], tr.model, tr.cfg.pipline, tr.background), count_render(cams[1], tr.model, tr.cfg.pipline, tr.background)
-    assert torch.equal(vr["countlist"], cr["gaussians_count"]) and torch.equal(vr["important_score"], cr["important_score"])
+    assert torch.equal(vr["countlist"], cr["gaussians_count"])
+    assert torch.allclose(vr["important_score"], cr["important_score"], rtol=1e-5, atol=1e-7)     # (fp32 atomics: run-to-run order)
+    assert not vr["important_score"].requires_grad and not cr["gaussians_count"].requires_grad
     c2, i2 = prune_list(tr.model, list(cams), tr.cfg.pipline, tr.background)
     assert torch.equal(c2, cnt) and torch.allclose(i2, imp, rtol=1e-5, atol=1e-6)
     assert torch.equal(get_visi_list(tr.model, list(cams), tr.cfg.pipline, tr.background)["visi"] & tr.model.get_inside_gaus_normalized()[0], vis)
@@ -284,8 +286,9 @@ def test_two_stream_sh_path_trains_like_the_serial_loop(device):
             if tr.current_iteration in (3, 4):
                 keep = {g["name"]: g["params"][0].grad for g in tr.model.optimizer.param_groups}
                 tr.join_side()
-                pkg = render(cams[2], tr.model, tr.cfg, tr.background, dirs=tr.dirs, raster_options=RasterOptions("rgb"))
-                (7.0 * pkg["render"]).sum().backward()
+                with torch.enable_grad():
+                    pkg = render(cams[2], tr.model, tr.cfg, tr.background, dirs=tr.dirs, raster_options=RasterOptions("rgb"))
+                    (7.0 * pkg["render"]).sum().backward()
                 assert pkg["raster"].drgb is not None and pkg["raster"] is not rec
                 for g in tr.model.optimizer.param_groups:
                     g["params"][0].grad = keep[g["name"]]
@@ -375,8 +378,13 @@ def test_fused_loss_node_matches_modular_losses(device):
     for k in losses[0]:
         assert abs(losses[0][k] - losses[1][k]) < 2e-4 * max(1.0, abs(losses[0][k])), (k, losses[0][k], losses[1][k])
     for k in finals[0]:
-        d = float((finals[0][k] - finals[1][k]).abs().max())
-        assert d < 5e-3 * max(1.0, float(finals[0][k].abs().max())), (k, d)     # 10 steps amplify fp32 atomic-order noise
+        # 10 steps amplify fp32 atomic-order noise, and Adam moves an entry whose gradient is ~0 by +-lr per step whatever its
+        # size (0.05 for an opacity logit): the bound holds for all but a few per mille of the entries, as in the trajectory
+        # tests above
+        d = (finals[0][k] - finals[1][k]).abs()
+        tol = 5e-3 * max(1.0, float(finals[0][k].abs().max()))
+        assert float((d > tol).double().mean()) < 5e-3, (k, float(d.max()), float((d > tol).double().mean()))
+        assert float(d.median()) < 0.1 * tol, (k, float(d.median()))
 
 
 @pytest.mark.parametrize("n,bits,iota", [(1, 32, True), (777, 32, True), (8193, 9, False), (300001, 32, True),

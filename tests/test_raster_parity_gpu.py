@@ -294,8 +294,10 @@ def test_edge_screen_filling_gaussians(device):
     inp["opac"][:12] = 0.08
     out, ref, hl, rl, st = _fwd_bwd_vs_oracle(device, cam, inp, dirs, torch.tensor([0.1, 0.1, 0.1]))
     assert st["R"] >= 12 * 24                                    # the giants really cover all 6 x 4 tiles
+    # (twelve Gaussians that reach EVERY pixel: each of their gradient entries is a sum over the whole image, accumulated by
+    #  fp32 atomics from all 24 tiles -- 3x the tolerance of the ordinary cases; measured 2x on the rotations' p99.9)
     for k in ["means3D", "opac", "scales", "rots", "shs", "normals"]:
-        util.assert_grads_close(hl[k].grad, rl[k].grad, k)
+        util.assert_grads_close(hl[k].grad, rl[k].grad, k, scale=3.0)
 
 
 def test_edge_equal_depths_and_opacity_extremes(device):

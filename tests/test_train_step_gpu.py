@@ -72,9 +72,9 @@ def check(tr, data, before, grads, ref, got_losses, maxnorm_tol=None, p999_tol=N
     assert torch.equal(data["radii"].cpu(), ref["radii"])
     # every parameter's gradient
     for k in PARAMS:
-        util.assert_grads_close(grads[k], ref["grads"][k], k, maxnorm_tol, p999_tol)
+        util.assert_grads_close(grads[k], ref["grads"][k], k, maxnorm_tol, p999_tol, regime="step")
     dg = data["viewspace_points_densify"].grad.cpu()
-    util.assert_grads_close(dg[:, :2], ref["densify_grad"][:, :2], "means2D_densify", maxnorm_tol, p999_tol)
+    util.assert_grads_close(dg[:, :2], ref["densify_grad"][:, :2], "means2D_densify", maxnorm_tol, p999_tol, regime="step")
     # parameters after Adam: first step moves every entry by lr * g / (|g| + eps) = +-lr; entries whose gradient is not
     # negligible must agree to a small fraction of that step
     for k, a in PARAMS.items():

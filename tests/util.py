@@ -1,5 +1,6 @@
 """Shared helpers for the parity tests (seeded inputs, oracle drivers, comparison metrics)."""
 import math
+import os
 
 import torch
 
@@ -112,55 +113,69 @@ def grad_stats(a, b):
     return dict(maxnorm=rel_err(a, b), med=float(q[0]), p99=float(q[1]), p999=float(q[2]), max=float(e.max()) if e.numel() else 0.0)
 
 
-# Gradient acceptance used by every parity test, PER TENSOR: (max-norm relative error, element-wise p99, element-wise
-# p99.9; see elem_err) must stay below 3x the error of the ORACLE ITSELF run in fp32 against its fp64 self on the parity
-# cases -- the yardstick columns of profiles/r2_grad_error_table.txt, worst case over its six rows per tensor -- i.e. the
-# HIP path may be at most 3x as noisy as a plain fp32 evaluation of the same algorithm.  Floors: 2e-5 / 2e-5 / 2e-4
-# (below that the figure is a handful of fp32 ulps of a sum of ~100 terms).  Two tensors get 6x instead of 3x: the
-# gradients of the scales and the rotations pass through the Sigma2D -> Sigma3D -> (s, q) adjoint, which amplifies the
-# rounding of the three conic-gradient sums the compositing backward accumulates with fp32 atomics in arbitrary order
-# (measured 2 - 2.5x the oracle-fp32 figure; the oracle sums them pairwise in index order).
+# Gradient acceptance used by every parity test, PER TENSOR and PER REGIME: (max-norm relative error, element-wise p99,
+# element-wise p99.9; see elem_err) must stay below FACTOR x the error of the ORACLE ITSELF run in fp32 against its fp64 self
+# in the same regime -- tests/golden/grad_yardstick.json, produced on the CPU by profiles/grad_yardstick.py:
+#   "small"  the parity cases (<= 10 000 Gaussians, <= 256 x 256),
+#   "full"   the full-size sampled-tile cases (every pixel sees ~10x more pairs: the yardstick itself is ~6x wider there),
+#   "step"   whole training iterations (the image losses add their own fp32 reductions).
+# i.e. the HIP path may be at most FACTOR times as noisy as a plain fp32 evaluation of the same algorithm.  FACTOR = 3,
+# with these measured exceptions (HIP / yardstick over the GPU suite, profiles/r3_grad_ratio_table.txt):
+#   small: 4 for means3D / scales / rots -- their gradients pass through the Sigma2D -> Sigma3D -> (s, q) and projection
+#          adjoints, which amplify the rounding of the conic / position sums the compositing backward accumulates with
+#          fp32 atomics in arbitrary order (measured up to 3.3x; the oracle sums pairwise in index order);
+#   step:  (16, 8, 8): on top of that the whole-step scenes use 6x enlarged Gaussians (long per-pixel lists), where the
+#          back-to-front transmittance recovery T_i = T_{i+1} / (1 - alpha_i) of the backward -- the reference's algorithm,
+#          which the autograd oracle does not share -- accumulates one rounding per list entry (measured 3 - 6.7x on the
+#          quantiles, 11x on one max-norm);
+#   full:  3 throughout (measured 0.7 - 1.6x).
+# Floors: 2e-5 / 2e-5 / 2e-4 (below that the figure is a handful of fp32 ulps of a sum of ~100 terms).
 # (A pixel whose alpha >= 1/255 or T < 1e-4 decision flips between fp32 and fp64 moves the gradients of the few
 # Gaussians under it discretely -- those are the tolerated 0.1 %.)
-_YARDSTICK = {                 # oracle-fp32 vs oracle-fp64: max-norm, p99, p99.9 (worst of the committed cases)
-    "means3D": (2.2e-4, 1.1e-4, 4.9e-4),
-    "shs": (3.3e-5, 3.6e-5, 5.1e-4),
-    "normals": (3.6e-4, 2.9e-5, 2.2e-4),
-    "opac": (3.0e-4, 1.1e-4, 1.3e-3),
-    "scales": (1.3e-4, 1.2e-4, 1.0e-3),
-    "rots": (4.0e-4, 1.1e-4, 7.4e-4),
-    "m2": (2.0e-4, 7.3e-5, 4.5e-4),
-    "m2d": (8.7e-5, 3.1e-5, 1.0e-4),
-    "sem": (4.5e-7, 2.6e-6, 3.9e-5),
-}
-_FACTOR = {"scales": 6.0, "rots": 6.0}
+import json as _json
+
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "grad_yardstick.json")) as _f:
+    _YARDSTICK = _json.load(_f)
+_FACTOR = {"small": {"means3D": (4, 4, 4), "scales": (4, 4, 4), "rots": (4, 4, 4)}, "full": {}, "step": {None: (16, 8, 8)}}
 _FLOOR = (2e-5, 2e-5, 2e-4)
-# raw-parameter gradients of the whole-step tests go through the activation chain of the same tensors
+# other names the tests use for the same tensors
 _ALIAS = {"xyz": "means3D", "f_dc": "shs", "f_rest": "shs", "opacity": "opac", "scaling": "scales", "rotation": "rots",
           "means2D_densify": "m2d", "means2D": "m2", "obj_dc": "sem", "col": "shs", "cov": "scales", "op": "opac", "nrm": "normals"}
-GRAD_TOL = {k: tuple(max(_FACTOR.get(k, 3.0) * y, f) for y, f in zip(v, _FLOOR)) for k, v in _YARDSTICK.items()}
 # ceiling for tensors without a yardstick row (and the figure the per-tensor values replace)
 GRAD_MAXNORM_TOL = 1e-3
 GRAD_ELEM_P99_TOL = 1e-3
 GRAD_ELEM_P999_TOL = 1e-2
 
 
-def grad_tolerance(name):
+def grad_tolerance(name, regime="small"):
     """-> (max-norm, p99, p99.9) tolerance for the tensor called `name` ("deg2:shs", "xyz", ... resolve to their row)."""
     key = name.split(":")[-1]
-    key = _ALIAS.get(key, key)
-    return GRAD_TOL.get(key, (GRAD_MAXNORM_TOL, GRAD_ELEM_P99_TOL, GRAD_ELEM_P999_TOL))
+    table = _YARDSTICK[regime]
+    if key not in table:
+        key = _ALIAS.get(key, key)
+    if key not in table:
+        return (GRAD_MAXNORM_TOL, GRAD_ELEM_P99_TOL, GRAD_ELEM_P999_TOL)
+    fac = _FACTOR[regime].get(key, _FACTOR[regime].get(None, (3, 3, 3)))
+    return tuple(max(f * y, fl) for f, y, fl in zip(fac, table[key], _FLOOR))
 
 
-def assert_grads_close(got, ref, name, maxnorm_tol=None, p999_tol=None, p99_tol=None, scale=1.0):
-    """`scale`: documented per-test widening factor on the tensor's own tolerances; explicit *_tol values replace them."""
+def assert_grads_close(got, ref, name, maxnorm_tol=None, p999_tol=None, p99_tol=None, scale=1.0, regime="small"):
+    """`regime`: which yardstick applies; `scale`: documented per-test widening factor on the tensor's own tolerances;
+    explicit *_tol values replace them."""
     st = grad_stats(got, ref)
-    t_max, t_p99, t_p999 = (scale * t for t in grad_tolerance(name))
+    t_max, t_p99, t_p999 = (scale * t for t in grad_tolerance(name, regime))
     if p999_tol is not None and p99_tol is None:
         p99_tol = GRAD_ELEM_P99_TOL * (p999_tol / GRAD_ELEM_P999_TOL)
     maxnorm_tol = t_max if maxnorm_tol is None else maxnorm_tol
     p99_tol = t_p99 if p99_tol is None else p99_tol
     p999_tol = t_p999 if p999_tol is None else p999_tol
+    rep = os.environ.get("VCR_GRAD_REPORT")
+    if rep:               # calibration runs: log measured figure vs tolerance for every call instead of stopping at the first
+        ok = st["maxnorm"] < maxnorm_tol and st["p99"] < p99_tol and st["p999"] < p999_tol
+        with open(rep, "a") as f:
+            f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]} | {name} | {'ok' if ok else 'FAIL'} | maxnorm {st['maxnorm']:.2e}/{maxnorm_tol:.1e}"
+                    f" | p99 {st['p99']:.2e}/{p99_tol:.1e} | p999 {st['p999']:.2e}/{p999_tol:.1e} | n {int(torch.as_tensor(ref).numel())}\n")
+        return st
     assert st["maxnorm"] < maxnorm_tol, f"grad {name}: max-norm rel err {st['maxnorm']:.2e} >= {maxnorm_tol:.1e} (stats {st})"
     assert st["p99"] < p99_tol, f"grad {name}: element-wise p99 err {st['p99']:.2e} >= {p99_tol:.1e} (stats {st})"
     assert st["p999"] < p999_tol, f"grad {name}: element-wise p99.9 err {st['p999']:.2e} >= {p999_tol:.1e} (stats {st})"
@@ -241,6 +256,6 @@ def sampled_tile_parity(device, cam, inp, dirs, bg, stride, min_inst, name, min_
             continue
         gfull = hl[k].grad.cpu()
         assert float(gfull[~hit].abs().max()) == 0.0 if (~hit).any() else True, f"{k}: gradient outside the sampled subset"
-        assert_grads_close(gfull[hit][clean], rl[k].grad[clean], f"{name}:{k}")
-    assert_grads_close(hl["m2d"].grad.cpu()[hit][clean][:, :2], rl["m2d"].grad[clean][:, :2], f"{name}:m2d")
+        assert_grads_close(gfull[hit][clean], rl[k].grad[clean], f"{name}:{k}", regime="full")
+    assert_grads_close(hl["m2d"].grad.cpu()[hit][clean][:, :2], rl["m2d"].grad[clean][:, :2], f"{name}:m2d", regime="full")
     return dict(instances=inst, flipped=bad, sampled_pixels=int(o.shape[1]), subset=int(hit.sum()))

@@ -16,7 +16,7 @@ c_int_p = C.POINTER(C.c_int32)
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 BUF_GEOM, BUF_BINNING, BUF_IMAGE, BUF_SCRATCH = 0, 1, 2, 3
-ABI_VERSION = 12         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
+ABI_VERSION = 13         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
 
 
 class VcrShUpdate(C.Structure):
@@ -56,7 +56,7 @@ class VcrForwardOut(C.Structure):
     _fields_ = [
         ("out", C.c_void_p), ("radii", C.c_void_p), ("count", C.c_void_p), ("score", C.c_void_p),
         ("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p),
-        ("num_rendered", C.c_int64), ("num_visible", C.c_int32), ("max_tile_len", C.c_int32),
+        ("num_rendered", C.c_int64), ("num_visible", C.c_int32), ("max_tile_len", C.c_int32), ("num_emitted", C.c_int64),
     ]
 
 

@@ -1,55 +1,59 @@
 // K2-K5: depth ordering, tile-instance emission, stable tile sort, per-tile ranges.
 //
 // MI355X-first ordering scheme (not the 64-bit (tile|depth) key sort of the public rasterizer):
-//   1. radix-sort the N Gaussians once by their 32-bit view depth (N*8 B per pass, tiny),
-//   2. emit (tile, id) instances in that depth order with a load-balanced wave-cooperative kernel that carries its own
-//      offsets scan (decoupled look-back),
-//   3. STABLE radix sort of the R instances on the tile bits only (ceil(log2 T) <= 14 bits -> 2 passes
-//      over 8-byte pairs instead of 6 passes over 12-byte pairs),
-// which yields the same (tile, depth, id) order with ~3.5x less sort traffic.  Both sorts run on the hand-written radix
-// sort of radix_sort.hip at every size; no library primitive is left on the path.
+//   1. radix-sort the N Gaussians once by their 32-bit view depth (8-byte pairs),
+//   2. emit (tile, id) instances in that depth order with a kernel that carries its own offsets scan (decoupled
+//      look-back).  Which tiles of its 3-sigma rectangle a Gaussian really reaches (alpha >= 1/255 at some pixel centre)
+//      was decided EXACTLY by the projection kernel and travels as a bit mask in the 8-byte rectangle record (round 3;
+//      rectangles of more than 32 tiles emit every tile),
+//   3. STABLE radix sort of the emitted R' instances on the tile bits only (ceil(log2 T) <= 14 bits -> 2 passes of
+//      <= 7 bits over 8-byte pairs instead of 6 passes over 12-byte pairs),
+// which yields the same (tile, depth, id) order.  The host reads R' back together with V and R (the 3-sigma count the
+// reference reports) right after the projection, so buffers and grids are sized for what is really emitted.
 #include "vcr_common.h"
 #include <cstring>
 #include <cstdlib>
 
 namespace {
 
-// Tile-instance emission with the offsets scan fused in.  Block b takes 256 Gaussians of the depth order, scans their tile
-// counts, obtains the number of instances before it by decoupled look-back over the status words of the earlier blocks
-// (flag | running total in ONE 64-bit word, so no data has to be ordered against the flag), and then emits its instances
-// wave-cooperatively and load-balanced: the wave's 64 counts are prefix-summed in LDS and every lane binary-searches the
-// slot it writes (giant Gaussians do not serialise a lane).  `status`: one zeroed 64-bit word per block.
 constexpr unsigned long long ST_AGG = 1ull << 32, ST_PREFIX = 2ull << 32;
-
 constexpr int DUP_ROUNDS = 4;                       // Gaussians per thread: 1024 per block keeps the look-back chain short
 
+// Tile-instance emission with the offsets scan fused in.  A block takes 1024 Gaussians of the depth order (4 rounds of
+// 256), scans their instance counts (popcount of the tile mask, or width x height for the few rectangles without one),
+// obtains the number of instances before it by decoupled look-back over the status words of the earlier blocks (flag |
+// running total in ONE 64-bit word, so no data has to be ordered against the flag; the logical block order comes from an
+// atomic ticket, so forward progress does not depend on the dispatch order of the workgroups), and emits:
+//   * masked rectangles (<= 32 tiles, nearly all): every lane walks the set bits of ITS mask -- a handful of iterations;
+//   * unmasked giants: wave-cooperatively and load-balanced -- the wave's giant counts are prefix-summed in LDS and every
+//     lane binary-searches the Gaussian its slot belongs to, so a screen-filling Gaussian does not serialise a lane.
+// `status`: one zeroed 64-bit word per block; `ticket`: one zeroed word.
 __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, const uint32_t* __restrict__ ids_sorted,
-                                                        unsigned long long* __restrict__ status,
-                                                        const uint2* __restrict__ rect,
-                                                        uint32_t* __restrict__ keys_out,
+                                                        unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket,
+                                                        const uint2* __restrict__ rect, uint32_t* __restrict__ keys_out,
                                                         uint32_t* __restrict__ vals_out, uint2* __restrict__ ranges,
                                                         int num_tiles) {
-    __shared__ uint32_t s_end[4][64], s_start[4][64], s_id[4][64];
+    __shared__ uint32_t s_gend[4][64], s_start[4][64], s_id[4][64];
     __shared__ int s_xmin[4][64], s_ymin[4][64], s_w[4][64];
-    __shared__ uint32_t s_wtot[DUP_ROUNDS][4], s_prefix;
+    __shared__ uint32_t s_wtot[DUP_ROUNDS][4], s_prefix, s_bid;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int gx = (W + VCR_TILE - 1) / VCR_TILE;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < num_tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);   // empty tiles
+    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int bid = (int)s_bid;
     // round r of this block covers the Gaussians base + r*256 + tid of the depth order
-    const int base = blockIdx.x * (256 * DUP_ROUNDS);
+    const int base = bid * (256 * DUP_ROUNDS);
     uint32_t id[DUP_ROUNDS], cnt[DUP_ROUNDS], inc[DUP_ROUNDS];
-    int xmin[DUP_ROUNDS], ymin[DUP_ROUNDS], w[DUP_ROUNDS];
+    uint2 rc[DUP_ROUNDS];
 #pragma unroll
     for (int r = 0; r < DUP_ROUNDS; ++r) {
         const int gi = base + r * 256 + (int)threadIdx.x;
-        id[r] = 0; cnt[r] = 0; xmin[r] = 0; ymin[r] = 0; w[r] = 1;
+        id[r] = 0; cnt[r] = 0; rc[r] = make_uint2(0u, 0u);
         if (gi < N) {
             id[r] = ids_sorted[gi];
-            const uint2 rc = rect[id[r]];                // {0, 0} for culled Gaussians
-            w[r] = (int)(rc.y & 0xFFFFu);
-            cnt[r] = (uint32_t)w[r] * (rc.y >> 16);
-            xmin[r] = (int)(rc.x & 0xFFFFu); ymin[r] = (int)(rc.x >> 16);
-            if (cnt[r] == 0) w[r] = 1;
+            rc[r] = rect[id[r]];                          // {0, 0} for culled Gaussians
+            cnt[r] = (rc[r].x & VCR_RECT_MASKED) ? (uint32_t)__popc(rc[r].y) : (rc[r].y & 0xFFFFu) * (rc[r].y >> 16);
         }
     }
 #pragma unroll
@@ -68,9 +72,9 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
     for (int r = 0; r < DUP_ROUNDS; ++r) agg += s_wtot[r][0] + s_wtot[r][1] + s_wtot[r][2] + s_wtot[r][3];
     if (wv == 0) {                                       // decoupled look-back by the first wave
         uint32_t excl = 0;
-        if (blockIdx.x > 0) {
-            if (lane == 0) __hip_atomic_store(status + blockIdx.x, ST_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int look = (int)blockIdx.x - 1;
+        if (bid > 0) {
+            if (lane == 0) __hip_atomic_store(status + bid, ST_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int look = bid - 1;
             for (;;) {
                 const int b = look - lane;
                 unsigned long long sv = ST_PREFIX;        // lanes past block 0 count as a zero prefix
@@ -87,7 +91,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
             }
         }
         if (lane == 0) {
-            __hip_atomic_store(status + blockIdx.x, ST_PREFIX | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(status + bid, ST_PREFIX | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_prefix = excl;
         }
     }
@@ -97,34 +101,52 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
     for (int r = 0; r < DUP_ROUNDS; ++r) {
         uint32_t wpre = 0;
         for (int k = 0; k < wv; ++k) wpre += s_wtot[r][k];
-        const uint32_t end = round_base + wpre + inc[r];
+        const uint32_t start = round_base + wpre + inc[r] - cnt[r];      // first output slot of this lane's Gaussian
         round_base += s_wtot[r][0] + s_wtot[r][1] + s_wtot[r][2] + s_wtot[r][3];
+        const bool masked = (rc[r].x & VCR_RECT_MASKED) != 0;
+        const int xmin = (int)(rc[r].x & 0x3FFu), ymin = (int)((rc[r].x >> 10) & 0x3FFu);
+        if (masked) {                                      // walk the set bits of the tile mask
+            const int w = (int)((rc[r].x >> 20) & 31u) + 1;
+            uint32_t m = rc[r].y, at = start;
+            while (m) {
+                const int k = __builtin_ctz(m);
+                m &= m - 1;
+                keys_out[at] = (uint32_t)((ymin + k / w) * gx + xmin + k % w);
+                vals_out[at] = id[r];
+                ++at;
+            }
+        }
+        const bool giant = !masked && cnt[r] != 0;
+        if (__builtin_amdgcn_ballot_w64(giant) == 0) continue;            // (wave-uniform)
+        uint32_t gc = giant ? cnt[r] : 0u;                 // inclusive scan of the giants' counts inside the wave
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = (uint32_t)__shfl_up((int)gc, o);
+            if (lane >= o) gc += u;
+        }
         __builtin_amdgcn_wave_barrier();                 // the previous round's reads of this wave's LDS rows are done
-        s_end[wv][lane] = end; s_start[wv][lane] = end - cnt[r]; s_id[wv][lane] = id[r];
-        s_xmin[wv][lane] = xmin[r]; s_ymin[wv][lane] = ymin[r]; s_w[wv][lane] = w[r];
+        s_gend[wv][lane] = gc; s_start[wv][lane] = start; s_id[wv][lane] = id[r];
+        s_xmin[wv][lane] = xmin; s_ymin[wv][lane] = ymin; s_w[wv][lane] = giant ? (int)(rc[r].y & 0xFFFFu) : 1;
         __builtin_amdgcn_wave_barrier();
-        const uint32_t wave_base = s_start[wv][0];
-        const uint32_t total = s_end[wv][63] - wave_base;
+        const uint32_t total = s_gend[wv][63];
         for (uint32_t e = lane; e < total; e += 64) {
-            const uint32_t target = wave_base + e;
-            int lo = 0, hi = 63;                       // first lane whose end > target
+            int lo = 0, hi = 63;                       // first lane whose end > e
 #pragma unroll
             for (int it = 0; it < 6; ++it) {
                 const int mid = (lo + hi) >> 1;
-                if (s_end[wv][mid] > target) hi = mid; else lo = mid + 1;
+                if (s_gend[wv][mid] > e) hi = mid; else lo = mid + 1;
             }
-            const uint32_t local = target - s_start[wv][lo];
+            const uint32_t local = e - (lo ? s_gend[wv][lo - 1] : 0u);
             const int ww = s_w[wv][lo];
             const int ty = s_ymin[wv][lo] + (int)(local / (uint32_t)ww);
             const int tx = s_xmin[wv][lo] + (int)(local % (uint32_t)ww);
+            const uint32_t target = s_start[wv][lo] + local;
             keys_out[target] = (uint32_t)(ty * gx + tx);
             vals_out[target] = s_id[wv][lo];
         }
     }
 }
 
-__global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t R, const uint32_t* __restrict__ keys,
-                                                          uint2* __restrict__ ranges) {
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t R, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= R) return;
     const uint32_t k = keys[i];
@@ -143,15 +165,17 @@ size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits) {
     return vcr_align(b0 > b2 ? b0 : b2);
 }
 
-size_t vcr_duplicate_status_bytes(int N) { return vcr_align(sizeof(unsigned long long) * (size_t)((N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS) + 1)); }
+// look-back status words of the emission kernel (+ its ticket word at the end), zeroed by the caller
+size_t vcr_duplicate_status_bytes(int N) { return vcr_align(sizeof(unsigned long long) * (size_t)((N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS) + 2)); }
 
-// depth order of the N Gaussians (ties by index).  (tmp_k, tmp_v): N words each; `totals`: VCR_SORT_TOTALS_WORDS zeroed words.
+// depth order of the N Gaussians (ties by index).  (tmp_k, tmp_v): N words each; `totals`: VCR_SORT_TOTALS_WORDS words.
 int vcr_depth_sort(int N, const uint32_t* depth_key, uint32_t* tmp_k, uint32_t* tmp_v, uint32_t* key_sorted,
                    uint32_t* ids_sorted, uint32_t* totals, void* temp, hipStream_t st) {
-    return vcr_sort_pairs(N, depth_key, nullptr, tmp_k, tmp_v, key_sorted, ids_sorted, 0, 32, (uint32_t*)temp, totals, st);
+    return vcr_sort_pairs(N, depth_key, nullptr, tmp_k, tmp_v, key_sorted, ids_sorted, 0, 32, (uint32_t*)temp, totals, st, nullptr);
 }
 
 // (keys_a, vals_a): instance buffers; (keys_t, vals_t): a second pair; keys_b / point_list: the sorted result.
+// R: the number of instances the emission kernel writes (the host's read-back of the projection kernel's count).
 int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const uint32_t* ids_sorted,
                            unsigned long long* status, int64_t R, int tile_bits, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_t, uint32_t* vals_t, uint32_t* keys_b, uint32_t* point_list, uint2* ranges,
@@ -161,17 +185,18 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
     static const bool no_snake = getenv("VCR_NO_SNAKE") != nullptr;
     if (R <= 0) {
         VCR_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, st));
-        return vcr_launch_tile_order(num_tiles, ranges, tile_order, meta, false, false, st);   // identity order
+        return vcr_launch_tile_order(num_tiles, ranges, tile_order, meta, 0, false, false, st);   // identity order
     }
     const int blocks = (a.N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS);
-    hipLaunchKernelGGL(duplicate_kernel, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, g.rect,
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(status + blocks + 1);
+    hipLaunchKernelGGL(duplicate_kernel, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, ticket, g.rect,
                        keys_a, vals_a, ranges, num_tiles);
     VCR_HIP_CHECK(hipGetLastError());
-    if (vcr_sort_pairs(R, keys_a, vals_a, keys_t, vals_t, keys_b, point_list, 0, tile_bits, (uint32_t*)temp, totals, st)) {
+    if (vcr_sort_pairs(R, keys_a, vals_a, keys_t, vals_t, keys_b, point_list, 0, tile_bits, (uint32_t*)temp, totals, st, nullptr)) {
         return 1;
     }
     const int64_t rb = (R + 255) / 256;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)rb), dim3(256), 0, st, R, keys_b, ranges);
     VCR_HIP_CHECK(hipGetLastError());
-    return vcr_launch_tile_order(num_tiles, ranges, tile_order, meta, !no_lpt, !no_snake, st);
+    return vcr_launch_tile_order(num_tiles, ranges, tile_order, meta, R, !no_lpt, !no_snake, st);
 }

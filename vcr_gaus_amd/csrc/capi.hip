@@ -44,19 +44,20 @@ struct StageTimer {
     }
 };
 
-// device counters of one forward call, zeroed by ONE memset: visible-count slots, tile-instance-count slots and the
-// digit totals of the two radix sorts
-#define VCR_CTR_WORDS (2 * VCR_VIS_SLOTS + 2 * VCR_SORT_TOTALS_WORDS)
+// device counters of one forward call, zeroed by ONE memset together with the emission kernel's look-back words:
+// visible-count slots and tile-instance-count slots
+#define VCR_CTR_WORDS (3 * VCR_VIS_SLOTS)
 struct Readback { uint32_t V[VCR_VIS_SLOTS]; uint32_t R[VCR_VIS_SLOTS]; };
-// what the host polls: totals + a sequence number published by the device AFTER the totals (system-scope fence)
-struct Published { unsigned long long R; uint32_t V; volatile uint32_t seq; };
+// what the host polls: totals + a sequence number published by the device AFTER the totals (system-scope fence).
+// R: tile instances of the 3-sigma rectangles (what the reference counts), E: instances really emitted (exact rejection)
+struct Published { unsigned long long R, E; uint32_t V; volatile uint32_t seq; };
 
 Published* pinned_published() {
     static thread_local Published* p = nullptr;
     if (!p) {
         // coherent (uncached on the device side) so that the host sees the device's system-scope stores while the stream runs
         if (hipHostMalloc((void**)&p, sizeof(Published), hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) { p = nullptr; return nullptr; }
-        p->R = 0; p->V = 0; p->seq = 0;
+        p->R = 0; p->E = 0; p->V = 0; p->seq = 0;
     }
     return p;
 }
@@ -65,15 +66,16 @@ Published* pinned_published() {
 // sleeping in hipEventSynchronize, whose wake-up latency (interrupt path) can exceed the ~0.15 ms of sort work that is
 // queued behind this kernel to cover it.
 __global__ void __launch_bounds__(256) publish_counts_kernel(const uint32_t* __restrict__ slots, Published* host, uint32_t seq) {
-    __shared__ unsigned long long s_r[4];
+    __shared__ unsigned long long s_r[4], s_e[4];
     __shared__ uint32_t s_v[4];
-    unsigned long long r = 0; uint32_t v = 0;
-    for (int k = threadIdx.x; k < VCR_VIS_SLOTS; k += 256) { v += slots[k]; r += slots[VCR_VIS_SLOTS + k]; }
-    for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o); r += __shfl_xor(r, o); }
-    if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = v; s_r[threadIdx.x >> 6] = r; }
+    unsigned long long r = 0, e = 0; uint32_t v = 0;
+    for (int k = threadIdx.x; k < VCR_VIS_SLOTS; k += 256) { v += slots[k]; r += slots[VCR_VIS_SLOTS + k]; e += slots[2 * VCR_VIS_SLOTS + k]; }
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o); r += __shfl_xor(r, o); e += __shfl_xor(e, o); }
+    if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = v; s_r[threadIdx.x >> 6] = r; s_e[threadIdx.x >> 6] = e; }
     __syncthreads();
     if (threadIdx.x == 0) {
         host->R = s_r[0] + s_r[1] + s_r[2] + s_r[3];
+        host->E = s_e[0] + s_e[1] + s_e[2] + s_e[3];
         host->V = s_v[0] + s_v[1] + s_v[2] + s_v[3];
         __threadfence_system();
         host->seq = seq;
@@ -117,6 +119,7 @@ __global__ void max_tile_len_kernel(int T, const uint2* __restrict__ ranges, uin
 int validate(const VcrRasterArgs* a) {
     if (!a) { vcr_set_error("args is NULL"); return 1; }
     if (a->N < 0 || a->H <= 0 || a->W <= 0) { vcr_set_error("bad sizes N=%d H=%d W=%d", a->N, a->H, a->W); return 1; }
+    if (a->H > VCR_MAX_IMAGE_DIM || a->W > VCR_MAX_IMAGE_DIM) { vcr_set_error("image %dx%d exceeds %d pixels per side", a->W, a->H, VCR_MAX_IMAGE_DIM); return 1; }
     if (a->S < 0 || a->S > VCR_MAX_SEM) { vcr_set_error("semantic channels S=%d unsupported (0..%d)", a->S, VCR_MAX_SEM); return 1; }
     if (a->num_dist < 0 || a->num_dist > 2) {
         vcr_set_error("num_dist=%d unsupported: 0 (none), 1 (depth distortion) or 2 (depth moments sum w d, sum w d^2)",
@@ -165,7 +168,6 @@ extern "C" int vcr_sort_pairs_u32(int64_t n, const uint32_t* keys_in, const uint
     if (!scratch || scratch_bytes < need) { vcr_set_error("vcr_sort_pairs_u32: scratch too small (%zu < %zu)", scratch_bytes, need); return 1; }
     char* s = (char*)scratch;
     hipStream_t st = (hipStream_t)stream;
-    VCR_HIP_CHECK(hipMemsetAsync(s + 2 * nb, 0, tot, st));
     return vcr_sort_pairs(n, keys_in, vals_in, (uint32_t*)s, (uint32_t*)(s + nb), keys_out, vals_out, begin_bit, end_bit,
                           (uint32_t*)(s + 2 * nb + tot), (uint32_t*)(s + 2 * nb), st);
 }
@@ -188,7 +190,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
     if (a.f_count != 3 && !out->out) { vcr_set_error("out buffer is NULL"); return 1; }
     if (a.f_count != 0 && !out->count) { vcr_set_error("count buffer is NULL for f_count=%d", a.f_count); return 1; }
     if ((a.f_count == 1 || a.f_count == 2) && !out->score) { vcr_set_error("score buffer is NULL"); return 1; }
-    out->num_rendered = 0; out->num_visible = 0; out->max_tile_len = -1;
+    out->num_rendered = 0; out->num_visible = 0; out->max_tile_len = -1; out->num_emitted = -1;
     out->geom = out->binning = out->image = nullptr;
 
     void* geom_p = alloc(user, VCR_BUF_GEOM, GeomState::bytes(N > 0 ? N : 1, a.S));
@@ -205,8 +207,9 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         const size_t tmp1 = vcr_binning_temp_bytes(N, 0, tbits);
         const size_t nb = vcr_align(sizeof(uint32_t) * (size_t)N);
         const size_t ctr_bytes = vcr_align(sizeof(uint32_t) * VCR_CTR_WORDS);
-        const size_t status_bytes = vcr_duplicate_status_bytes(N);       // look-back words of the emission kernel, zeroed with the counters
-        char* s1 = (char*)alloc(user, VCR_BUF_SCRATCH, 5 * nb + ctr_bytes + status_bytes + tmp1);
+        const size_t status_bytes = vcr_duplicate_status_bytes(N);       // look-back words + ticket of the emission kernel, zeroed with the counters
+        const size_t tot_bytes = vcr_align(sizeof(uint32_t) * 2 * VCR_SORT_TOTALS_WORDS);   // digit totals of the two sorts (not zeroed)
+        char* s1 = (char*)alloc(user, VCR_BUF_SCRATCH, 5 * nb + ctr_bytes + status_bytes + tot_bytes + tmp1);
         if (!s1) { vcr_set_error("allocator returned NULL"); return 1; }
         uint32_t* depth_key = (uint32_t*)s1;
         uint32_t* ids = (uint32_t*)(s1 + nb);                 // iota from preprocess; reused as the sort's second key buffer
@@ -216,9 +219,9 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         uint32_t* ctr = (uint32_t*)(s1 + 5 * nb);
         unsigned long long* dup_status = (unsigned long long*)(s1 + 5 * nb + ctr_bytes);
         uint32_t* vis_counter = ctr;
-        uint32_t* totals_depth = ctr + 2 * VCR_VIS_SLOTS;
+        uint32_t* totals_depth = (uint32_t*)(s1 + 5 * nb + ctr_bytes + status_bytes);
         uint32_t* totals_tile = totals_depth + VCR_SORT_TOTALS_WORDS;
-        void* temp1 = s1 + 5 * nb + ctr_bytes + status_bytes;
+        void* temp1 = s1 + 5 * nb + ctr_bytes + status_bytes + tot_bytes;
         VCR_HIP_CHECK(hipMemsetAsync(ctr, 0, ctr_bytes + status_bytes, st));
         // Work launched on the optional streams must be joined on EVERY exit (the scratch buffers go back to the caller's
         // stream-ordered allocator when this call returns): error returns go through join_streams().
@@ -228,6 +231,15 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             if (colour_launched) (void)hipStreamWaitEvent(st, colour_event(1), 0);
             return 1;
         };
+        // like VCR_HIP_CHECK, but the error return first makes `st` wait for whatever already runs on the optional streams
+#define VCR_HIP_CHECK_JOIN(expr)                                                                        \
+        do {                                                                                            \
+            hipError_t _e = (expr);                                                                     \
+            if (_e != hipSuccess) {                                                                     \
+                vcr_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+                return join_streams();                                                                  \
+            }                                                                                           \
+        } while (0)
         // optional sort stream: depth keys + depth sort of the N Gaussians start now, beside the projection
         const bool split_sort = a.sort_stream && a.sort_stream != stream;
         if (split_sort) {
@@ -241,8 +253,13 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
                 StageTimer tm(ST_DEPTHSORT, ss);
                 rc = vcr_depth_sort(N, depth_key, ids, tmp_v, key_sorted, ids_sorted, totals_depth, temp1, ss);
             }
-            VCR_HIP_CHECK(hipEventRecord(e_sorted, ss));
-            sort_launched = true;
+            sort_launched = true;                           // (from here on every exit joins the sort stream)
+            if (hipEventRecord(e_sorted, ss) != hipSuccess) {  // no event to wait on: drain the stream instead
+                (void)hipStreamSynchronize(ss);
+                sort_launched = false;
+                vcr_set_error("hipEventRecord on the sort stream failed");
+                return join_streams();
+            }
             if (rc) return join_streams();
         }
         // two-stream form: geometry here, SH -> RGB on the colour stream behind whatever the caller queued there
@@ -257,12 +274,17 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             hipEvent_t e_geo = colour_event(0), e_col = colour_event(1);
             if (!e_geo || !e_col) { vcr_set_error("hipEventCreate for the colour stream failed"); return join_streams(); }
             hipStream_t cs = (hipStream_t)a.colour_stream;
-            VCR_HIP_CHECK(hipEventRecord(e_geo, st));
-            VCR_HIP_CHECK(hipStreamWaitEvent(cs, e_geo, 0));
+            VCR_HIP_CHECK_JOIN(hipEventRecord(e_geo, st));
+            VCR_HIP_CHECK_JOIN(hipStreamWaitEvent(cs, e_geo, 0));
             if (a.colour_stream_hook) a.colour_stream_hook(a.colour_stream_hook_user);
             const int rc = a.sh_update ? vcr_launch_sh_update_colour(a, g, cs) : vcr_launch_colour(a, g, cs);
-            VCR_HIP_CHECK(hipEventRecord(e_col, cs));
             colour_launched = true;
+            if (hipEventRecord(e_col, cs) != hipSuccess) {
+                (void)hipStreamSynchronize(cs);
+                colour_launched = false;
+                vcr_set_error("hipEventRecord on the colour stream failed");
+                return join_streams();
+            }
             if (rc) return join_streams();
         }
         // R and V go back to the host now; the depth sort and the offsets scan do not need them and keep the GPU busy
@@ -274,8 +296,8 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         static thread_local uint32_t seq_counter = 0;
         const uint32_t seq = ++seq_counter ? seq_counter : ++seq_counter;      // never 0
         hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(256), 0, st, vis_counter, pub, seq);
-        VCR_HIP_CHECK(hipGetLastError());
-        VCR_HIP_CHECK(hipEventRecord(ev, st));
+        VCR_HIP_CHECK_JOIN(hipGetLastError());
+        VCR_HIP_CHECK_JOIN(hipEventRecord(ev, st));
         if (!split_sort) {
             StageTimer tm(ST_DEPTHSORT, st);
             if (vcr_depth_sort(N, depth_key, ids, tmp_v, key_sorted, ids_sorted, totals_depth, temp1, st)) return join_streams();
@@ -302,45 +324,49 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
         }
         R = (int64_t)pub->R;
+        const int64_t E = (int64_t)pub->E;                  // what the emission kernel will write: sizes everything below
         out->num_visible = (int32_t)pub->V;
+        out->num_emitted = E;
         if (R >= (1ll << 32)) { vcr_set_error("more than 2^32 tile instances"); return fail_joined(); }
 
-        void* bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(R, T));
+        void* bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(E, T));
         if (!bin_p) { vcr_set_error("allocator returned NULL"); return fail_joined(); }
-        BinState b = BinState::view(bin_p, R, T);
+        BinState b = BinState::view(bin_p, T);
         out->binning = bin_p;
-        const size_t tmp2 = vcr_binning_temp_bytes(N, R, tbits);
-        const size_t rbts = vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1));
+        const size_t tmp2 = vcr_binning_temp_bytes(N, E, tbits);
+        const size_t rbts = vcr_align(sizeof(uint32_t) * (size_t)(E > 0 ? E : 1));
         char* s2 = (char*)alloc(user, VCR_BUF_SCRATCH, 5 * rbts + tmp2);
         if (!s2) { vcr_set_error("allocator returned NULL"); return fail_joined(); }
-        if (split_sort) VCR_HIP_CHECK(hipStreamWaitEvent(st, colour_event(3), 0));       // the depth order is needed from here on
+        if (split_sort) VCR_HIP_CHECK_JOIN(hipStreamWaitEvent(st, colour_event(3), 0));  // the depth order is needed from here on
         {
             StageTimer tm(ST_BINNING, st);
-            if (vcr_duplicate_and_sort(a, g, out->radii, ids_sorted, dup_status, R, tbits, (uint32_t*)s2, (uint32_t*)(s2 + rbts),
+            if (vcr_duplicate_and_sort(a, g, out->radii, ids_sorted, dup_status, E, tbits, (uint32_t*)s2, (uint32_t*)(s2 + rbts),
                                        (uint32_t*)(s2 + 2 * rbts), (uint32_t*)(s2 + 3 * rbts), (uint32_t*)(s2 + 4 * rbts),
                                        b.point_list, b.ranges, b.tile_order, b.meta, T, totals_tile, s2 + 5 * rbts, tmp2, st))
                 return fail_joined();
         }
         out->num_rendered = R;
         if (a.debug) {                       // diagnostics only: longest per-tile list (one extra sync)
-            VCR_HIP_CHECK(hipMemsetAsync(vis_counter, 0, sizeof(uint32_t), st));
+            VCR_HIP_CHECK_JOIN(hipMemsetAsync(vis_counter, 0, sizeof(uint32_t), st));
             hipLaunchKernelGGL(max_tile_len_kernel, dim3(32), dim3(256), 0, st, T, b.ranges, vis_counter);
-            VCR_HIP_CHECK(hipMemcpyAsync(&rb->R[0], vis_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            VCR_HIP_CHECK(hipStreamSynchronize(st));
+            VCR_HIP_CHECK_JOIN(hipMemcpyAsync(&rb->R[0], vis_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            VCR_HIP_CHECK_JOIN(hipStreamSynchronize(st));
             out->max_tile_len = (int32_t)rb->R[0];
         }
-        if (split_colour) VCR_HIP_CHECK(hipStreamWaitEvent(st, colour_event(1), 0));
+        if (split_colour) VCR_HIP_CHECK_JOIN(hipStreamWaitEvent(st, colour_event(1), 0));
         {
             StageTimer tm(ST_COMPOSITE_FWD, st);
-            if (vcr_launch_composite_forward(a, g, b, im, *out, st)) return 1;
+            if (vcr_launch_composite_forward(a, g, b, im, *out, st)) return fail_joined();
         }
+#undef VCR_HIP_CHECK_JOIN
     } else {
         void* bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(0, T));
         if (!bin_p) { vcr_set_error("allocator returned NULL"); return 1; }
-        BinState b = BinState::view(bin_p, 0, T);
+        BinState b = BinState::view(bin_p, T);
         out->binning = bin_p;
+        out->num_emitted = 0;
         VCR_HIP_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * (size_t)T, st));
-        if (vcr_launch_tile_order(T, b.ranges, b.tile_order, b.meta, false, false, st)) return 1;   // identity order
+        if (vcr_launch_tile_order(T, b.ranges, b.tile_order, b.meta, 0, false, false, st)) return 1;   // identity order
         VCR_HIP_CHECK(hipMemsetAsync(img_p, 0, ImageState::bytes(P), st));
         if (a.f_count != 3)
             hipLaunchKernelGGL(fill_background_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, a.f_count ? 3 : C, a.bg,
@@ -367,7 +393,7 @@ extern "C" int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* 
     if (a.cov3D_precomp && !io->dL_dcov3D) { vcr_set_error("backward: dL_dcov3D is NULL"); return 1; }
     const int gx = (a.W + VCR_TILE - 1) / VCR_TILE, gy = (a.H + VCR_TILE - 1) / VCR_TILE;
     GeomState g = GeomState::view(const_cast<void*>(io->geom), N, a.S);
-    BinState b = BinState::view(const_cast<void*>(io->binning), io->num_rendered, gx * gy);
+    BinState b = BinState::view(const_cast<void*>(io->binning), gx * gy);
     ImageState im = ImageState::view(const_cast<void*>(io->image), P);
     const size_t gb = vcr_align(sizeof(GradRec) * (size_t)N);
     const size_t sb = vcr_align(sizeof(float) * (size_t)N * (a.S > 0 ? a.S : 1));

@@ -57,6 +57,15 @@ __device__ __forceinline__ bool quad_touch(const float4 q0, const float4 q1, flo
     return qm <= tau + 0.05f + 2e-6f * (A * mx + C * my);
 }
 
+// Can the Gaussian reach alpha >= 1/255 at a pixel centre of tile (tx, ty)?  The same conservative conic-minimum test the
+// compositing kernels apply per 8x8 quad, on the tile's 16x16 pixel rectangle: a tile rejected here would have been culled
+// by all four of its quad waves, so the rendered image, the n_contrib semantics (positions are relative to the tile's own
+// list, forward and backward alike) and every gradient are unchanged -- only the lists, the tile sort and the chunk
+// culling get shorter.  Used by the projection kernel (exact per-tile rejection, preprocess.hip).
+__device__ __forceinline__ bool tile_touch(float4 q0, float4 q1, int tx, int ty) {
+    return quad_touch(q0, q1, (float)(tx * VCR_TILE), (float)(ty * VCR_TILE), (float)(VCR_TILE - 1), (float)(VCR_TILE - 1));
+}
+
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // Packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue two fp32 lanes-worth per instruction on CDNA3/4):

@@ -4,6 +4,7 @@
 // Reference call sites: gaussian_renderer/__init__.py:61-120 (inputs), :83-87 (colour rule),
 // tools/general_utils.py:98-130 (covariance from scale/rotation), scene/cameras.py:68-70 (matrices).
 #include "vcr_common.h"
+#include "composite_math.h"
 #include <stdlib.h>
 
 namespace {
@@ -199,11 +200,14 @@ __device__ __forceinline__ void stage_sh_in(const VcrRasterArgs& a, int base, in
 }
 
 // COLOUR = false: geometry only (the SH -> RGB evaluation runs as colour_fwd_kernel on VcrRasterArgs.colour_stream)
-// Returns the number of tiles the Gaussian touches (0 = culled).
+// Returns the number of tiles of the Gaussian's 3-sigma rectangle (0 = culled); `emit` receives the number of tile instances
+// it will emit: rectangles of up to VCR_RECT_MASK_TILES tiles are tested tile by tile (see vcr_common.h, `tile_touch`) and
+// carry the result as a bit mask in their 8-byte rectangle record, larger ones emit every tile.
 template <bool STAGE, bool COLOUR>
 __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const GeomState& g, int32_t* __restrict__ radii,
                                                    uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
-                                                   const float* s_sh, int i) {
+                                                   const float* s_sh, int i, uint32_t& emit) {
+    emit = 0;
     if (i >= a.N) return 0;
     radii[i] = 0;
     g.tiles[i] = 0;
@@ -293,14 +297,27 @@ __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const
     for (int k = 0; k < a.S; ++k) g.sem[(size_t)i * a.S + k] = a.semantics_precomp[(size_t)i * a.S + k];
     if (COLOUR) g.clamped[i] = clampbits;
     g.tiles[i] = (uint32_t)ntiles;
-    g.rect[i] = make_uint2((uint32_t)xmin | ((uint32_t)ymin << 16), (uint32_t)(xmax - xmin) | ((uint32_t)(ymax - ymin) << 16));
+    const int rw = xmax - xmin, rh = ymax - ymin;
+    if (ntiles <= VCR_RECT_MASK_TILES) {
+        const float4 q0 = make_float4(rec.px, rec.py, rec.z, rec.opacity), q1 = make_float4(rec.ca, rec.cb, rec.cc, rec.plane);
+        uint32_t mask = 0;
+        for (int k = 0, ty = ymin; ty < ymax; ++ty)
+            for (int tx = xmin; tx < xmax; ++tx, ++k)
+                if (tile_touch(q0, q1, tx, ty)) mask |= 1u << k;
+        emit = (uint32_t)__popc(mask);
+        g.rect[i] = make_uint2(VCR_RECT_MASKED | (uint32_t)xmin | ((uint32_t)ymin << 10) | ((uint32_t)(rw - 1) << 20) |
+                               ((uint32_t)(rh - 1) << 25), mask);
+    } else {
+        emit = (uint32_t)ntiles;
+        g.rect[i] = make_uint2((uint32_t)xmin | ((uint32_t)ymin << 10), (uint32_t)rw | ((uint32_t)rh << 16));
+    }
     radii[i] = (int32_t)rad;
     if (depth_key) depth_key[i] = __float_as_uint(pr.t[2]);
     return (uint32_t)ntiles;
 }
 
-// vis_slots (optional): 2 x VCR_VIS_SLOTS counters, [visible Gaussians | tile instances], one pair of atomics per block
-// spread over many addresses (same-address L2 atomics serialise at ~200 ns each)
+// vis_slots (optional): 3 x VCR_VIS_SLOTS counters, [visible Gaussians | tile instances of the 3-sigma rectangles | tile
+// instances emitted], three atomics per block spread over many addresses (same-address L2 atomics serialise at ~200 ns each)
 template <bool STAGE, bool COLOUR>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, GeomState g, int32_t* __restrict__ radii,
                                                              uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
@@ -311,14 +328,15 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
         stage_sh_in(a, base, min(256, a.N - base), s_sh);
         __syncthreads();
     }
-    const uint32_t nt = preprocess_one<STAGE, COLOUR>(a, g, radii, depth_key, ids, s_sh, blockIdx.x * 256 + threadIdx.x);
+    uint32_t em;
+    const uint32_t nt = preprocess_one<STAGE, COLOUR>(a, g, radii, depth_key, ids, s_sh, blockIdx.x * 256 + threadIdx.x, em);
     if (vis_slots) {
-        __shared__ uint32_t s_cnt[2][4];
+        __shared__ uint32_t s_cnt[3][4];
         uint32_t c = nt != 0 ? 1u : 0u, r = nt;
-        for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); r += __shfl_xor(r, o); }
-        if ((threadIdx.x & 63) == 0) { s_cnt[0][threadIdx.x >> 6] = c; s_cnt[1][threadIdx.x >> 6] = r; }
+        for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); r += __shfl_xor(r, o); em += __shfl_xor(em, o); }
+        if ((threadIdx.x & 63) == 0) { s_cnt[0][threadIdx.x >> 6] = c; s_cnt[1][threadIdx.x >> 6] = r; s_cnt[2][threadIdx.x >> 6] = em; }
         __syncthreads();
-        if (threadIdx.x < 2) {
+        if (threadIdx.x < 3) {
             const uint32_t t = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
             if (t) atomicAdd(vis_slots + threadIdx.x * VCR_VIS_SLOTS + blockIdx.x % VCR_VIS_SLOTS, t);
         }

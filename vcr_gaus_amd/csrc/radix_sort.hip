@@ -1,127 +1,157 @@
 // Stable LSD radix sort of (u32 key, u32 value) pairs, sized for the rasterizer's two sorts (N ~ 1e6 depth keys,
-// R ~ 3e6 tile keys of <= 14 bits) -- problem sizes where a device-wide library sort is launch- and latency-bound
-// (rocPRIM onesweep here: 2 memsets + 1 kernel per 8-bit pass, ~40 us per pass at N = 1e6, plus a histogram kernel).
+// R' ~ 2e6 tile keys of <= 14 bits) -- problem sizes where a device-wide sort is bound by its dependent launches and
+// by how much of the chip every launch reaches, not by bytes.
 //
-// Two kernels per 8-bit pass (three above 4.2 M items, see rs_hist_scan_kernel), no look-back chains, no memsets:
-//   upsweep   : every block counts the digits of its slice into LDS, writes one row of hist[block][digit] and adds
-//               the row to totals[pass][digit] (256 atomics per block);
-//   downsweep : every block sums the rows of the blocks before it (coalesced 1 KB rows out of L2), scans the 256
-//               totals, ranks its slice stably (wave w owns consecutive items and walks them in chunks of 64; peers
-//               of a digit inside a chunk are found with one ballot per digit bit) and scatters.
-// `totals` (VCR_SORT_TOTALS_WORDS words) must be zero on entry; the caller zeroes it together with its other counters.
+// Round-3 form (round 2: 8-bit digits, 8192 items per 1024-thread workgroup = 123 workgroups for 1 M keys on 256 CUs):
+//   * WIDE DIGITS: up to 11 bits per pass, so the 32-bit depth keys take 3 passes instead of 4 and the <= 14 tile bits
+//     take two passes of <= 7 bits;
+//   * 4096 items per workgroup, 4 per lane (16 waves, short dependent chains per wave): 245 workgroups at 1 M keys;
+//   * three short kernels per pass, none of them with work quadratic in the block count:
+//       upsweep   : digit histogram of every 4096-item slice in LDS -> one row of hist[block][digit];
+//       scan      : exclusive scan over the blocks of every digit column, in place, plus the digit totals;
+//       downsweep : every block ranks its slice stably (wave w owns 256 consecutive items and walks them in chunks of
+//                   64; the peers of a digit inside a chunk come from one ballot per digit bit; per-wave running counts
+//                   are 16-bit, 2 x RADIX bytes per wave), reorders it through LDS so that the global writes are runs,
+//                   and scatters;
+//   * the element count may also live in DEVICE memory (`n_dev`, <= the host's n): grids are then sized for the host's
+//     upper bound and surplus workgroups return at once.
+// Nothing has to be zeroed by the caller.
 #include "vcr_common.h"
 #include <stdlib.h>
 
 namespace {
 
-constexpr int RS_BLOCK = 1024;                // threads
-constexpr int RS_WAVES = RS_BLOCK / 64;
-#ifndef VCR_RS_CHUNKS
-#define VCR_RS_CHUNKS 8
-#endif
-constexpr int RS_CHUNKS = VCR_RS_CHUNKS;      // 64-item chunks per wave
-constexpr int RS_IPB = RS_BLOCK * RS_CHUNKS;  // items per block
-constexpr int RS_RADIX = 256;
-#ifndef VCR_RS_INLINE_PREFIX_MAX
-#define VCR_RS_INLINE_PREFIX_MAX 512
-#endif
-constexpr int RS_INLINE_PREFIX_MAX = VCR_RS_INLINE_PREFIX_MAX;   // blocks (x 8192 items) up to which the downsweep sums earlier rows itself
+constexpr int RS_IPB = 4096;                              // items per workgroup (the row granularity of hist[block][digit])
+// Workgroup shapes (threads x 64-item chunks per wave = RS_IPB).  The depth sort runs BESIDE the persistent SH-update kernel
+// of the second stream (256-thread workgroups, 50 KB of LDS and 124 VGPRs each, up to two per CU), so its
+// kernels must fit into what that leaves on a CU -- 60 KB of LDS, 256 VGPRs per SIMD lane -- or every pass waits for the
+// whole SH update: the 11-bit downsweep therefore uses 512 threads x 8 chunks (56 KB; 16-bit per-wave counts are what
+// make 2048 digits fit at all), the <= 8-bit passes 1024 threads x 4 chunks (25 KB).
+template <int BITS> struct RsShape { static constexpr int THREADS = BITS > 8 ? 512 : 1024; };
 
-__global__ void __launch_bounds__(RS_BLOCK) rs_upsweep_kernel(int64_t n, const uint32_t* __restrict__ keys, int shift,
-                                                             uint32_t mask, uint32_t* __restrict__ hist,
-                                                             uint32_t* __restrict__ totals) {
-    __shared__ uint32_t cnt[RS_RADIX];
-    const int t = threadIdx.x;
-    if (t < RS_RADIX) cnt[t] = 0;
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * RS_IPB;
-#pragma unroll
-    for (int c = 0; c < RS_CHUNKS; ++c) {
-        const int64_t i = base + (int64_t)c * RS_BLOCK + t;   // (any order: counting only)
-        if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & mask], 1u);
-    }
-    __syncthreads();
-    if (t < RS_RADIX) {
-        const uint32_t c = cnt[t];
-        hist[(size_t)blockIdx.x * RS_RADIX + t] = c;
-        if (c) atomicAdd(totals + t, c);
-    }
+__device__ __forceinline__ int64_t rs_count(int64_t n_host, const uint32_t* __restrict__ n_dev) {
+    return n_dev ? (int64_t)*n_dev : n_host;
 }
 
-// Exclusive scan over the blocks of every digit's counts, in place (hist[b][d] -> number of items with digit d in the
-// blocks before b): one workgroup per digit.  Used when the block count is large (> RS_INLINE_PREFIX_MAX blocks); below
-// that the downsweep sums the rows of the earlier blocks itself, which spares a launch but is quadratic in the block count.
-__global__ void __launch_bounds__(256) rs_hist_scan_kernel(int nblk, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t s_part[256];
-    const int d = blockIdx.x, t = threadIdx.x;
-    const int per = (nblk + 255) / 256, b0 = t * per, b1 = min(nblk, b0 + per);
-    uint32_t sum = 0;
-    for (int b = b0; b < b1; ++b) sum += hist[(size_t)b * RS_RADIX + d];
-    s_part[t] = sum;
+template <int BITS>
+__global__ void __launch_bounds__(1024) rs_upsweep_kernel(int64_t n_host, const uint32_t* __restrict__ n_dev,
+                                                               const uint32_t* __restrict__ keys, int shift, uint32_t mask,
+                                                               uint32_t* __restrict__ hist) {
+    constexpr int RADIX = 1 << BITS;
+    const int64_t n = rs_count(n_host, n_dev);
+    const int64_t base = (int64_t)blockIdx.x * RS_IPB;
+    if (base >= n) return;
+    __shared__ uint32_t cnt[RADIX];
+    const int t = threadIdx.x;
+    constexpr int UT = 1024, UC = RS_IPB / UT;
+    for (int i = t; i < RADIX; i += UT) cnt[i] = 0;
     __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {                    // Hillis-Steele over the 256 partials
-        const uint32_t v = t >= o ? s_part[t - o] : 0u;
-        __syncthreads();
-        s_part[t] += v;
-        __syncthreads();
+    uint32_t k[UC];
+#pragma unroll
+    for (int c = 0; c < UC; ++c) {                         // (any order: counting only) -- all loads first
+        const int64_t i = base + (int64_t)c * UT + t;
+        k[c] = i < n ? keys[i] : 0u;
     }
-    uint32_t run = s_part[t] - sum;
+#pragma unroll
+    for (int c = 0; c < UC; ++c)
+        if (base + (int64_t)c * UT + t < n) atomicAdd(&cnt[(k[c] >> shift) & mask], 1u);
+    __syncthreads();
+    for (int i = t; i < RADIX; i += UT) hist[(size_t)blockIdx.x * RADIX + i] = cnt[i];
+}
+
+// hist[b][d] -> number of items with digit d in the blocks before b (exclusive scan down every digit column, in place);
+// totals[d] = the column sum.  One workgroup per 16 digit columns (rows are read in 64-byte pieces), 64 row groups.
+template <int BITS>
+__global__ void __launch_bounds__(1024) rs_scan_kernel(int64_t n_host, const uint32_t* __restrict__ n_dev,
+                                                       uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
+    constexpr int RADIX = 1 << BITS;
+    const int64_t n = rs_count(n_host, n_dev);
+    const int nblk = (int)((n + RS_IPB - 1) / RS_IPB);
+    __shared__ uint32_t part[64][17];
+    const int dd = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int d = blockIdx.x * 16 + dd;
+    const int per = (nblk + 63) / 64, b0 = rg * per, b1 = min(nblk, b0 + per);
+    uint32_t sum = 0;
+    for (int b = b0; b < b1; ++b) sum += hist[(size_t)b * RADIX + d];
+    part[rg][dd] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int g = 0; g < rg; ++g) run += part[g][dd];
+    if (rg == 63) totals[d] = run + sum;
     for (int b = b0; b < b1; ++b) {
-        const uint32_t c = hist[(size_t)b * RS_RADIX + d];
-        hist[(size_t)b * RS_RADIX + d] = run;
+        const size_t at = (size_t)b * RADIX + d;
+        const uint32_t c = hist[at];
+        hist[at] = run;
         run += c;
     }
 }
 
-template <bool IOTA, bool PRESCAN>
-__global__ void __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) rs_downsweep_kernel(int64_t n, const uint32_t* __restrict__ keys_in,
-                                                               const uint32_t* __restrict__ vals_in, int shift, int nbits,
-                                                               const uint32_t* __restrict__ hist,
-                                                               const uint32_t* __restrict__ totals,
-                                                               uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
-    __shared__ uint32_t cnt[RS_WAVES][RS_RADIX];          // running digit counts of each wave's own item stream
-    __shared__ uint32_t before_blk[4][RS_RADIX];          // partial sums over the rows of the earlier blocks
-    __shared__ uint32_t dig_base[RS_RADIX];               // exclusive scan of the digit totals
-    __shared__ uint32_t lstart[RS_RADIX];                 // block-local start of every digit
-    // Half of the slice in sorted order (32 KB at 8 chunks): the reorder runs in two rounds so that the workgroup needs
-    // 54 KB of LDS, not 86 KB -- with 86 KB it could not become resident on a CU that holds the two persistent 50 KB
-    // workgroups of the side stream's SH-update kernel, and every scatter pass waited for that whole kernel
-    __shared__ uint2 items[RS_IPB / 2];
+// Exclusive scan over the whole block of the per-thread sums `sum` (each thread holds PER consecutive values).
+// `wsum`: one word of LDS per wave.  Returns the exclusive prefix of this thread's first value.
+__device__ __forceinline__ uint32_t block_exclusive(uint32_t sum, uint32_t* wsum) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    uint32_t inc = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, o);
+        if (lane >= o) inc += v;
+    }
+    __syncthreads();                                        // (wsum may still be read from a previous call)
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int k = 0; k < w; ++k) base += wsum[k];
+    return base + inc - sum;
+}
+
+template <int BITS, bool IOTA>
+__global__ void __launch_bounds__(RsShape<BITS>::THREADS) rs_downsweep_kernel(int64_t n_host, const uint32_t* __restrict__ n_dev,
+                                                                 const uint32_t* __restrict__ keys_in,
+                                                                 const uint32_t* __restrict__ vals_in, int shift, int nbits,
+                                                                 const uint32_t* __restrict__ hist,
+                                                                 const uint32_t* __restrict__ totals,
+                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    constexpr int RADIX = 1 << BITS;
+    constexpr int THREADS = RsShape<BITS>::THREADS, WAVES = THREADS / 64, CHUNKS = RS_IPB / THREADS;
+    constexpr int PER = RADIX > THREADS ? RADIX / THREADS : 1;             // digits per thread in the block-wide scans
+    static_assert(64 * CHUNKS <= 65535, "per-wave digit counts are 16-bit");
+    const int64_t n = rs_count(n_host, n_dev);
+    const int64_t bbase = (int64_t)blockIdx.x * RS_IPB;
+    if (bbase >= n) return;
+    __shared__ uint16_t cnt[WAVES][RADIX];                 // running digit counts of each wave's own item stream
+    __shared__ uint32_t gbase[RADIX];                       // global position of the block's first item of every digit, minus its local start
+    __shared__ uint32_t wsum[WAVES];
+    __shared__ uint2 items[RS_IPB / 2];                     // half of the slice in sorted order (two reorder rounds)
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint32_t mask = (1u << nbits) - 1u;
-    for (int i = t; i < RS_WAVES * RS_RADIX; i += RS_BLOCK) (&cnt[0][0])[i] = 0;
-    {   // rows of the blocks before this one: 4 thread groups x 256 digits, independent coalesced loads
-        const int d = t & (RS_RADIX - 1), grp = t >> 8;
-        uint32_t s = 0;
-        if (PRESCAN) { if (grp == 0) s = hist[(size_t)blockIdx.x * RS_RADIX + d]; }
-        else for (int b = grp; b < (int)blockIdx.x; b += 4) s += hist[(size_t)b * RS_RADIX + d];
-        before_blk[grp][d] = s;
-        if (t < RS_RADIX) dig_base[t] = totals[t];
+    {
+        uint32_t* z = reinterpret_cast<uint32_t*>(&cnt[0][0]);
+        for (int i = t; i < WAVES * RADIX / 2; i += THREADS) z[i] = 0;
     }
-    __syncthreads();
-    if (t < 64) {                                          // exclusive scan of 256 totals by one wave, 4 per lane
-        const uint32_t a0 = dig_base[4 * t], a1 = dig_base[4 * t + 1], a2 = dig_base[4 * t + 2], a3 = dig_base[4 * t + 3];
-        const uint32_t sum = a0 + a1 + a2 + a3;
-        uint32_t inc = sum;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t v = (uint32_t)__shfl_up((int)inc, o);
-            if (t >= o) inc += v;
-        }
-        const uint32_t ex = inc - sum;
-        dig_base[4 * t] = ex; dig_base[4 * t + 1] = ex + a0; dig_base[4 * t + 2] = ex + a0 + a1; dig_base[4 * t + 3] = ex + a0 + a1 + a2;
-    }
-    const int64_t wbase = (int64_t)blockIdx.x * RS_IPB + (int64_t)w * (64 * RS_CHUNKS);
-    uint32_t key[RS_CHUNKS], val[RS_CHUNKS], rank[RS_CHUNKS];
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    // loads first: this block's slice, its row of block prefixes and the digit totals
+    const int64_t wbase = bbase + (int64_t)w * (64 * CHUNKS);
+    uint32_t key[CHUNKS], val[CHUNKS], rank[CHUNKS];
 #pragma unroll
-    for (int c = 0; c < RS_CHUNKS; ++c) {
+    for (int c = 0; c < CHUNKS; ++c) {
         const int64_t i = wbase + c * 64 + lane;
         const bool valid = i < n;
         key[c] = valid ? keys_in[i] : 0xFFFFFFFFu;
         val[c] = valid ? (IOTA ? (uint32_t)i : vals_in[i]) : 0u;
     }
+    uint32_t tot[PER], pre[PER];
+    uint32_t tsum = 0;
 #pragma unroll
-    for (int c = 0; c < RS_CHUNKS; ++c) {
+    for (int k = 0; k < PER; ++k) {
+        const int d = PER * t + k;
+        const bool in = d < RADIX;
+        tot[k] = in ? totals[d] : 0u;
+        pre[k] = in ? hist[(size_t)blockIdx.x * RADIX + d] : 0u;
+        tsum += tot[k];
+    }
+    // exclusive scan of the digit totals -> start of every digit in the output
+    const uint32_t dstart = block_exclusive(tsum, wsum);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
         const bool valid = wbase + c * 64 + lane < n;
         const uint32_t d = (key[c] >> shift) & mask;
         unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
@@ -132,62 +162,57 @@ __global__ void __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(8
         }
         const uint32_t before = cnt[w][d];                 // every peer reads the count before the leader bumps it
         __builtin_amdgcn_wave_barrier();
-        if (valid && (peers & lt) == 0) cnt[w][d] = before + (uint32_t)__popcll(peers);
+        if (valid && (peers & lt) == 0) cnt[w][d] = (uint16_t)(before + (uint32_t)__popcll(peers));
         __builtin_amdgcn_wave_barrier();
         rank[c] = before + (uint32_t)__popcll(peers & lt);
     }
     __syncthreads();
-    if (t < 64) {                                          // block-local start of every digit (exclusive scan, 4 per lane)
-        uint32_t a[4];
+    // block-local start of every digit; per-wave bases (cnt[w][d] <- items of digit d in the waves before w)
+    uint32_t cd[PER];
+    uint32_t csum = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t c = 0;
+    for (int k = 0; k < PER; ++k) {
+        const int d = PER * t + k;
+        uint32_t c = 0;
+        if (d < RADIX) {
 #pragma unroll
-            for (int ww = 0; ww < RS_WAVES; ++ww) c += cnt[ww][4 * t + k];
-            a[k] = c;
+            for (int ww = 0; ww < WAVES; ++ww) { const uint32_t x = cnt[ww][d]; cnt[ww][d] = (uint16_t)c; c += x; }
         }
-        const uint32_t sum = a[0] + a[1] + a[2] + a[3];
-        uint32_t inc = sum;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t v = (uint32_t)__shfl_up((int)inc, o);
-            if (t >= o) inc += v;
-        }
-        const uint32_t ex = inc - sum;
-        lstart[4 * t] = ex; lstart[4 * t + 1] = ex + a[0]; lstart[4 * t + 2] = ex + a[0] + a[1]; lstart[4 * t + 3] = ex + a[0] + a[1] + a[2];
+        cd[k] = c;
+        csum += c;
     }
-    __syncthreads();
-    if (t < RS_RADIX) {                                    // per-wave local bases; global minus local start of the digit
-        const uint32_t ls = lstart[t];
-        uint32_t run = ls;
+    uint32_t ls = block_exclusive(csum, wsum), ds = dstart;
 #pragma unroll
-        for (int ww = 0; ww < RS_WAVES; ++ww) {
-            const uint32_t c = cnt[ww][t];
-            cnt[ww][t] = run;
-            run += c;
+    for (int k = 0; k < PER; ++k) {
+        const int d = PER * t + k;
+        if (d < RADIX) {
+#pragma unroll
+            for (int ww = 0; ww < WAVES; ++ww) cnt[ww][d] = (uint16_t)(cnt[ww][d] + ls);     // (< RS_IPB = 4096: fits)
+            gbase[d] = ds + pre[k] - ls;
         }
-        dig_base[t] = dig_base[t] + before_blk[0][t] + before_blk[1][t] + before_blk[2][t] + before_blk[3][t] - ls;
+        ls += cd[k]; ds += tot[k];
     }
     __syncthreads();
     // reorder through LDS so that the global writes of a wave are runs of consecutive addresses, not 64 scattered words
-    const int64_t left = n - (int64_t)blockIdx.x * RS_IPB;
+    const int64_t left = n - bbase;
     const int nvalid = left < RS_IPB ? (int)left : RS_IPB;
 #pragma unroll
-    for (int c = 0; c < RS_CHUNKS; ++c) rank[c] += cnt[w][(key[c] >> shift) & mask];     // position inside the sorted slice
+    for (int c = 0; c < CHUNKS; ++c) rank[c] += cnt[w][(key[c] >> shift) & mask];     // position inside the sorted slice
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const uint32_t lo = (uint32_t)half * (RS_IPB / 2);
         if (half) __syncthreads();                          // round 0 has drained `items`
 #pragma unroll
-        for (int c = 0; c < RS_CHUNKS; ++c) {
+        for (int c = 0; c < CHUNKS; ++c) {
             if (wbase + c * 64 + lane < n && rank[c] - lo < (uint32_t)(RS_IPB / 2)) items[rank[c] - lo] = make_uint2(key[c], val[c]);
         }
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < RS_CHUNKS / 2; ++c) {
-            const int j = (int)lo + c * RS_BLOCK + t;
+        for (int c = 0; c < CHUNKS / 2; ++c) {
+            const int j = (int)lo + c * THREADS + t;
             if (j < nvalid) {
                 const uint2 kv = items[j - (int)lo];
-                const uint32_t dst = (uint32_t)j + dig_base[(kv.x >> shift) & mask];
+                const uint32_t dst = (uint32_t)j + gbase[(kv.x >> shift) & mask];
                 keys_out[dst] = kv.x;
                 vals_out[dst] = kv.y;
             }
@@ -204,7 +229,8 @@ __global__ void __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(8
 // compositing forward 221 -> 160 us, backward 467 -> 352 us) but costs 1.9x their shading work, which only pays while
 // the SIMDs are not full (1 M Gaussians / 1080p: none).  meta[0] = S, meta[1] = non-empty tiles, meta[2] = longest list.
 __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order,
-                                                        uint32_t* __restrict__ meta, int split_slots, int lpt, int snake) {
+                                                        uint32_t* __restrict__ meta, unsigned long long instances, int split_slots,
+                                                        int lpt, int snake) {
     constexpr int BINS = 2048, SH = 2;                 // classes of 4 list entries; lists >= 8188 share the first class
     __shared__ uint32_t hist[BINS];
     __shared__ uint32_t wsum[16];
@@ -214,15 +240,18 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2* __
         if (t < VCR_BIN_META_WORDS) meta[t] = 0u;
         return;
     }
-    __shared__ uint32_t s_ne, s_max;
+    __shared__ uint32_t s_ne, s_max, s_empty;
     hist[t] = 0; hist[t + 1024] = 0;
     if (t == 0) { s_ne = 0; s_max = 0; }
     __syncthreads();
+    // Empty tiles (84 % of the 1080p frame of the metric scene) do not go through the histogram: thousands of LDS atomics
+    // on ONE word serialise (this kernel measured 14.6 us for 8160 tiles); they are placed behind the non-empty tiles
+    // with one atomic per wave instead.
     uint32_t ne = 0, mx = 0;
     for (int i = t; i < T; i += 1024) {
         const uint32_t len = ranges[i].y - ranges[i].x;
         ne += len > 0; mx = max(mx, len);
-        atomicAdd(&hist[BINS - 1 - min(len >> SH, (uint32_t)(BINS - 1))], 1u);   // bin 0 = longest
+        if (len > 0) atomicAdd(&hist[BINS - 1 - min(len >> SH, (uint32_t)(BINS - 1))], 1u);   // bin 0 = longest
     }
     for (int o = 32; o > 0; o >>= 1) { ne += (uint32_t)__shfl_xor((int)ne, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
     if (lane == 0) { atomicAdd(&s_ne, ne); atomicMax(&s_max, mx); }
@@ -231,7 +260,12 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2* __
         const int idle = split_slots - (int)s_ne;
         int S = idle <= 0 ? 0 : min(min(idle / 3, (int)s_ne), VCR_SPLIT_MAX);
         if (S < 16) S = 0;                               // (a handful of split items only shifts the launch order of the rest)
+        // ... and only when the launch is bound by its longest serial chain rather than by total work: longest list > 4x the
+        // list entries per workgroup slot (c2: 6400 against 590 -> split; 1 M / 1080p: 4500 against 1200 -> not: there the
+        // SIMDs stay full to the end and the 1.9x work of the split items costs more than their shorter chains return)
+        if ((unsigned long long)s_max * (unsigned)split_slots <= 4ull * instances) S = 0;
         meta[0] = (uint32_t)S; meta[1] = s_ne; meta[2] = s_max;
+        s_empty = s_ne;                                  // the empty tiles follow the non-empty ones in launch order
     }
     // exclusive scan of the 2048 classes: 2 per lane, wave scan, 16 wave totals
     const uint32_t h0 = hist[2 * t], h1 = hist[2 * t + 1];
@@ -247,8 +281,18 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2* __
     const uint32_t ex = base + inc - (h0 + h1);
     hist[2 * t] = ex; hist[2 * t + 1] = ex + h0;           // exclusive start of every class
     __syncthreads();
-    for (int i = t; i < T; i += 1024) {
-        const uint32_t r = atomicAdd(&hist[BINS - 1 - min((ranges[i].y - ranges[i].x) >> SH, (uint32_t)(BINS - 1))], 1u);
+    for (int i0 = 0; i0 < T; i0 += 1024) {
+        const int i = i0 + t;
+        const uint32_t len = i < T ? ranges[i].y - ranges[i].x : 1u;
+        const unsigned long long em = __builtin_amdgcn_ballot_w64(i < T && len == 0);
+        uint32_t ebase = 0;
+        if (em) {
+            if (lane == 0) ebase = atomicAdd(&s_empty, (uint32_t)__popcll(em));
+            ebase = (uint32_t)__builtin_amdgcn_readfirstlane((int)ebase);
+        }
+        if (i >= T) continue;
+        const uint32_t r = len == 0 ? ebase + (uint32_t)__popcll(em & ((1ull << lane) - 1ull))
+                                    : atomicAdd(&hist[BINS - 1 - min(len >> SH, (uint32_t)(BINS - 1))], 1u);
         uint32_t pos = r;                                   // rank in launch order
         if (snake) {
             const int band = (int)(r >> 8), j = (int)(r & 255);
@@ -259,47 +303,68 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2* __
     }
 }
 
-}  // namespace
-
-size_t vcr_sort_scratch_bytes(int64_t n) {
-    const int64_t nblk = (n + RS_IPB - 1) / RS_IPB;
-    return vcr_align(sizeof(uint32_t) * (size_t)(RS_RADIX * (nblk > 0 ? nblk : 1)));
+template <int BITS>
+void rs_pass(int64_t n, const uint32_t* n_dev, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int shift,
+             int nbits, uint32_t* hist, uint32_t* totals, hipStream_t st) {
+    constexpr int RADIX = 1 << BITS;
+    const int nblk = (int)((n + RS_IPB - 1) / RS_IPB);
+    constexpr int DT = RsShape<BITS>::THREADS;
+    hipLaunchKernelGGL((rs_upsweep_kernel<BITS>), dim3(nblk), dim3(1024), 0, st, n, n_dev, kin, shift, (1u << nbits) - 1u, hist);
+    hipLaunchKernelGGL((rs_scan_kernel<BITS>), dim3(RADIX / 16), dim3(1024), 0, st, n, n_dev, hist, totals);
+    if (vin) hipLaunchKernelGGL((rs_downsweep_kernel<BITS, false>), dim3(nblk), dim3(DT), 0, st, n, n_dev, kin, vin, shift, nbits,
+                                hist, totals, kout, vout);
+    else hipLaunchKernelGGL((rs_downsweep_kernel<BITS, true>), dim3(nblk), dim3(DT), 0, st, n, n_dev, kin, vin, shift, nbits,
+                            hist, totals, kout, vout);
 }
 
-// Sorts bits [begin_bit, end_bit) of the keys (at most 4 passes of 8 bits).  vals_in == nullptr means vals = 0..n-1.
-// The result lands in (keys_out, vals_out); (keys_tmp, vals_tmp) is a second buffer pair of n words each; the inputs are
-// left untouched.  `hist` holds vcr_sort_scratch_bytes(n); `totals` is VCR_SORT_TOTALS_WORDS zero-initialised words.
+}  // namespace
+
+// hist[block][digit] of the widest pass
+size_t vcr_sort_scratch_bytes(int64_t n) {
+    const int64_t nblk = (n + RS_IPB - 1) / RS_IPB;
+    return vcr_align(sizeof(uint32_t) * (size_t)(2048 * (nblk > 0 ? nblk : 1)));
+}
+
+// Pass plan for `bits` key bits: digits of at most 8 bits while two passes suffice (small histograms, more resident
+// workgroups), else of at most 11.  -> number of passes, bits of every pass in `out`.
+static int rs_plan(int bits, int out[4]) {
+    static const int max_digit = [] { const char* e = getenv("VCR_SORT_DIGIT_BITS"); const int v = e ? atoi(e) : 11; return v < 8 ? 8 : (v > 11 ? 11 : v); }();
+    int passes = bits <= 8 ? 1 : (bits <= 16 ? 2 : (bits <= 2 * max_digit ? 2 : (bits <= 3 * max_digit ? 3 : 4)));
+    for (int p = 0, left = bits; p < passes; ++p) {
+        out[p] = (left + (passes - p) - 1) / (passes - p);
+        left -= out[p];
+    }
+    return passes;
+}
+
+// Sorts bits [begin_bit, end_bit) of the keys.  vals_in == nullptr means vals = 0..n-1.  The result lands in
+// (keys_out, vals_out); (keys_tmp, vals_tmp) is a second buffer pair of n words each; the inputs are left untouched.
+// `hist` holds vcr_sort_scratch_bytes(n); `totals`: VCR_SORT_TOTALS_WORDS words (need not be zeroed).  `n` is the host's
+// (upper bound of the) element count; `n_dev`, when not NULL, points to the actual count in device memory (<= n).
 int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_tmp, uint32_t* vals_tmp,
                    uint32_t* keys_out, uint32_t* vals_out, int begin_bit, int end_bit, uint32_t* hist, uint32_t* totals,
-                   hipStream_t st) {
+                   hipStream_t st, const uint32_t* n_dev) {
     if (n <= 0) return 0;
-    const int nblk = (int)((n + RS_IPB - 1) / RS_IPB);
-    const int passes = (end_bit - begin_bit + 7) / 8;
-    if (passes > VCR_SORT_TOTALS_WORDS / RS_RADIX) { vcr_set_error("vcr_sort_pairs: more than 4 passes"); return 1; }
+    int bits[4];
+    const int passes = rs_plan(end_bit - begin_bit, bits);
     const uint32_t* kin = keys_in;
     const uint32_t* vin = vals_in;
+    int shift = begin_bit;
     for (int p = 0; p < passes; ++p) {
-        const int shift = begin_bit + 8 * p;
-        const int nbits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
         const bool to_out = ((passes - 1 - p) & 1) == 0;             // the last pass writes (keys_out, vals_out)
         uint32_t* kout = to_out ? keys_out : keys_tmp;
         uint32_t* vout = to_out ? vals_out : vals_tmp;
-        uint32_t* tot = totals + p * RS_RADIX;
-        hipLaunchKernelGGL(rs_upsweep_kernel, dim3(nblk), dim3(RS_BLOCK), 0, st, n, kin, shift, (1u << nbits) - 1u, hist, tot);
-        const bool prescan = nblk > RS_INLINE_PREFIX_MAX;
-        if (prescan) hipLaunchKernelGGL(rs_hist_scan_kernel, dim3(RS_RADIX), dim3(256), 0, st, nblk, hist);
-#define VCR_DOWN(IOTA, PRE) hipLaunchKernelGGL((rs_downsweep_kernel<IOTA, PRE>), dim3(nblk), dim3(RS_BLOCK), 0, st, n, kin, vin, shift, \
-                                               nbits, hist, tot, kout, vout)
-        if (vin) { if (prescan) VCR_DOWN(false, true); else VCR_DOWN(false, false); }
-        else { if (prescan) VCR_DOWN(true, true); else VCR_DOWN(true, false); }
-#undef VCR_DOWN
+        if (bits[p] <= 8) rs_pass<8>(n, n_dev, kin, vin, kout, vout, shift, bits[p], hist, totals, st);
+        else rs_pass<11>(n, n_dev, kin, vin, kout, vout, shift, bits[p], hist, totals, st);
+        shift += bits[p];
         kin = kout; vin = vout;
     }
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, uint32_t* meta, bool lpt, bool snake, hipStream_t st) {
+int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, uint32_t* meta, int64_t instances, bool lpt, bool snake,
+                          hipStream_t st) {
     // workgroup slots of the compositing kernels on the chip: 5 resident 256-thread workgroups per CU (VCR_SPLIT_SLOTS overrides;
     // 0 disables the split work items)
     static const int slots = [] {
@@ -311,7 +376,8 @@ int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, uint32_t*
             cus = prop.multiProcessorCount;
         return 5 * cus;
     }();
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, T, ranges, order, meta, slots, lpt ? 1 : 0, snake ? 1 : 0);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, T, ranges, order, meta, (unsigned long long)instances, slots,
+                       lpt ? 1 : 0, snake ? 1 : 0);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -56,8 +56,10 @@ struct GeomState {
     float* sem;          // [N,S]
     uint32_t* tiles;     // [N] tiles touched (0 = culled)
     uint8_t* clamped;    // [N] bit c set when colour channel c was clamped at 0
-    uint2* rect;         // [N] tile rectangle {xmin | ymin << 16, width | height << 16}: ONE 8-byte gather per Gaussian
-                         //     for the instance emission instead of three (tiles, record, radius)
+    uint2* rect;         // [N] tile rectangle, ONE 8-byte gather per Gaussian for the instance emission.  Rectangles of up to
+                         //     VCR_RECT_MASK_TILES tiles: {MASKED | xmin | ymin << 10 | (w-1) << 20 | (h-1) << 25, bit k set when
+                         //     tile (xmin + k % w, ymin + k / w) can be reached (exact rejection, tile_touch)}; larger ones:
+                         //     {xmin | ymin << 10, w | h << 16}, every tile emitted; {0, 0} = culled
     static size_t bytes(int N, int S) {
         return vcr_align(sizeof(GeomRec) * (size_t)N) + vcr_align(sizeof(float) * (size_t)N * (S > 0 ? S : 1)) +
                vcr_align(sizeof(uint32_t) * (size_t)N) + vcr_align((size_t)N) + vcr_align(sizeof(uint2) * (size_t)N);
@@ -74,25 +76,29 @@ struct GeomState {
     }
 };
 
+#define VCR_RECT_MASK_TILES 32
+#define VCR_RECT_MASKED 0x80000000u
+#define VCR_MAX_IMAGE_DIM 16384          // tile coordinates have 10 bits in the rectangle record
+
 #define VCR_BIN_META_WORDS 16
 #define VCR_SPLIT_MAX 256          // at most this many tiles are split (one band of the launch order)
 struct BinState {
-    uint32_t* point_list;  // [R] Gaussian ids, (tile, depth, id)-ordered
     uint2* ranges;         // [T] per-tile [begin,end)
     uint32_t* tile_order;  // [T] tile ids, longest list first (block scheduling order)
     uint32_t* meta;        // [VCR_BIN_META_WORDS] written by tile_order: [0] number S of heaviest tiles launched as split work
                            //     items (composite.hip), [1] non-empty tiles, [2] longest tile list
+    uint32_t* point_list;  // [R'] Gaussian ids, (tile, depth, id)-ordered; LAST, so that the views above do not depend on R'
     static size_t bytes(int64_t R, int T) {
-        return vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1)) + vcr_align(sizeof(uint2) * (size_t)T) +
-               vcr_align(sizeof(uint32_t) * (size_t)T) + vcr_align(sizeof(uint32_t) * VCR_BIN_META_WORDS);
+        return vcr_align(sizeof(uint2) * (size_t)T) + vcr_align(sizeof(uint32_t) * (size_t)T) +
+               vcr_align(sizeof(uint32_t) * VCR_BIN_META_WORDS) + vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1));
     }
-    static BinState view(void* p, int64_t R, int T) {
+    static BinState view(void* p, int T) {
         BinState b;
         char* c = (char*)p;
-        b.point_list = (uint32_t*)c;  c += vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1));
         b.ranges = (uint2*)c;         c += vcr_align(sizeof(uint2) * (size_t)T);
         b.tile_order = (uint32_t*)c;  c += vcr_align(sizeof(uint32_t) * (size_t)T);
-        b.meta = (uint32_t*)c;
+        b.meta = (uint32_t*)c;        c += vcr_align(sizeof(uint32_t) * VCR_BIN_META_WORDS);
+        b.point_list = (uint32_t*)c;
         return b;
     }
 };
@@ -142,7 +148,7 @@ void vcr_set_error(const char* fmt, ...);
     } while (0)
 
 // ---- stage launchers (defined in the .hip files) ----------------------------------------------
-#define VCR_VIS_SLOTS 1024                    // counter slots for visible Gaussians / tile instances
+#define VCR_VIS_SLOTS 1024                    // counter slots for visible Gaussians / 3-sigma tile instances / emitted tile instances
 int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key,
                           uint32_t* ids, uint32_t* vis_slots, bool colour, hipStream_t st);
 int vcr_launch_depth_keys(const VcrRasterArgs& a, uint32_t* depth_key, hipStream_t st);
@@ -157,17 +163,18 @@ size_t vcr_duplicate_status_bytes(int N);
 int vcr_depth_sort(int N, const uint32_t* depth_key, uint32_t* tmp_k, uint32_t* tmp_v, uint32_t* key_sorted,
                    uint32_t* ids_sorted, uint32_t* totals, void* temp, hipStream_t st);
 int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const uint32_t* ids_sorted,
-                           unsigned long long* status, int64_t R, int tile_bits, uint32_t* keys_a, uint32_t* vals_a,
+                           unsigned long long* status, int64_t R /* emitted instances */, int tile_bits, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_t, uint32_t* vals_t, uint32_t* keys_b, uint32_t* point_list, uint2* ranges,
                            uint32_t* tile_order, uint32_t* meta, int num_tiles, uint32_t* totals, void* temp,
                            size_t temp_bytes, hipStream_t st);
 // radix_sort.hip: hand-written stable radix sort of (u32 key, u32 value) pairs and the block-scheduling order
-#define VCR_SORT_TOTALS_WORDS 1024            // 4 passes x 256 digit totals, zero on entry
+#define VCR_SORT_TOTALS_WORDS 2048            // digit totals of one pass (the widest digit has 11 bits); need not be zeroed
 size_t vcr_sort_scratch_bytes(int64_t n);
 int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_tmp, uint32_t* vals_tmp,
                    uint32_t* keys_out, uint32_t* vals_out, int begin_bit, int end_bit, uint32_t* hist, uint32_t* totals,
-                   hipStream_t st);
-int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, uint32_t* meta, bool lpt, bool snake, hipStream_t st);
+                   hipStream_t st, const uint32_t* n_dev = nullptr);
+int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, uint32_t* meta, int64_t instances, bool lpt, bool snake,
+                          hipStream_t st);
 int vcr_launch_composite_forward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o,
                                  hipStream_t st);
 int vcr_launch_composite_backward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,

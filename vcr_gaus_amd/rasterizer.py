@@ -93,14 +93,16 @@ DEFAULT_OPTIONS = RasterOptions()
 
 class RasterRecord:
     """What ONE rasterizer call leaves behind besides its return tuple: the work it did (N Gaussians, V visible, R tile
-    instances, longest tile list when `debug`) and, after the backward of an `sh_grad="rgb"` call, the two factors of its SH
+    instances of the 3-sigma rectangles -- the reference's count --, R' tile instances really emitted after the exact
+    per-tile rejection, and with `debug` the longest tile list) and, after the backward of an `sh_grad="rgb"` call, the two factors of its SH
     gradient.  One object per call (`GaussianRasterizer.record`, `render()["raster"]`): a second render -- an evaluation
     pass, another model -- between a backward and the gradient exchange cannot replace them."""
-    __slots__ = ("N", "V", "R", "max_tile_len", "drgb", "view_dirs", "timing")
+    __slots__ = ("N", "V", "R", "max_tile_len", "emitted", "drgb", "view_dirs", "timing")
 
     def __init__(self):
         self.N = self.V = self.R = 0
-        self.max_tile_len = -1
+        self.emitted = 0                               # R' <= R: tile instances really emitted (exact per-tile rejection)
+        self.max_tile_len = -1                         # (only read back by `debug` renders)
         self.drgb = self.view_dirs = self.timing = None
 
     def take_sh_factors(self):
@@ -172,6 +174,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(dev):
             _check(lib.vcr_rasterize_forward(a, fo, al.cb, None, stream))
         rec.R, rec.V, rec.N, rec.max_tile_len = int(fo.num_rendered), int(fo.num_visible), N, int(fo.max_tile_len)
+        rec.emitted = int(fo.num_emitted)
         if fc == 0:
             ctx.rs, ctx.args_t, ctx.state, ctx.rec = rs, t, al.bufs, rec
             ctx.num_rendered = int(fo.num_rendered)
@@ -181,8 +184,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             ctx.save_for_backward(radii)
             ctx.mark_non_differentiable(radii)
             return out, radii
-        if fc in (1, 2):
+        if fc in (1, 2):                                   # forward-only modes: nothing to differentiate
+            ctx.mark_non_differentiable(count, score, out, radii)
             return count, score, out, radii
+        ctx.mark_non_differentiable(count, radii)
         return count, radii
 
     @staticmethod

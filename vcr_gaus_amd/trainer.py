@@ -536,7 +536,7 @@ class BenchTrainer:
     def __init__(self, raw, cams, device, world=1, rank=0, preset="tnt"):
         self.tr = make_synthetic_trainer(raw, cams, device, world=world, rank=rank, preset=preset,
                                          optim={"densify_from_iter": 10 ** 9, "prune": {"iterations": []}})
-        self.last_R = self.last_V = 0
+        self.last_R = self.last_V = self.last_E = 0
         self._primed = False
 
     def prime(self, min_seconds=1.0):
@@ -578,7 +578,7 @@ class BenchTrainer:
 
     def step(self, i):
         rec = self.tr.train_step()["raster"]    # (no per-rank fallback: a rank that switched exchange algorithm alone would hang RCCL)
-        self.last_R, self.last_V = rec.R, rec.V
+        self.last_R, self.last_V, self.last_E = rec.R, rec.V, rec.emitted
 
     @torch.no_grad()
     def scene_shape(self):
