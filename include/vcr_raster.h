@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 13
+#define VCR_ABI_VERSION 14
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -309,6 +309,10 @@ void vcr_profile_enable(int on);
 void vcr_profile_select(unsigned stage_mask);   /* bit k = time stage k (default: all); an event pair costs a few us of stream time */
 int  vcr_profile_num_stages(void);
 int  vcr_profile_read(float* ms, int32_t* launches, int n);
+/* Instrumented builds only (-DVCR_HITHIST, see profiles/hit_histogram.py): how many of the 64 pixels of an 8x8 quad a
+ * surviving (quad, Gaussian) pair really hits.  out[0..64]: forward, out[65..129]: backward; accumulated over all launches
+ * since the last reset.  Returns 1 in ordinary builds. */
+int  vcr_debug_hit_histogram(uint32_t out[130], int reset);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ c_int_p = C.POINTER(C.c_int32)
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 BUF_GEOM, BUF_BINNING, BUF_IMAGE, BUF_SCRATCH = 0, 1, 2, 3
-ABI_VERSION = 13         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
+ABI_VERSION = 14         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
 
 
 class VcrShUpdate(C.Structure):
@@ -127,6 +127,7 @@ SYMBOLS = {
     "vcr_profile_select": (None, [C.c_uint]),
     "vcr_profile_num_stages": (C.c_int, []),
     "vcr_profile_read": (C.c_int, [c_float_p, c_int_p, C.c_int]),
+    "vcr_debug_hit_histogram": (C.c_int, [C.POINTER(C.c_uint32), C.c_int]),
 }
 STAGES = ["preprocess", "depth_sort_scan", "binning", "composite_fwd", "composite_bwd", "preprocess_bwd"]
 

@@ -120,6 +120,19 @@ __device__ __forceinline__ void live_box(unsigned long long live, float X0, floa
 #ifndef VCR_KO
 #define VCR_KO 0
 #endif
+// -DVCR_HITHIST: instrumented build that counts, per surviving (quad, Gaussian) pair, how many of the 64 pixels it hits
+// (forward: bins 0..64, backward: 65..129); read with vcr_debug_hit_histogram (profiles/hit_histogram.py)
+#ifdef VCR_HITHIST
+__device__ unsigned int g_hithist[130];
+#define VCR_COUNT_HITS(BASE, MASK) do { if (lane == 0) atomicAdd(&g_hithist[(BASE) + __popcll(MASK)], 1u); } while (0)
+#else
+#define VCR_COUNT_HITS(BASE, MASK) do { } while (0)
+#endif
+// Survivors that hit at most this many pixels of the quad skip the 16-value wave reduction of the backward: their few lanes
+// add their 16 values to the GradRec directly (16 masked atomic instructions).  0 disables the path.
+#ifndef VCR_BWD_SPARSE_HITS
+#define VCR_BWD_SPARSE_HITS 2
+#endif
 #ifndef VCR_BWD_WAVES
 #define VCR_BWD_WAVES 4          // waves per SIMD the backward is compiled for: 4 (no spills) 540 us, 5 (5 spills) 560 us, 6 657 us, 3 539 us at 1 M / 1080p
 #endif
@@ -226,6 +239,7 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
             const float test_T = fmaf(-alpha, T, T);                                                                     \
             if (hit && test_T < VCR_T_EPS) { done = true; hit = false; }                                                 \
             const float w = hit ? alpha * T : 0.f;                                                                       \
+            VCR_COUNT_HITS(0, __builtin_amdgcn_ballot_w64(hit));                                                         \
             if (FC != 0) {                                                                                               \
                 const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);                                          \
                 if (hm != 0) {                                                                                           \
@@ -425,7 +439,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 
             const float e = gauss_exponent(d, sAC, r1.x, r1.y, u, hs);                                                   \
             const float araw = __builtin_amdgcn_exp2f(e);                                                                \
             const bool hit = idx1 <= lastc && hs <= 0.f && araw >= VCR_ALPHA_MIN;                                        \
-            if (__builtin_amdgcn_ballot_w64(hit) != 0) {                                                                 \
+            const unsigned long long hitm_ = __builtin_amdgcn_ballot_w64(hit);                                           \
+            VCR_COUNT_HITS(65, hitm_);                                                                                   \
+            if (hitm_ != 0) {                                                                                            \
             const f2 c01 = {r2.x, r2.y}, c2n = {r2.z, r2.w}, n12 = {r3.x, r3.y};                                         \
             const float zc = r1.z, pl = r1.w;                                                                            \
             const uint32_t gid = __float_as_uint(r3.z);                                                                  \
@@ -480,6 +496,14 @@ _Pragma("unroll")                                                               
 _Pragma("unroll")                                                                                                        \
                 for (int k = 0; k < S; ++k) vs[k] = w * g[8 + k];                                                        \
             }                                                                                                            \
+            if (VCR_BWD_SPARSE_HITS > 0 && __popcll(hitm_) <= VCR_BWD_SPARSE_HITS) {                                    \
+                /* one or two pixels hit: no wave reduction -- the hitting lanes add their 16 values themselves            */ \
+                if (hit) {                                                                                               \
+                    float* dst_ = reinterpret_cast<float*>(sgrad + gid);                                                 \
+_Pragma("unroll")                                                                                                        \
+                    for (int j = 0; j < 8; ++j) { atomicAdd(dst_ + 2 * j, v[j].x); atomicAdd(dst_ + 2 * j + 1, v[j].y); }  \
+                }                                                                                                        \
+            } else {                                                                                                     \
             float r4[4];                                                                                                 \
             if (VCR_KO & 4) { r4[0] = v[0].x + v[4].x; r4[1] = v[1].y + v[5].y; r4[2] = v[2].x + v[6].y; r4[3] = v[3].y + v[7].x; } \
             else wave_reduce16(v, r4);                                                                                   \
@@ -488,6 +512,7 @@ _Pragma("unroll")                                                               
                 const float val = sub == 0 ? r4[0] : (sub == 1 ? r4[1] : (sub == 2 ? r4[2] : r4[3]));                    \
                 const int k = 8 * (lane >> 5) + 4 * ((lane >> 4) & 1) + sub;                                             \
                 if ((VCR_KO & 2) ? val == 1.2345e-30f : val != 0.f) atomicAdd(reinterpret_cast<float*>(sgrad + gid) + k, val); \
+            }                                                                                                            \
             }                                                                                                            \
             if (S > 0) {     /* semantic gradients: DPP row sums only (no cross-row ds_bpermute round trips); the four row   */ \
                 float ts = 0.f;  /* totals of feature k sit in lanes 16 r + k and go out as ONE atomic instruction            */ \
@@ -570,6 +595,22 @@ int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
 }
 
 }  // namespace
+
+extern "C" int vcr_debug_hit_histogram(uint32_t out[130], int reset) {
+#ifdef VCR_HITHIST
+    VCR_HIP_CHECK(hipDeviceSynchronize());
+    VCR_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hithist), sizeof(unsigned int) * 130));
+    if (reset) {
+        unsigned int z[130] = {0};
+        VCR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_hithist), z, sizeof(z)));
+    }
+    return 0;
+#else
+    (void)out; (void)reset;
+    vcr_set_error("vcr_debug_hit_histogram: this library was built without -DVCR_HITHIST");
+    return 1;
+#endif
+}
 
 int vcr_launch_composite_forward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o,
                                  hipStream_t st) {
