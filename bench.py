@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--workload", default="metric_1m_1080p")
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-context", action="store_true", help="skip the untimed context measurements (dense / full-frame variants, "
+                    "schedule-inclusive window)")
     ap.add_argument("--cpu-tile-stride", type=int, default=0, help="0 = auto (~1/8 of the tiles, 10-30 s of CPU work)")
     return ap.parse_args()
 
@@ -153,7 +155,7 @@ def cpu_loss_chain(H, W):
 
 def pmc_value(counter, kernel="composite_fwd", names=("sq", "grbm")):
     import csv
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         for name in names:
             path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{name}.csv")
             if os.path.exists(path):
@@ -186,8 +188,10 @@ def pmc_traffic(kernel="composite_fwd_v2_kernel"):
     the x2 the MI355X guide prescribes (uncalibrated for this gather pattern)."""
     import csv
     vals = {}
-    rnd = "r2" if os.path.exists(os.path.join(ROOT, "profiles", "r2_pmc_fetch.csv")) else "r1"
+    rnd = next((r for r in ("r3", "r2", "r1") if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_pmc_fetch.csv"))), "r1")
     pmc_traffic.source = f"profiles/{rnd}_pmc_{{fetch,write}}.csv (rocprofv3 --pmc, separate passes)"
+    meta = os.path.join(ROOT, "profiles", f"{rnd}_pmc_meta.json")
+    pmc_traffic.meta = json.load(open(meta)) if os.path.exists(meta) else None      # R / R' / camera of the counter passes
     for name in ("fetch", "write"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{name}.csv")
         if not os.path.exists(path):
@@ -198,6 +202,83 @@ def pmc_traffic(kernel="composite_fwd_v2_kernel"):
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
+def measure_variant(name, dev, steps=30):
+    """Untimed context beside the headline line: the SAME training step on another workload (own BenchTrainer, primed, `steps`
+    timed steps + one pass with every stage timed).  -> dict with its step time, stage times, work counts and the roofline
+    figure of its compositing forward."""
+    from vcr_gaus_amd import _lib, synthetic
+    from vcr_gaus_amd.trainer import BenchTrainer
+    n, views, W, H, focal, sem, smult = synthetic.workload(name)
+    raw = synthetic.make_gaussians(n, seed=0, sem_channels=sem)
+    if smult != 1.0:
+        raw["scaling"] = raw["scaling"] + math.log(smult)
+    cams = synthetic.make_cameras(8, W, H, focal, radius=synthetic.camera_radius(name), device=dev)
+    bt = BenchTrainer(raw, cams, dev)
+    bt.prime()
+    for i in range(5):
+        bt.step(i)
+    torch.cuda.synchronize()
+    _lib.profile_enable(True, stages=["composite_fwd"])
+    _lib.profile_read()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        bt.step(5 + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fwd = _lib.profile_read()["composite_fwd"]
+    _lib.profile_enable(True)
+    for i in range(10):
+        bt.step(5 + steps + i)
+    torch.cuda.synchronize()
+    allst = _lib.profile_read()
+    _lib.profile_enable(False)
+    shape = bt.scene_shape()
+    P, R = W * H, bt.last_R
+    ms_fwd = fwd[0] / max(fwd[1], 1)
+    alg = (60 + 4 * sem) * R + (4 * (8 + sem) + 20) * P
+    ach = alg / (ms_fwd * 1e-3) / 1e9 if ms_fwd > 0 else 0.0
+    stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in allst.items()}
+    stages["composite_fwd"] = round(ms_fwd, 4)
+    del bt
+    torch.cuda.empty_cache()
+    return {"workload": name, "camera_radius": synthetic.camera_radius(name), "scale_mult": smult, "ms_per_step": 1e3 * dt / steps,
+            "iters_per_s": steps / dt, "tile_instances_R": R, "emitted_instances": shape.get("emitted"), "visible_V": shape.get("visible"),
+            "max_tile_len": shape["max_tile_len"], "covered_pixels": shape["covered_pixels"], "coverage": shape["covered_pixels"] / P,
+            "stage_ms": stages,
+            "roofline": {"kernel": "composite_fwd", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": alg, "avg_ms": ms_fwd}}
+
+
+def schedule_inclusive(trainer, iters=200):
+    """What a training run costs per iteration WITH the reference's schedule inside the window ('densify
+    amortised'): the headline trainer continues for `iters` iterations with densification switched on at the reference's
+    interval of 100 (`configs/config_base.yaml`), i.e. two densify-and-prune steps, each preceded (tnt preset) by the 200
+    visibility renders at 1500 x 1500 of `densify_large` (`trainer.py:357-370`).  Untimed by the contract; wall clock."""
+    tr = trainer.tr
+    o = tr.cfg.optim
+    keep = (o.densify_from_iter, o.densification_interval, o.densify_until_iter)
+    o.densify_from_iter, o.densification_interval, o.densify_until_iter = tr.current_iteration, 100, 10 ** 9
+    n0 = tr.model._xyz.shape[0]
+    sizes = []
+    tr.join_side()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        before = tr.model._xyz.shape[0]
+        trainer.step(10 ** 6 + i)
+        if tr.model._xyz.shape[0] != before:
+            sizes.append(tr.model._xyz.shape[0])
+    tr.join_side()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    o.densify_from_iter, o.densification_interval, o.densify_until_iter = keep
+    dl = o.densify_large
+    vis = dl.sample_cams.num if (dl.percent_dense and dl.sample_cams.num > 0) else 0
+    return {"iters": iters, "ms_per_iter": 1e3 * dt / iters, "iters_per_s": iters / dt, "densify_steps": len(sizes),
+            "visibility_renders_per_densify": vis, "gaussians_start": n0, "gaussians_after_each_densify": sizes,
+            "what": "same step as `value` with densify_and_prune every 100 iterations (and its visibility passes) inside the window"}
 
 
 def main():
@@ -224,7 +305,7 @@ def main():
     raw = synthetic.make_gaussians(n, seed=0, sem_channels=sem)
     if smult != 1.0:
         raw["scaling"] = raw["scaling"] + math.log(smult)
-    cams = synthetic.make_cameras(max(args.views, world), W, H, focal, device=dev)
+    cams = synthetic.make_cameras(max(args.views, world), W, H, focal, radius=synthetic.camera_radius(args.workload), device=dev)
     trainer = BenchTrainer(raw, cams, dev, world=world, rank=rank)
 
     def sync():
@@ -275,6 +356,9 @@ def main():
         line = {
             "metric": "train iters/sec @1M Gaussians 1080p (full step: render fwd, losses, bwd, optimizer)",
             "value": world * args.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+            # one camera per rank per optimizer iteration: `value` is the whole-job aggregate in VIEWS (= iterations x ranks)
+            "iters_per_s": args.steps / dt, "views_per_s": world * args.steps / dt,
+            "value_is": "views/s = optimizer iterations/s x views per iteration (n_gpus); equal to iters/s on one GPU",
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scale_mult": smult, "gaussians": n, "width": W, "height": H, "sh_degree": 3,
@@ -291,6 +375,7 @@ def main():
                          "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                          "traffic": pmc_traffic() if args.workload == "metric_1m_1080p" else None,
                          "traffic_source": getattr(pmc_traffic, "source", None),
+                         "traffic_pass": getattr(pmc_traffic, "meta", None),
                          "algorithmic_bytes": alg_bytes, "avg_ms": ms_fwd,
                          # the kernel is VALU-bound in practice.  `naive_*`: the algorithm's (pixel, Gaussian) pair
                          # evaluations (256 per tile instance, ~30 wave64 VALU instructions per 64 pairs) priced at the issue
@@ -298,8 +383,12 @@ def main():
                          # per-quad culling skips most pairs) and the share of the launch the VALUs are busy.
                          "valu": valu_block(R, ms_fwd, args.workload)},
         }
-        if world == 1 and args.workload == "metric_1m_1080p":
+        if world == 1 and args.workload == "metric_1m_1080p" and not args.no_context:
             line["roofline"]["dense_variant"] = trainer.dense_variant_roofline(3.5, HBM_PEAK_GBS, sem)
+            line["schedule_inclusive"] = schedule_inclusive(trainer)
+            del trainer
+            torch.cuda.empty_cache()
+            line["fullframe_variant"] = measure_variant("fullframe_1m_1080p", dev)
         if world == 1 and not args.no_cpu_baseline:
             stride = args.cpu_tile_stride or max(1, ((W + 15) // 16) * ((H + 15) // 16) // 1024)
             dirs = get_all_px_dir(cams[0].intr, H, W)

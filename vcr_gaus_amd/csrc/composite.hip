@@ -129,9 +129,12 @@ __device__ unsigned int g_hithist[130];
 #define VCR_COUNT_HITS(BASE, MASK) do { } while (0)
 #endif
 // Survivors that hit at most this many pixels of the quad skip the 16-value wave reduction of the backward: their few lanes
-// add their 16 values to the GradRec directly (16 masked atomic instructions).  0 disables the path.
+// add their 16 values to the GradRec directly (16 masked atomic instructions).  0 disables the path -- the default:
+// measured with 2 on the metric workload (28 % of the survivors hit <= 2 pixels, profiles/r3_hit_histogram_metric.txt):
+// compositing backward 0.76 ms against 0.51 -- sixteen atomic INSTRUCTIONS cost several times the ~195 SIMD cycles of the
+// butterfly they replace (the atomics are free in bandwidth, not in issue).
 #ifndef VCR_BWD_SPARSE_HITS
-#define VCR_BWD_SPARSE_HITS 2
+#define VCR_BWD_SPARSE_HITS 0
 #endif
 #ifndef VCR_BWD_WAVES
 #define VCR_BWD_WAVES 4          // waves per SIMD the backward is compiled for: 4 (no spills) 540 us, 5 (5 spills) 560 us, 6 657 us, 3 539 us at 1 M / 1080p
@@ -239,7 +242,7 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
             const float test_T = fmaf(-alpha, T, T);                                                                     \
             if (hit && test_T < VCR_T_EPS) { done = true; hit = false; }                                                 \
             const float w = hit ? alpha * T : 0.f;                                                                       \
-            VCR_COUNT_HITS(0, __builtin_amdgcn_ballot_w64(hit));                                                         \
+            { const unsigned long long hm_ = __builtin_amdgcn_ballot_w64(hit); VCR_COUNT_HITS(0, hm_); (void)hm_; }      \
             if (FC != 0) {                                                                                               \
                 const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);                                          \
                 if (hm != 0) {                                                                                           \

@@ -26,14 +26,25 @@ WORKLOADS = {
 # Denser variants of a workload (same scene, every scale multiplied): the Appendix-B recipe gives R/N ~ 3 tile instances per
 # Gaussian and leaves 84 % of the 1080p tiles empty; real trained scenes sit at R/N ~ 10-20.  name -> (base, scale multiplier)
 DENSE_VARIANTS = {"dense_1m_1080p": ("metric_1m_1080p", 3.5)}
+# Full-frame variant: the same 1 M Gaussians seen from INSIDE the orbit (radius 1.3 instead of 3: the scene subtends more than
+# the field of view), so that ~every pixel is covered and R/N ~ 10 as in a trained scene -- the Appendix-B orbit leaves 81 %
+# of the 1080p frame empty.  name -> (base workload, camera orbit radius)
+CLOSE_VARIANTS = {"fullframe_1m_1080p": ("metric_1m_1080p", 1.3)}
 
 
 def workload(name):
-    """-> (n, views, width, height, focal, sem_channels, scale_mult) for a name of WORKLOADS or DENSE_VARIANTS."""
+    """-> (n, views, width, height, focal, sem_channels, scale_mult) for a name of WORKLOADS, DENSE_VARIANTS or CLOSE_VARIANTS."""
     if name in DENSE_VARIANTS:
         base, mult = DENSE_VARIANTS[name]
         return WORKLOADS[base] + (mult,)
+    if name in CLOSE_VARIANTS:
+        return WORKLOADS[CLOSE_VARIANTS[name][0]] + (1.0,)
     return WORKLOADS[name] + (1.0,)
+
+
+def camera_radius(name):
+    """Orbit radius of the workload's cameras (3 = SURVEY Appendix B)."""
+    return CLOSE_VARIANTS[name][1] if name in CLOSE_VARIANTS else 3.0
 
 
 def _surface_points(n, g):

@@ -593,7 +593,9 @@ class BenchTrainer:
             pkg = render(cam, tr.model, tr.cfg, tr.background, dirs=tr.dirs)
         finally:
             tr.cfg.pipline.debug = dbg
-        return {"max_tile_len": int(pkg["raster"].max_tile_len), "covered_pixels": int((pkg["alpha"] > 0).sum())}
+        rec = pkg["raster"]
+        return {"max_tile_len": int(rec.max_tile_len), "covered_pixels": int((pkg["alpha"] > 0).sum()), "emitted": int(rec.emitted),
+                "visible": int(rec.V)}
 
     @torch.no_grad()
     def dense_variant_roofline(self, scale_mult, peak_gbs, sem=0, reps=10):
