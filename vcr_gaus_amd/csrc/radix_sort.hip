@@ -325,10 +325,15 @@ size_t vcr_sort_scratch_bytes(int64_t n) {
     return vcr_align(sizeof(uint32_t) * (size_t)(2048 * (nblk > 0 ? nblk : 1)));
 }
 
-// Pass plan for `bits` key bits: digits of at most 8 bits while two passes suffice (small histograms, more resident
-// workgroups), else of at most 11.  -> number of passes, bits of every pass in `out`.
+// Pass plan for `bits` key bits -> number of passes, bits of every pass in `out`.  Digits of at most 8 bits by default
+// (VCR_SORT_DIGIT_BITS=11 selects 11-bit digits: 3 instead of 4 passes over the 32-bit depth keys).  Measured at 1 M keys
+// (profiles/r3_sort_ab.txt): 3 x 11 bits 88 us stand-alone / 146 us inside the step against 4 x 8 bits 79 / 137 us -- with
+// 2048 digits and 4096 items per workgroup a run of equal digits is 2 items long, so the scatter of the first passes
+// degenerates to single 4-byte stores, and the scan kernel works on 8 KB rows; the wide digits lose more per pass than the
+// saved pass returns.
+
 static int rs_plan(int bits, int out[4]) {
-    static const int max_digit = [] { const char* e = getenv("VCR_SORT_DIGIT_BITS"); const int v = e ? atoi(e) : 11; return v < 8 ? 8 : (v > 11 ? 11 : v); }();
+    static const int max_digit = [] { const char* e = getenv("VCR_SORT_DIGIT_BITS"); const int v = e ? atoi(e) : 8; return v < 8 ? 8 : (v > 11 ? 11 : v); }();
     int passes = bits <= 8 ? 1 : (bits <= 16 ? 2 : (bits <= 2 * max_digit ? 2 : (bits <= 3 * max_digit ? 3 : 4)));
     for (int p = 0, left = bits; p < passes; ++p) {
         out[p] = (left + (passes - p) - 1) / (passes - p);

@@ -27,9 +27,9 @@ WORKLOADS = {
 # Gaussian and leaves 84 % of the 1080p tiles empty; real trained scenes sit at R/N ~ 10-20.  name -> (base, scale multiplier)
 DENSE_VARIANTS = {"dense_1m_1080p": ("metric_1m_1080p", 3.5)}
 # Full-frame variant: the same 1 M Gaussians seen from INSIDE the orbit (radius 1.3 instead of 3: the scene subtends more than
-# the field of view), so that ~every pixel is covered and R/N ~ 10 as in a trained scene -- the Appendix-B orbit leaves 81 %
-# of the 1080p frame empty.  name -> (base workload, camera orbit radius)
-CLOSE_VARIANTS = {"fullframe_1m_1080p": ("metric_1m_1080p", 1.3)}
+# the field of view) with every scale x 1.6, so that nearly every pixel is covered and R/N ~ 10 as in a trained scene -- the
+# Appendix-B orbit leaves 81 % of the 1080p frame empty.  name -> (base workload, camera orbit radius, scale multiplier)
+CLOSE_VARIANTS = {"fullframe_1m_1080p": ("metric_1m_1080p", 1.3, 1.6)}
 
 
 def workload(name):
@@ -38,7 +38,7 @@ def workload(name):
         base, mult = DENSE_VARIANTS[name]
         return WORKLOADS[base] + (mult,)
     if name in CLOSE_VARIANTS:
-        return WORKLOADS[CLOSE_VARIANTS[name][0]] + (1.0,)
+        return WORKLOADS[CLOSE_VARIANTS[name][0]] + (CLOSE_VARIANTS[name][2],)
     return WORKLOADS[name] + (1.0,)
 
 
