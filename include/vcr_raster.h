@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 14
+#define VCR_ABI_VERSION 15
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -184,7 +184,8 @@ size_t vcr_sort_pairs_u32_scratch_bytes(int64_t n);
 int vcr_sort_pairs_u32(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                        int begin_bit, int end_bit, void* scratch, size_t scratch_bytes, void* stream);
 /* simple_knn._C.distCUDA2 (scene/gaussian_model.py:17-20,211): mean squared distance to the 3 nearest neighbours,
- * points [N,3] -> out [N].  Exact brute force (one-time initialisation from the SfM point cloud). */
+ * points [N,3] -> out [N].  Exact: a uniform grid of ~2 points per cell searched shell by shell (brute force up to 2048
+ * points).  One-time initialisation from the SfM point cloud: synchronises the stream and allocates its scratch itself. */
 int vcr_knn3_mean_dist2(int N, const float* points, float* out, void* stream);
 /* One launch for all parameter groups; semantics of torch.optim.Adam(eps=1e-15) with per-group lr
  * (scene/gaussian_model.py:247-258).  Pointer arrays are HOST arrays of device pointers (<= 8 tensors).
@@ -192,6 +193,30 @@ int vcr_knn3_mean_dist2(int N, const float* points, float* out, void* stream);
 int vcr_adam_step(int ntensors, float* const* params, const float* const* grads, float* const* exp_avg,
                   float* const* exp_avg_sq, const int64_t* numel, const float* lr, float beta1, float beta2,
                   float eps, int step, float grad_scale, void* stream);
+/* The static tail of a training iteration in ONE pass over the Gaussians (single process, no densify / prune / reset this
+ * iteration): adjoint of the fused activation (the four upstream gradients are those of vcr_rasterize_backward w.r.t. the
+ * ACTIVATED scales / rotations / opacities / camera-space normals of this iteration's render; `aux`, `Rw2c` as saved by
+ * vcr_activate_forward) plus the l1_scale gradient (trainer.py:243-245; scale_reg_* NULL = none) -> densification statistics
+ * (scene/gaussian_model.py:669-671, trainer.py:345; grad2d NULL = none) -> one torch.optim.Adam(eps) step on
+ * xyz / scaling / rotation / opacity (scene/gaussian_model.py:232-262; d_means3D NULL = xyz untouched) -> fused activation of
+ * the UPDATED parameters for the next render's camera (next_* NULL = none).  Replaces vcr_activate_backward +
+ * vcr_scale_reg_backward + vcr_densify_stats + vcr_adam_step + vcr_activate_forward on those four groups. */
+typedef struct VcrGeometryStep {
+    int32_t N, pad_;
+    int32_t step_xyz, step_scaling, step_rotation, step_opacity;     /* torch counts Adam steps per tensor (>= 1) */
+    float *xyz, *scaling, *rotation, *opacity;                       /* raw parameters, updated in place */
+    const float *d_means3D, *d_scales, *d_rots, *d_opac, *d_normals; /* upstream gradients (any may be NULL) */
+    const uint8_t* aux; const float* Rw2c;                           /* of this iteration's activation */
+    const float* scale_reg_gout; const double* scale_reg_sums;       /* [1] weight x seed; sums[2] = Gaussians inside the box */
+    const float *trans, *scale;                                      /* [3] each: normalised bounding box */
+    float *m_xyz, *v_xyz, *m_scaling, *v_scaling, *m_rotation, *v_rotation, *m_opacity, *v_opacity;
+    float lr_xyz, lr_scaling, lr_rotation, lr_opacity, beta1, beta2, eps;
+    const float* grad2d; const int32_t* radii; float *accum, *denom, *max_radii;
+    const float *next_campos, *next_Rw2c;
+    float *next_scales, *next_rots, *next_opac, *next_normals; uint8_t* next_aux;
+} VcrGeometryStep;
+int vcr_geometry_step(const VcrGeometryStep* args, void* stream);
+
 /* add_densification_stats + max_radii2D update (scene/gaussian_model.py:669-671, trainer.py:345) */
 int vcr_densify_stats(int N, const float* grad2d /*[N,3]*/, const int32_t* radii, float* accum, float* denom,
                       float* max_radii, void* stream);

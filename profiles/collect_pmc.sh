@@ -1,15 +1,29 @@
 #!/bin/bash
-# PMC passes for the compositing kernels on the metric workload (run on the GPU box: bash profiles/collect_pmc.sh).
+# PMC passes for the compositing / sort kernels on the metric workload (run on the GPU box: bash profiles/collect_pmc.sh sq lds grbm fetch write).
 # One rocprofv3 run per counter set (--pmc is never combined with API/runtime tracing); summaries land in gpurun_out/.
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
+RND=${VCR_ROUND:-r3}
 run() {  # name counters...
     local name=$1; shift
     rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$name -o pmc -- \
-        python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $R/gpurun_out/pmc_$name.log 2>&1
+        python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-context > $R/gpurun_out/pmc_$name.log 2>&1
     python $R/profiles/summarize.py counters $(ls $R/gpurun_out/pmc_$name/*counter_collection.csv | head -1) \
-        $R/gpurun_out/r2_pmc_$name.csv composite_ adam_kernel sh_adam rs_ > /dev/null
+        $R/gpurun_out/${RND}_pmc_$name.csv composite_ adam_kernel sh_ rs_ duplicate_ preprocess_ > /dev/null
+    # which frame the counters saw: R / R' / V of the bench line printed by the same command
+    python - "$R/gpurun_out/pmc_$name.log" "$R/gpurun_out/${RND}_pmc_meta.json" "$name" <<'PY'
+import json, sys
+line = [l for l in open(sys.argv[1]) if l.startswith("{")][-1]
+d = json.loads(line)["config"]
+try:
+    meta = json.load(open(sys.argv[2]))
+except Exception:
+    meta = {}
+meta[sys.argv[3]] = {k: d.get(k) for k in ("workload", "tile_instances_R", "emitted_instances", "visible_V")}
+json.dump(meta, open(sys.argv[2], "w"), indent=1, sort_keys=True)
+PY
+    rm -rf $R/gpurun_out/pmc_$name
 }
 for set in "$@"; do
     case $set in

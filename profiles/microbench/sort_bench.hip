@@ -24,8 +24,9 @@ static void run(const char* name, int64_t n, int bits, bool float_keys, bool iot
     std::vector<uint32_t> idx(n);
     std::iota(idx.begin(), idx.end(), 0u);
     std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return k[a] < k[b]; });
-    uint32_t *dk, *dv, *tk, *tv, *ok, *ov, *table, *ticket;   // ticket = digit totals
-    hipMalloc(&dk, n * 4); hipMalloc(&dv, n * 4); hipMalloc(&tk, n * 4); hipMalloc(&tv, n * 4); hipMalloc(&ok, n * 4); hipMalloc(&ov, n * 4);
+    uint32_t *dk, *dv, *ok, *ov, *table, *ticket;   // ticket = digit totals
+    uint2 *pa, *pb;                                 // 8-byte (key, value) records of the intermediate passes
+    hipMalloc(&dk, n * 4); hipMalloc(&dv, n * 4); hipMalloc(&pa, n * 8); hipMalloc(&pb, n * 8); hipMalloc(&ok, n * 4); hipMalloc(&ov, n * 4);
     hipMalloc(&table, vcr_sort_scratch_bytes(n)); hipMalloc(&ticket, VCR_SORT_TOTALS_WORDS * 4);
     hipMemcpy(dk, k.data(), n * 4, hipMemcpyHostToDevice); hipMemcpy(dv, v.data(), n * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -33,7 +34,7 @@ static void run(const char* name, int64_t n, int bits, bool float_keys, bool iot
     for (int rep = 0; rep < 6; ++rep) {
         hipMemsetAsync(ticket, 0, VCR_SORT_TOTALS_WORDS * 4, 0);
         hipEventRecord(e0);
-        vcr_sort_pairs(n, dk, iota ? nullptr : dv, tk, tv, ok, ov, 0, bits, table, ticket, 0);
+        vcr_sort_pairs(n, dk, iota ? nullptr : dv, nullptr, pa, pb, ok, ov, 0, bits, table, ticket, 0);
         hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms_mine, e0, e1);
     }
@@ -52,7 +53,7 @@ static void run(const char* name, int64_t n, int bits, bool float_keys, bool iot
     }
     printf("%-28s n=%lld bits=%d  mismatches=%lld  hand-written %.1f us   rocPRIM onesweep %.1f us\n", name, (long long)n, bits,
            (long long)bad, ms_mine * 1e3, ms_prim * 1e3);
-    hipFree(dk); hipFree(dv); hipFree(tk); hipFree(tv); hipFree(ok); hipFree(ov); hipFree(table); hipFree(ticket); hipFree(tmp);
+    hipFree(dk); hipFree(dv); hipFree(pa); hipFree(pb); hipFree(ok); hipFree(ov); hipFree(table); hipFree(ticket); hipFree(tmp);
 }
 
 int main() {
@@ -70,13 +71,13 @@ int main() {
     uint2* drg; uint32_t *dord, *dmeta; hipMalloc(&drg, T * 8); hipMalloc(&dord, T * 4); hipMalloc(&dmeta, VCR_BIN_META_WORDS * 4);
     hipMemcpy(drg, rg.data(), T * 8, hipMemcpyHostToDevice);
     hipMemset(dord, 0xFF, T * 4);
-    vcr_launch_tile_order(T, drg, dord, dmeta, true, false, 0);
+    vcr_launch_tile_order(T, drg, dord, dmeta, 1000000, true, false, 0);
     std::vector<uint32_t> ord(T);
     hipMemcpy(ord.data(), dord, T * 4, hipMemcpyDeviceToHost);
     std::vector<int> seen(T, 0); int badp = 0, inv = 0;
     for (int i = 0; i < T; ++i) { if (ord[i] >= (uint32_t)T || seen[ord[i]]++) ++badp; }
-    for (int i = 1; i < T && !badp; ++i) inv += ((rg[ord[i]].y >> 2) > (rg[ord[i - 1]].y >> 2));
-    vcr_launch_tile_order(T, drg, dord, dmeta, true, true, 0);
+    for (int i = 1; i < T && !badp; ++i) inv += ((rg[ord[i]].y >> 2) > (rg[ord[i - 1]].y >> 2));      // (empty tiles last)
+    vcr_launch_tile_order(T, drg, dord, dmeta, 1000000, true, true, 0);
     hipMemcpy(ord.data(), dord, T * 4, hipMemcpyDeviceToHost);
     std::fill(seen.begin(), seen.end(), 0); int badp2 = 0;
     for (int i = 0; i < T; ++i) { if (ord[i] >= (uint32_t)T || seen[ord[i]]++) ++badp2; }

@@ -236,6 +236,52 @@ def test_knn3_init_matches_bruteforce(device):
     assert abs(float(torch.sigmoid(m._opacity).mean()) - 0.1) < 1e-6 and m._features_rest.abs().max() == 0
 
 
+def _knn3_reference(pts):
+    """mean of the 3 smallest squared distances to OTHER points, fp64, chunked"""
+    p = pts.double()
+    out = torch.empty(len(p), dtype=torch.float64)
+    for a in range(0, len(p), 2048):
+        d = torch.cdist(p[a:a + 2048], p) ** 2
+        d[torch.arange(d.shape[0]), torch.arange(a, a + d.shape[0])] = float("inf")
+        out[a:a + 2048] = d.topk(3, largest=False).values.mean(1)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cloud", ["uniform", "clustered", "planar", "line_with_duplicates", "offset_far", "n2049"])
+def test_knn3_grid_search_is_exact(device, cloud):
+    """The grid search of vcr_knn3_mean_dist2 (N > 2048) returns what the brute force returns on clouds that stress it:
+    empty cells between clusters, a degenerate axis, coincident points, coordinates far from the origin."""
+    from vcr_gaus_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    n = 20000
+    if cloud == "uniform":
+        pts = torch.rand(n, 3, generator=g) * torch.tensor([4.0, 1.0, 0.3])
+    elif cloud == "clustered":
+        centres = torch.randn(12, 3, generator=g) * 5
+        pts = centres[torch.randint(0, 12, (n,), generator=g)] + 0.02 * torch.randn(n, 3, generator=g)
+        pts[:40] = torch.randn(40, 3, generator=g) * 30                       # far outliers: many empty shells to cross
+    elif cloud == "planar":
+        pts = torch.rand(n, 3, generator=g)
+        pts[:, 1] = 0.25
+    elif cloud == "line_with_duplicates":
+        pts = torch.zeros(n, 3)
+        pts[:, 0] = torch.randint(0, 500, (n,), generator=g).float() * 0.01   # ~40 coincident points per site
+    elif cloud == "offset_far":
+        pts = torch.rand(n, 3, generator=g) * 0.5 + torch.tensor([1000.0, -2000.0, 500.0])
+    else:
+        pts = torch.randn(2049, 3, generator=g)
+    ref = _knn3_reference(pts)
+    lib = _lib.load()
+    d_pts = pts.to(device).contiguous()
+    out = torch.empty(len(pts), device=device)
+    _lib.check(lib.vcr_knn3_mean_dist2(len(pts), d_pts.data_ptr(), out.data_ptr(), _lib.stream_of(d_pts)))
+    got = out.cpu().double()
+    # fp32 differences of fp32 coordinates: relative to the squared coordinate spread, not to the (possibly zero) distance
+    tol = 1e-5 * ref + 1e-6 * float((pts - pts.mean(0)).abs().max()) ** 2 * (1e-2 if cloud != "offset_far" else 1.0)
+    assert bool(((got - ref).abs() <= tol + 1e-12).all()), float(((got - ref).abs() - tol).max())
+
+
 def test_factorised_sh_path_trains_like_the_dense_path(device):
     """The DP exchange path (backward leaves dL/drgb, SH gradients rebuilt by vcr_sh_grad_from_rgb) run at world size 1
     must follow the same trajectory as the ordinary path."""

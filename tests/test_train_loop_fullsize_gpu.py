@@ -74,5 +74,5 @@ def test_c3_training_loop_at_size_then_oracle_parity(device, two_stream):
                rots=act["rotation"], sem=None)
     from vcr_gaus_amd.graphics_utils import get_all_px_dir
     info = util.sampled_tile_parity(device, cam, inp, get_all_px_dir(cam.intr, H, W), torch.tensor([0.15, 0.05, 0.3]), 37, 2000,
-                                    "c3-trained", min_alpha=0.05)
+                                    "c3-trained", min_alpha=0.05, own_yardstick=True)
     assert info["subset"] > 500

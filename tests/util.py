@@ -209,11 +209,14 @@ def flip_clean_mask(cam, inp, out, ref, bg, sh_degree=3):
     return clean, int(bad.sum())
 
 
-def sampled_tile_parity(device, cam, inp, dirs, bg, stride, min_inst, name, min_alpha=0.5):
+def sampled_tile_parity(device, cam, inp, dirs, bg, stride, min_inst, name, min_alpha=0.5, own_yardstick=False):
     """Oracle parity of ONE full-size render on sampled tiles (see tests/test_fullsize_sampled_gpu.py): the HIP path renders
     the whole scene `inp`; the fp64 oracle composites every `stride`-th tile from exactly the Gaussians that touch those
     tiles.  Compared: sampled pixels, radii of the subset, gradients of a random loss restricted to the sampled tiles
-    (zero outside the subset).  Gaussians under a flipped pixel (< 5 %, asserted) are left out of the gradient check."""
+    (zero outside the subset).  Gaussians under a flipped pixel (< 5 %, asserted) are left out of the gradient check.
+    `own_yardstick`: for scenes the tabulated "full" yardstick was not measured on (a TRAINED model: needle-shaped Gaussians
+    whose fp32 conic carries far more rounding than the synthetic blobs'), the oracle is also evaluated in fp32 on the same
+    subset and the max-norm tolerance of a tensor becomes max(table, 3 x the fp32 oracle's own max-norm error)."""
     n = inp["means3D"].shape[0]
     H, W = cam.image_height, cam.image_width
     (out, radii), hl = hip_forward(cam, inp, dirs, bg, device, requires_grad=True)
@@ -244,6 +247,14 @@ def sampled_tile_parity(device, cam, inp, dirs, bg, stride, min_inst, name, min_
     badmask = ((o - r).abs() > 2e-4 + 1e-4 * r.abs()).any(0)
     bad = int(badmask.sum())
     assert bad <= max(4, int(2e-3 * o.shape[1])), f"{bad} of {o.shape[1]} sampled pixels differ"
+    g = torch.Generator().manual_seed(stride)
+    wgt = torch.randn(ref.shape, generator=g, dtype=torch.float64) * tmask[None]
+    l32 = None
+    if own_yardstick:
+        (o32, _, _), l32 = oracle_forward(cam, sub, dirs, bg, dtype=torch.float32, requires_grad=True, tile_stride=stride)
+        (o32 * wgt.float()).sum().backward()
+        o32 = o32.detach().double()[:, tmask]
+        badmask = badmask | ((o32 - r).abs() > 2e-4 + 1e-4 * r.abs()).any(0)     # (flips of the fp32 oracle are left out too)
     ys, xs = torch.nonzero(tmask, as_tuple=True)
     clean = torch.ones(int(hit.sum()), dtype=torch.bool)          # Gaussians of the subset not covering a flipped pixel
     for y, x in zip(ys[badmask].tolist(), xs[badmask].tolist()):
@@ -252,15 +263,22 @@ def sampled_tile_parity(device, cam, inp, dirs, bg, stride, min_inst, name, min_
         clean &= ~((power <= 0) & (sop * torch.exp(power) >= 0.5 / 255.0))       # contributes (or nearly does) at that pixel
     assert float((~clean).double().mean()) < 0.05
     assert float(ref[7][tmask].max()) > min_alpha               # the sample sees real coverage
-    g = torch.Generator().manual_seed(stride)
-    wgt = torch.randn(ref.shape, generator=g, dtype=torch.float64) * tmask[None]
     (ref * wgt).sum().backward()
     (out * wgt.float().to(device)).sum().backward()
+
+    def tol(k, a, b):
+        if l32 is None:
+            return None
+        own = grad_stats(a, b)["maxnorm"]
+        return max(grad_tolerance(k, "full")[0], 3.0 * own)
+
     for k in ["means3D", "shs", "normals", "opac", "scales", "rots", "m2", "sem"]:
         if rl.get(k) is None or hl[k] is None:
             continue
         gfull = hl[k].grad.cpu()
         assert float(gfull[~hit].abs().max()) == 0.0 if (~hit).any() else True, f"{k}: gradient outside the sampled subset"
-        assert_grads_close(gfull[hit][clean], rl[k].grad[clean], f"{name}:{k}", regime="full")
-    assert_grads_close(hl["m2d"].grad.cpu()[hit][clean][:, :2], rl["m2d"].grad[clean][:, :2], f"{name}:m2d", regime="full")
+        assert_grads_close(gfull[hit][clean], rl[k].grad[clean], f"{name}:{k}", regime="full",
+                           maxnorm_tol=tol(k, l32[k].grad[clean], rl[k].grad[clean]) if l32 is not None else None)
+    assert_grads_close(hl["m2d"].grad.cpu()[hit][clean][:, :2], rl["m2d"].grad[clean][:, :2], f"{name}:m2d", regime="full",
+                       maxnorm_tol=tol("m2d", l32["m2d"].grad[clean][:, :2], rl["m2d"].grad[clean][:, :2]) if l32 is not None else None)
     return dict(instances=inst, flipped=bad, sampled_pixels=int(o.shape[1]), subset=int(hit.sum()))

@@ -16,7 +16,7 @@ c_int_p = C.POINTER(C.c_int32)
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 BUF_GEOM, BUF_BINNING, BUF_IMAGE, BUF_SCRATCH = 0, 1, 2, 3
-ABI_VERSION = 14         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
+ABI_VERSION = 15         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
 
 
 class VcrShUpdate(C.Structure):
@@ -26,6 +26,16 @@ class VcrShUpdate(C.Structure):
         ("m_dc", C.c_void_p), ("v_dc", C.c_void_p), ("m_rest", C.c_void_p), ("v_rest", C.c_void_p),
         ("lr_dc", C.c_float), ("lr_rest", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
     ]
+
+
+class VcrGeometryStep(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("N", "pad_", "step_xyz", "step_scaling", "step_rotation", "step_opacity")] + [(k, C.c_void_p) for k in (
+        "xyz", "scaling", "rotation", "opacity", "d_means3D", "d_scales", "d_rots", "d_opac", "d_normals", "aux", "Rw2c",
+        "scale_reg_gout", "scale_reg_sums", "trans", "scale", "m_xyz", "v_xyz", "m_scaling", "v_scaling", "m_rotation",
+        "v_rotation", "m_opacity", "v_opacity")] + [(k, C.c_float) for k in (
+            "lr_xyz", "lr_scaling", "lr_rotation", "lr_opacity", "beta1", "beta2", "eps")] + [(k, C.c_void_p) for k in (
+                "grad2d", "radii", "accum", "denom", "max_radii", "next_campos", "next_Rw2c", "next_scales", "next_rots",
+                "next_opac", "next_normals", "next_aux")]
 
 
 MAX_ROW_ARRAYS = 32
@@ -95,6 +105,7 @@ SYMBOLS = {
     "vcr_adam_step": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_int64), c_float_p, C.c_float, C.c_float,
                                 C.c_float, C.c_int, C.c_float, C.c_void_p]),
+    "vcr_geometry_step": (C.c_int, [C.POINTER(VcrGeometryStep), C.c_void_p]),
     "vcr_densify_stats": (C.c_int, [C.c_int] + [C.c_void_p] * 6),
     "vcr_depth_to_normal_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 3),
     "vcr_depth_to_normal_backward": (C.c_int, [C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 5),

@@ -30,9 +30,8 @@ constexpr int DUP_ROUNDS = 4;                       // Gaussians per thread: 102
 // `status`: one zeroed 64-bit word per block; `ticket`: one zeroed word.
 __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, const uint32_t* __restrict__ ids_sorted,
                                                         unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket,
-                                                        const uint2* __restrict__ rect, uint32_t* __restrict__ keys_out,
-                                                        uint32_t* __restrict__ vals_out, uint2* __restrict__ ranges,
-                                                        int num_tiles) {
+                                                        const uint2* __restrict__ rect, uint2* __restrict__ inst_out,
+                                                        uint2* __restrict__ ranges, int num_tiles) {
     __shared__ uint32_t s_gend[4][64], s_start[4][64], s_id[4][64];
     __shared__ int s_xmin[4][64], s_ymin[4][64], s_w[4][64];
     __shared__ uint32_t s_wtot[DUP_ROUNDS][4], s_prefix, s_bid;
@@ -111,8 +110,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
             while (m) {
                 const int k = __builtin_ctz(m);
                 m &= m - 1;
-                keys_out[at] = (uint32_t)((ymin + k / w) * gx + xmin + k % w);
-                vals_out[at] = id[r];
+                inst_out[at] = make_uint2((uint32_t)((ymin + k / w) * gx + xmin + k % w), id[r]);      // (tile, Gaussian)
                 ++at;
             }
         }
@@ -140,8 +138,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
             const int ty = s_ymin[wv][lo] + (int)(local / (uint32_t)ww);
             const int tx = s_xmin[wv][lo] + (int)(local % (uint32_t)ww);
             const uint32_t target = s_start[wv][lo] + local;
-            keys_out[target] = (uint32_t)(ty * gx + tx);
-            vals_out[target] = s_id[wv][lo];
+            inst_out[target] = make_uint2((uint32_t)(ty * gx + tx), s_id[wv][lo]);
         }
     }
 }
@@ -168,19 +165,20 @@ size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits) {
 // look-back status words of the emission kernel (+ its ticket word at the end), zeroed by the caller
 size_t vcr_duplicate_status_bytes(int N) { return vcr_align(sizeof(unsigned long long) * (size_t)((N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS) + 2)); }
 
-// depth order of the N Gaussians (ties by index).  (tmp_k, tmp_v): N words each; `totals`: VCR_SORT_TOTALS_WORDS words.
-int vcr_depth_sort(int N, const uint32_t* depth_key, uint32_t* tmp_k, uint32_t* tmp_v, uint32_t* key_sorted,
-                   uint32_t* ids_sorted, uint32_t* totals, void* temp, hipStream_t st) {
-    return vcr_sort_pairs(N, depth_key, nullptr, tmp_k, tmp_v, key_sorted, ids_sorted, 0, 32, (uint32_t*)temp, totals, st, nullptr);
+// depth order of the N Gaussians (ties by index).  (pair_a, pair_b): N 8-byte records each; `totals`: VCR_SORT_TOTALS_WORDS words.
+int vcr_depth_sort(int N, const uint32_t* depth_key, uint2* pair_a, uint2* pair_b, uint32_t* ids_sorted, uint32_t* totals,
+                   void* temp, hipStream_t st) {
+    return vcr_sort_pairs(N, depth_key, nullptr, nullptr, pair_a, pair_b, nullptr, ids_sorted, 0, 32, (uint32_t*)temp, totals, st,
+                          nullptr);
 }
 
-// (keys_a, vals_a): instance buffers; (keys_t, vals_t): a second pair; keys_b / point_list: the sorted result.
+// inst: the emitted (tile, Gaussian) records; (pair_a, pair_b): buffers of the sort's intermediate passes (pair_b may be
+// NULL when the tile bits take at most two passes); keys_b / point_list: the sorted result.
 // R: the number of instances the emission kernel writes (the host's read-back of the projection kernel's count).
 int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const uint32_t* ids_sorted,
-                           unsigned long long* status, int64_t R, int tile_bits, uint32_t* keys_a, uint32_t* vals_a,
-                           uint32_t* keys_t, uint32_t* vals_t, uint32_t* keys_b, uint32_t* point_list, uint2* ranges,
-                           uint32_t* tile_order, uint32_t* meta, int num_tiles, uint32_t* totals, void* temp,
-                           size_t temp_bytes, hipStream_t st) {
+                           unsigned long long* status, int64_t R, int tile_bits, uint2* inst, uint2* pair_a, uint2* pair_b,
+                           uint32_t* keys_b, uint32_t* point_list, uint2* ranges, uint32_t* tile_order, uint32_t* meta,
+                           int num_tiles, uint32_t* totals, void* temp, size_t temp_bytes, hipStream_t st) {
     static const bool no_lpt = getenv("VCR_NO_LPT") != nullptr;          // experiment switches
     static const bool no_snake = getenv("VCR_NO_SNAKE") != nullptr;
     if (R <= 0) {
@@ -189,10 +187,11 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
     }
     const int blocks = (a.N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS);
     uint32_t* ticket = reinterpret_cast<uint32_t*>(status + blocks + 1);
-    hipLaunchKernelGGL(duplicate_kernel, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, ticket, g.rect,
-                       keys_a, vals_a, ranges, num_tiles);
+    hipLaunchKernelGGL(duplicate_kernel, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, ticket, g.rect, inst,
+                       ranges, num_tiles);
     VCR_HIP_CHECK(hipGetLastError());
-    if (vcr_sort_pairs(R, keys_a, vals_a, keys_t, vals_t, keys_b, point_list, 0, tile_bits, (uint32_t*)temp, totals, st, nullptr)) {
+    if (vcr_sort_pairs(R, nullptr, nullptr, inst, pair_a, pair_b, keys_b, point_list, 0, tile_bits, (uint32_t*)temp, totals, st,
+                       nullptr)) {
         return 1;
     }
     const int64_t rb = (R + 255) / 256;

@@ -163,18 +163,18 @@ extern "C" int vcr_sort_pairs_u32(int64_t n, const uint32_t* keys_in, const uint
     if (!keys_in || !keys_out || !vals_out || begin_bit < 0 || end_bit > 32 || begin_bit >= end_bit) {
         vcr_set_error("vcr_sort_pairs_u32: bad arguments"); return 1;
     }
-    const size_t nb = vcr_align(sizeof(uint32_t) * (size_t)n), tot = vcr_align(sizeof(uint32_t) * VCR_SORT_TOTALS_WORDS);
-    const size_t need = 2 * nb + tot + vcr_sort_scratch_bytes(n);
+    const size_t pb = vcr_align(sizeof(uint2) * (size_t)n), tot = vcr_align(sizeof(uint32_t) * VCR_SORT_TOTALS_WORDS);
+    const size_t need = 2 * pb + tot + vcr_sort_scratch_bytes(n);
     if (!scratch || scratch_bytes < need) { vcr_set_error("vcr_sort_pairs_u32: scratch too small (%zu < %zu)", scratch_bytes, need); return 1; }
     char* s = (char*)scratch;
     hipStream_t st = (hipStream_t)stream;
-    return vcr_sort_pairs(n, keys_in, vals_in, (uint32_t*)s, (uint32_t*)(s + nb), keys_out, vals_out, begin_bit, end_bit,
-                          (uint32_t*)(s + 2 * nb + tot), (uint32_t*)(s + 2 * nb), st);
+    return vcr_sort_pairs(n, keys_in, vals_in, nullptr, (uint2*)s, (uint2*)(s + pb), keys_out, vals_out, begin_bit, end_bit,
+                          (uint32_t*)(s + 2 * pb + tot), (uint32_t*)(s + 2 * pb), st);
 }
 
 extern "C" size_t vcr_sort_pairs_u32_scratch_bytes(int64_t n) {
     if (n <= 0) return 0;
-    return 2 * vcr_align(sizeof(uint32_t) * (size_t)n) + vcr_align(sizeof(uint32_t) * VCR_SORT_TOTALS_WORDS) + vcr_sort_scratch_bytes(n);
+    return 2 * vcr_align(sizeof(uint2) * (size_t)n) + vcr_align(sizeof(uint32_t) * VCR_SORT_TOTALS_WORDS) + vcr_sort_scratch_bytes(n);
 }
 
 extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* out, vcr_alloc_fn alloc, void* user,
@@ -209,19 +209,20 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         const size_t ctr_bytes = vcr_align(sizeof(uint32_t) * VCR_CTR_WORDS);
         const size_t status_bytes = vcr_duplicate_status_bytes(N);       // look-back words + ticket of the emission kernel, zeroed with the counters
         const size_t tot_bytes = vcr_align(sizeof(uint32_t) * 2 * VCR_SORT_TOTALS_WORDS);   // digit totals of the two sorts (not zeroed)
-        char* s1 = (char*)alloc(user, VCR_BUF_SCRATCH, 5 * nb + ctr_bytes + status_bytes + tot_bytes + tmp1);
+        // [depth keys | depth order | two buffers of 8-byte (key, id) records for the sort's passes | counters ...]
+        char* s1 = (char*)alloc(user, VCR_BUF_SCRATCH, 6 * nb + ctr_bytes + status_bytes + tot_bytes + tmp1);
         if (!s1) { vcr_set_error("allocator returned NULL"); return 1; }
         uint32_t* depth_key = (uint32_t*)s1;
-        uint32_t* ids = (uint32_t*)(s1 + nb);                 // iota from preprocess; reused as the sort's second key buffer
-        uint32_t* key_sorted = (uint32_t*)(s1 + 2 * nb);
-        uint32_t* ids_sorted = (uint32_t*)(s1 + 3 * nb);
-        uint32_t* tmp_v = (uint32_t*)(s1 + 4 * nb);
-        uint32_t* ctr = (uint32_t*)(s1 + 5 * nb);
-        unsigned long long* dup_status = (unsigned long long*)(s1 + 5 * nb + ctr_bytes);
+        uint32_t* ids_sorted = (uint32_t*)(s1 + nb);
+        uint2* pair_a = (uint2*)(s1 + 2 * nb);
+        uint2* pair_b = (uint2*)(s1 + 4 * nb);
+        uint32_t* ids = nullptr;                               // (unused by the projection kernel)
+        uint32_t* ctr = (uint32_t*)(s1 + 6 * nb);
+        unsigned long long* dup_status = (unsigned long long*)(s1 + 6 * nb + ctr_bytes);
         uint32_t* vis_counter = ctr;
-        uint32_t* totals_depth = (uint32_t*)(s1 + 5 * nb + ctr_bytes + status_bytes);
+        uint32_t* totals_depth = (uint32_t*)(s1 + 6 * nb + ctr_bytes + status_bytes);
         uint32_t* totals_tile = totals_depth + VCR_SORT_TOTALS_WORDS;
-        void* temp1 = s1 + 5 * nb + ctr_bytes + status_bytes + tot_bytes;
+        void* temp1 = s1 + 6 * nb + ctr_bytes + status_bytes + tot_bytes;
         VCR_HIP_CHECK(hipMemsetAsync(ctr, 0, ctr_bytes + status_bytes, st));
         // Work launched on the optional streams must be joined on EVERY exit (the scratch buffers go back to the caller's
         // stream-ordered allocator when this call returns): error returns go through join_streams().
@@ -251,7 +252,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             int rc = vcr_launch_depth_keys(a, depth_key, ss);
             if (!rc) {
                 StageTimer tm(ST_DEPTHSORT, ss);
-                rc = vcr_depth_sort(N, depth_key, ids, tmp_v, key_sorted, ids_sorted, totals_depth, temp1, ss);
+                rc = vcr_depth_sort(N, depth_key, pair_a, pair_b, ids_sorted, totals_depth, temp1, ss);
             }
             sort_launched = true;                           // (from here on every exit joins the sort stream)
             if (hipEventRecord(e_sorted, ss) != hipSuccess) {  // no event to wait on: drain the stream instead
@@ -300,7 +301,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         VCR_HIP_CHECK_JOIN(hipEventRecord(ev, st));
         if (!split_sort) {
             StageTimer tm(ST_DEPTHSORT, st);
-            if (vcr_depth_sort(N, depth_key, ids, tmp_v, key_sorted, ids_sorted, totals_depth, temp1, st)) return join_streams();
+            if (vcr_depth_sort(N, depth_key, pair_a, pair_b, ids_sorted, totals_depth, temp1, st)) return join_streams();
         }
         // From here on the colour stream may already be running work that consumed the caller's pending SH update: every
         // error return below first joins it (the caller's retry / error handling must not see an un-joined stream).
@@ -335,14 +336,16 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         out->binning = bin_p;
         const size_t tmp2 = vcr_binning_temp_bytes(N, E, tbits);
         const size_t rbts = vcr_align(sizeof(uint32_t) * (size_t)(E > 0 ? E : 1));
-        char* s2 = (char*)alloc(user, VCR_BUF_SCRATCH, 5 * rbts + tmp2);
+        const bool third = vcr_sort_passes(tbits) > 2;      // (more than 16 tile bits: a second intermediate buffer)
+        // [emitted (tile, id) records | records of the sort's first pass | sorted tile keys | (records of a third pass)]
+        char* s2 = (char*)alloc(user, VCR_BUF_SCRATCH, (third ? 7 : 5) * rbts + tmp2);
         if (!s2) { vcr_set_error("allocator returned NULL"); return fail_joined(); }
         if (split_sort) VCR_HIP_CHECK_JOIN(hipStreamWaitEvent(st, colour_event(3), 0));  // the depth order is needed from here on
         {
             StageTimer tm(ST_BINNING, st);
-            if (vcr_duplicate_and_sort(a, g, out->radii, ids_sorted, dup_status, E, tbits, (uint32_t*)s2, (uint32_t*)(s2 + rbts),
-                                       (uint32_t*)(s2 + 2 * rbts), (uint32_t*)(s2 + 3 * rbts), (uint32_t*)(s2 + 4 * rbts),
-                                       b.point_list, b.ranges, b.tile_order, b.meta, T, totals_tile, s2 + 5 * rbts, tmp2, st))
+            if (vcr_duplicate_and_sort(a, g, out->radii, ids_sorted, dup_status, E, tbits, (uint2*)s2, (uint2*)(s2 + 2 * rbts),
+                                       third ? (uint2*)(s2 + 5 * rbts) : nullptr, (uint32_t*)(s2 + 4 * rbts),
+                                       b.point_list, b.ranges, b.tile_order, b.meta, T, totals_tile, s2 + (third ? 7 : 5) * rbts, tmp2, st))
                 return fail_joined();
         }
         out->num_rendered = R;

@@ -4,6 +4,8 @@
 //   fused multi-tensor Adam (scene/gaussian_model.py:232-262: torch.optim.Adam(lr=0, eps=1e-15), per-group lr),
 //   densification statistics (scene/gaussian_model.py:669-671, trainer.py:345).
 #include "vcr_common.h"
+#include <string.h>
+#include <math.h>
 
 namespace {
 
@@ -13,67 +15,55 @@ __device__ __forceinline__ void quat_R(float r, float x, float y, float z, float
     R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
 }
 
-// aux: bits0-1 = shortest axis, bit2 = flipped
-__global__ void __launch_bounds__(256) activate_fwd_kernel(int N, const float* __restrict__ scaling_raw,
-                                                           const float* __restrict__ rotation_raw,
-                                                           const float* __restrict__ opacity_raw,
-                                                           const float* __restrict__ xyz, const float* __restrict__ campos,
-                                                           const float* __restrict__ Rw2c, float* __restrict__ scales,
-                                                           float* __restrict__ rots, float* __restrict__ opac,
-                                                           float* __restrict__ normals, uint8_t* __restrict__ aux) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const size_t i3 = 3 * (size_t)i;
-    const float l0 = scaling_raw[i3], l1 = scaling_raw[i3 + 1], l2 = scaling_raw[i3 + 2];
-    const float s0 = expf(l0), s1 = expf(l1), s2 = expf(l2);
-    scales[i3] = s0; scales[i3 + 1] = s1; scales[i3 + 2] = s2;
-    const float4 qr = reinterpret_cast<const float4*>(rotation_raw)[i];
+// ---- per-Gaussian pieces, shared by the stand-alone kernels and the fused geometry step ---------------------------------
+struct ActOut { float s[3]; float4 q; float o; float n[3]; uint8_t aux; };
+
+// exp / normalize / sigmoid + shortest-axis normal, flipped to face away from the camera and rotated into camera space
+// (scene/gaussian_model.py:125-192, gaussian_renderer/__init__.py:95-101).  aux: bits0-1 = shortest axis, bit2 = flipped
+__device__ __forceinline__ ActOut activate_one(const float l[3], float4 qr, float oraw, const float p[3], const float* __restrict__ campos,
+                                               const float* __restrict__ Rw2c, bool want_normal) {
+    ActOut a;
+    a.s[0] = expf(l[0]); a.s[1] = expf(l[1]); a.s[2] = expf(l[2]);
     const float inv = 1.f / fmaxf(sqrtf(qr.x * qr.x + qr.y * qr.y + qr.z * qr.z + qr.w * qr.w), 1e-12f);
-    const float4 q = make_float4(qr.x * inv, qr.y * inv, qr.z * inv, qr.w * inv);
-    reinterpret_cast<float4*>(rots)[i] = q;
-    opac[i] = 1.f / (1.f + expf(-opacity_raw[i]));
-    if (!normals) return;
+    a.q = make_float4(qr.x * inv, qr.y * inv, qr.z * inv, qr.w * inv);
+    a.o = 1.f / (1.f + expf(-oraw));
+    a.n[0] = a.n[1] = a.n[2] = 0.f; a.aux = 0;
+    if (!want_normal) return a;
     int axis = 0;                              // torch.argmin: first minimum
-    float sm = s0;
-    if (s1 < sm) { sm = s1; axis = 1; }
-    if (s2 < sm) { sm = s2; axis = 2; }
+    float sm = a.s[0];
+    if (a.s[1] < sm) { sm = a.s[1]; axis = 1; }
+    if (a.s[2] < sm) { sm = a.s[2]; axis = 2; }
     float R[9];
-    quat_R(q.x, q.y, q.z, q.w, R);
+    quat_R(a.q.x, a.q.y, a.q.z, a.q.w, R);
     float n0 = R[axis], n1 = R[3 + axis], n2 = R[6 + axis];
-    const float vx = xyz[i3] - campos[0], vy = xyz[i3 + 1] - campos[1], vz = xyz[i3 + 2] - campos[2];
+    const float vx = p[0] - campos[0], vy = p[1] - campos[1], vz = p[2] - campos[2];
     const bool keep = (vx * n0 + vy * n1 + vz * n2) > 0.f;
     if (!keep) { n0 = -n0; n1 = -n1; n2 = -n2; }
-    normals[i3] = Rw2c[0] * n0 + Rw2c[1] * n1 + Rw2c[2] * n2;
-    normals[i3 + 1] = Rw2c[3] * n0 + Rw2c[4] * n1 + Rw2c[5] * n2;
-    normals[i3 + 2] = Rw2c[6] * n0 + Rw2c[7] * n1 + Rw2c[8] * n2;
-    aux[i] = (uint8_t)(axis | (keep ? 0 : 4));
+    a.n[0] = Rw2c[0] * n0 + Rw2c[1] * n1 + Rw2c[2] * n2;
+    a.n[1] = Rw2c[3] * n0 + Rw2c[4] * n1 + Rw2c[5] * n2;
+    a.n[2] = Rw2c[6] * n0 + Rw2c[7] * n1 + Rw2c[8] * n2;
+    a.aux = (uint8_t)(axis | (keep ? 0 : 4));
+    return a;
 }
 
-__global__ void __launch_bounds__(256) activate_bwd_kernel(int N, const float* __restrict__ scaling_raw,
-                                                           const float* __restrict__ rotation_raw,
-                                                           const float* __restrict__ opacity_raw,
-                                                           const float* __restrict__ Rw2c, const uint8_t* __restrict__ aux,
-                                                           const float* __restrict__ d_scales, const float* __restrict__ d_rots,
-                                                           const float* __restrict__ d_opac, const float* __restrict__ d_normals,
-                                                           const float* __restrict__ d_scaling_extra, float* __restrict__ d_scaling_raw, float* __restrict__ d_rotation_raw,
-                                                           float* __restrict__ d_opacity_raw) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const size_t i3 = 3 * (size_t)i;
+// adjoint of activate_one: gradients w.r.t. the raw scaling (gs), rotation (gq), opacity (go).  `has_*`: which upstream
+// gradients exist; ds / dq / dop / dn: upstream gradients; extra: second gradient path into the raw scaling (l1_scale).
+__device__ __forceinline__ void activate_bwd_one(const float l[3], float4 qr, float oraw, const float* __restrict__ Rw2c, uint8_t aux,
+                                                 bool has_s, const float ds[3], bool has_q, float4 dq, bool has_o, float dop,
+                                                 bool has_n, const float dn[3], const float extra[3], float gs[3], float4& gq,
+                                                 float& go) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-        d_scaling_raw[i3 + k] = (d_scales ? d_scales[i3 + k] * expf(scaling_raw[i3 + k]) : 0.f) + (d_scaling_extra ? d_scaling_extra[i3 + k] : 0.f);
-    const float o = 1.f / (1.f + expf(-opacity_raw[i]));
-    d_opacity_raw[i] = d_opac ? d_opac[i] * o * (1.f - o) : 0.f;
-    const float4 qr = reinterpret_cast<const float4*>(rotation_raw)[i];
+    for (int k = 0; k < 3; ++k) gs[k] = (has_s ? ds[k] * expf(l[k]) : 0.f) + extra[k];
+    const float o = 1.f / (1.f + expf(-oraw));
+    go = has_o ? dop * o * (1.f - o) : 0.f;
     const float inv = 1.f / fmaxf(sqrtf(qr.x * qr.x + qr.y * qr.y + qr.z * qr.z + qr.w * qr.w), 1e-12f);
     const float r = qr.x * inv, x = qr.y * inv, y = qr.z * inv, z = qr.w * inv;
     float g[4] = {0.f, 0.f, 0.f, 0.f};                 // gradient w.r.t. the unit quaternion
-    if (d_rots) { const float4 d = reinterpret_cast<const float4*>(d_rots)[i]; g[0] = d.x; g[1] = d.y; g[2] = d.z; g[3] = d.w; }
-    if (d_normals) {
-        const int axis = aux[i] & 3;
-        const float sgn = (aux[i] & 4) ? -1.f : 1.f;
-        const float c0 = d_normals[i3], c1 = d_normals[i3 + 1], c2 = d_normals[i3 + 2];
+    if (has_q) { g[0] = dq.x; g[1] = dq.y; g[2] = dq.z; g[3] = dq.w; }
+    if (has_n) {
+        const int axis = aux & 3;
+        const float sgn = (aux & 4) ? -1.f : 1.f;
+        const float c0 = dn[0], c1 = dn[1], c2 = dn[2];
         // n_cam = Rw2c * (sgn * R[:,axis])
         const float w0 = sgn * (Rw2c[0] * c0 + Rw2c[3] * c1 + Rw2c[6] * c2);
         const float w1 = sgn * (Rw2c[1] * c0 + Rw2c[4] * c1 + Rw2c[7] * c2);
@@ -91,8 +81,148 @@ __global__ void __launch_bounds__(256) activate_bwd_kernel(int N, const float* _
     }
     // q = raw/|raw|
     const float gd = g[0] * r + g[1] * x + g[2] * y + g[3] * z;
-    reinterpret_cast<float4*>(d_rotation_raw)[i] =
-        make_float4((g[0] - r * gd) * inv, (g[1] - x * gd) * inv, (g[2] - y * gd) * inv, (g[3] - z * gd) * inv);
+    gq = make_float4((g[0] - r * gd) * inv, (g[1] - x * gd) * inv, (g[2] - y * gd) * inv, (g[3] - z * gd) * inv);
+}
+
+// one Adam update (torch.optim.Adam, eps outside the bias-corrected root): step = lr / bc1
+__device__ __forceinline__ void adam_one(float& p, float& m, float& v, float g, float b1, float b2, float eps, float step,
+                                         float bc2_sqrt) {
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    p -= step * (m / (sqrtf(v) / bc2_sqrt + eps));
+}
+
+__global__ void __launch_bounds__(256) activate_fwd_kernel(int N, const float* __restrict__ scaling_raw,
+                                                           const float* __restrict__ rotation_raw,
+                                                           const float* __restrict__ opacity_raw,
+                                                           const float* __restrict__ xyz, const float* __restrict__ campos,
+                                                           const float* __restrict__ Rw2c, float* __restrict__ scales,
+                                                           float* __restrict__ rots, float* __restrict__ opac,
+                                                           float* __restrict__ normals, uint8_t* __restrict__ aux) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const size_t i3 = 3 * (size_t)i;
+    const float l[3] = {scaling_raw[i3], scaling_raw[i3 + 1], scaling_raw[i3 + 2]};
+    float p[3] = {0.f, 0.f, 0.f};
+    if (normals) { p[0] = xyz[i3]; p[1] = xyz[i3 + 1]; p[2] = xyz[i3 + 2]; }
+    const ActOut a = activate_one(l, reinterpret_cast<const float4*>(rotation_raw)[i], opacity_raw[i], p, campos, Rw2c, normals != nullptr);
+    scales[i3] = a.s[0]; scales[i3 + 1] = a.s[1]; scales[i3 + 2] = a.s[2];
+    reinterpret_cast<float4*>(rots)[i] = a.q;
+    opac[i] = a.o;
+    if (!normals) return;
+    normals[i3] = a.n[0]; normals[i3 + 1] = a.n[1]; normals[i3 + 2] = a.n[2];
+    aux[i] = a.aux;
+}
+
+__global__ void __launch_bounds__(256) activate_bwd_kernel(int N, const float* __restrict__ scaling_raw,
+                                                           const float* __restrict__ rotation_raw,
+                                                           const float* __restrict__ opacity_raw,
+                                                           const float* __restrict__ Rw2c, const uint8_t* __restrict__ aux,
+                                                           const float* __restrict__ d_scales, const float* __restrict__ d_rots,
+                                                           const float* __restrict__ d_opac, const float* __restrict__ d_normals,
+                                                           const float* __restrict__ d_scaling_extra, float* __restrict__ d_scaling_raw, float* __restrict__ d_rotation_raw,
+                                                           float* __restrict__ d_opacity_raw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const size_t i3 = 3 * (size_t)i;
+    const float l[3] = {scaling_raw[i3], scaling_raw[i3 + 1], scaling_raw[i3 + 2]};
+    float ds[3] = {0.f, 0.f, 0.f}, dn[3] = {0.f, 0.f, 0.f}, ex[3] = {0.f, 0.f, 0.f};
+    if (d_scales) { ds[0] = d_scales[i3]; ds[1] = d_scales[i3 + 1]; ds[2] = d_scales[i3 + 2]; }
+    if (d_normals) { dn[0] = d_normals[i3]; dn[1] = d_normals[i3 + 1]; dn[2] = d_normals[i3 + 2]; }
+    if (d_scaling_extra) { ex[0] = d_scaling_extra[i3]; ex[1] = d_scaling_extra[i3 + 1]; ex[2] = d_scaling_extra[i3 + 2]; }
+    float gs[3], go;
+    float4 gq;
+    activate_bwd_one(l, reinterpret_cast<const float4*>(rotation_raw)[i], opacity_raw[i], Rw2c, d_normals ? aux[i] : (uint8_t)0,
+                     d_scales != nullptr, ds, d_rots != nullptr, d_rots ? reinterpret_cast<const float4*>(d_rots)[i] : make_float4(0.f, 0.f, 0.f, 0.f),
+                     d_opac != nullptr, d_opac ? d_opac[i] : 0.f, d_normals != nullptr, dn, ex, gs, gq, go);
+    d_scaling_raw[i3] = gs[0]; d_scaling_raw[i3 + 1] = gs[1]; d_scaling_raw[i3 + 2] = gs[2];
+    d_opacity_raw[i] = go;
+    reinterpret_cast<float4*>(d_rotation_raw)[i] = gq;
+}
+
+// ---- the static tail of a training iteration in ONE pass over the Gaussians (single GPU, no surgery this iteration) ------
+// activation backward (+ the l1_scale gradient) -> densification statistics -> Adam on xyz / scaling / rotation / opacity ->
+// activation for the NEXT iteration's camera.  Replaces activate_bwd + scale_reg_bwd + densify_stats + adam + activate_fwd:
+// the raw-parameter gradients are never written, the parameters are read once.  Same per-Gaussian functions as the
+// stand-alone kernels above.
+struct GeomBias { float st[4], bc2[4]; };       // per group (xyz, scaling, rotation, opacity): lr / (1 - b1^t), sqrt(1 - b2^t)
+__global__ void __launch_bounds__(256) geometry_step_kernel(VcrGeometryStep a, GeomBias gb) {
+    const float st_xyz = gb.st[0], st_scaling = gb.st[1], st_rotation = gb.st[2], st_opacity = gb.st[3];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.N) return;
+    const size_t i3 = 3 * (size_t)i;
+    float l[3] = {a.scaling[i3], a.scaling[i3 + 1], a.scaling[i3 + 2]};
+    float4 qr = reinterpret_cast<float4*>(a.rotation)[i];
+    float oraw = a.opacity[i];
+    float p[3] = {a.xyz[i3], a.xyz[i3 + 1], a.xyz[i3 + 2]};
+    // ---- gradients w.r.t. the raw parameters
+    float ds[3] = {0.f, 0.f, 0.f}, dn[3] = {0.f, 0.f, 0.f}, ex[3] = {0.f, 0.f, 0.f};
+    if (a.d_scales) { ds[0] = a.d_scales[i3]; ds[1] = a.d_scales[i3 + 1]; ds[2] = a.d_scales[i3 + 2]; }
+    if (a.d_normals) { dn[0] = a.d_normals[i3]; dn[1] = a.d_normals[i3 + 1]; dn[2] = a.d_normals[i3 + 2]; }
+    if (a.scale_reg_sums) {          // l1_scale (trainer.py:243-245): d/d raw of mean over the box of min_axis exp(raw)
+        const bool in = fabsf((p[0] - a.trans[0]) / a.scale[0]) < 1.f && fabsf((p[1] - a.trans[1]) / a.scale[1]) < 1.f &&
+                        fabsf((p[2] - a.trans[2]) / a.scale[2]) < 1.f;
+        if (in) {
+            const int k = (l[0] <= l[1] && l[0] <= l[2]) ? 0 : (l[1] <= l[2] ? 1 : 2);           // first minimum, like torch.min
+            ex[k] = a.scale_reg_gout[0] / (float)a.scale_reg_sums[2] * __expf(fminf(l[0], fminf(l[1], l[2])));
+        }
+    }
+    float gs[3], go;
+    float4 gq;
+    activate_bwd_one(l, qr, oraw, a.Rw2c, a.d_normals ? a.aux[i] : (uint8_t)0, a.d_scales != nullptr, ds, a.d_rots != nullptr,
+                     a.d_rots ? reinterpret_cast<const float4*>(a.d_rots)[i] : make_float4(0.f, 0.f, 0.f, 0.f), a.d_opac != nullptr,
+                     a.d_opac ? a.d_opac[i] : 0.f, a.d_normals != nullptr, dn, ex, gs, gq, go);
+    // ---- densification statistics (scene/gaussian_model.py:669-671, trainer.py:345)
+    if (a.grad2d) {
+        const int r = a.radii[i];
+        if (r > 0) {
+            const float gx = a.grad2d[i3], gy = a.grad2d[i3 + 1];
+            a.accum[i] += sqrtf(gx * gx + gy * gy);
+            a.denom[i] += 1.f;
+            a.max_radii[i] = fmaxf(a.max_radii[i], (float)r);
+        }
+    }
+    // ---- Adam
+    const float b1 = a.beta1, b2 = a.beta2, eps = a.eps;
+    if (a.d_means3D) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float m = a.m_xyz[i3 + k], v = a.v_xyz[i3 + k];
+            adam_one(p[k], m, v, a.d_means3D[i3 + k], b1, b2, eps, st_xyz, gb.bc2[0]);
+            a.m_xyz[i3 + k] = m; a.v_xyz[i3 + k] = v; a.xyz[i3 + k] = p[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float m = a.m_scaling[i3 + k], v = a.v_scaling[i3 + k];
+        adam_one(l[k], m, v, gs[k], b1, b2, eps, st_scaling, gb.bc2[1]);
+        a.m_scaling[i3 + k] = m; a.v_scaling[i3 + k] = v; a.scaling[i3 + k] = l[k];
+    }
+    {
+        float4 m = reinterpret_cast<float4*>(a.m_rotation)[i], v = reinterpret_cast<float4*>(a.v_rotation)[i];
+        adam_one(qr.x, m.x, v.x, gq.x, b1, b2, eps, st_rotation, gb.bc2[2]);
+        adam_one(qr.y, m.y, v.y, gq.y, b1, b2, eps, st_rotation, gb.bc2[2]);
+        adam_one(qr.z, m.z, v.z, gq.z, b1, b2, eps, st_rotation, gb.bc2[2]);
+        adam_one(qr.w, m.w, v.w, gq.w, b1, b2, eps, st_rotation, gb.bc2[2]);
+        reinterpret_cast<float4*>(a.m_rotation)[i] = m; reinterpret_cast<float4*>(a.v_rotation)[i] = v;
+        reinterpret_cast<float4*>(a.rotation)[i] = qr;
+    }
+    {
+        float m = a.m_opacity[i], v = a.v_opacity[i];
+        adam_one(oraw, m, v, go, b1, b2, eps, st_opacity, gb.bc2[3]);
+        a.m_opacity[i] = m; a.v_opacity[i] = v; a.opacity[i] = oraw;
+    }
+    // ---- activation of the updated parameters for the next render
+    if (a.next_scales) {
+        const ActOut n = activate_one(l, qr, oraw, p, a.next_campos, a.next_Rw2c, a.next_normals != nullptr);
+        a.next_scales[i3] = n.s[0]; a.next_scales[i3 + 1] = n.s[1]; a.next_scales[i3 + 2] = n.s[2];
+        reinterpret_cast<float4*>(a.next_rots)[i] = n.q;
+        a.next_opac[i] = n.o;
+        if (a.next_normals) {
+            a.next_normals[i3] = n.n[0]; a.next_normals[i3 + 1] = n.n[1]; a.next_normals[i3 + 2] = n.n[2];
+            a.next_aux[i] = n.aux;
+        }
+    }
 }
 
 // ---- fused multi-tensor Adam ---------------------------------------------------------------------
@@ -123,11 +253,7 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamPack pk, float b1, float 
         const float gg[4] = {g4.x * gscale, g4.y * gscale, g4.z * gscale, g4.w * gscale};
         float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            mm[c] = b1 * mm[c] + (1.f - b1) * gg[c];
-            vv[c] = b2 * vv[c] + (1.f - b2) * gg[c] * gg[c];
-            pp[c] -= step * (mm[c] / (sqrtf(vv[c]) / bc2_sqrt + eps));
-        }
+        for (int c = 0; c < 4; ++c) adam_one(pp[c], mm[c], vv[c], gg[c], b1, b2, eps, step, bc2_sqrt);
         reinterpret_cast<float4*>(pk.m[t])[j] = make_float4(mm[0], mm[1], mm[2], mm[3]);
         reinterpret_cast<float4*>(pk.v[t])[j] = make_float4(vv[0], vv[1], vv[2], vv[3]);
         reinterpret_cast<float4*>(pk.p[t])[j] = make_float4(pp[0], pp[1], pp[2], pp[3]);
@@ -198,10 +324,189 @@ __global__ void __launch_bounds__(256) knn3_kernel(int N, const float* __restric
 
 }  // namespace
 
+// ---- exact 3-NN through a uniform grid (N > 2048): O(N) expected instead of the O(N^2) brute force above ------------------
+namespace {
+struct KnnGrid { float lo[3]; float h, inv_h, slack; int dim[3]; };
+
+__device__ __forceinline__ unsigned int float_order(float f) {        // monotone map float -> uint (for atomicMin / atomicMax)
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float float_unorder(unsigned int u) {
+    const unsigned int v = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    float f;
+#ifdef __HIP_DEVICE_COMPILE__
+    f = __uint_as_float(v);
+#else
+    memcpy(&f, &v, 4);
+#endif
+    return f;
+}
+
+// lohi[0..2] = min, lohi[3..5] = max (order-mapped uints; initialised to 0xFFFFFFFF / 0)
+__global__ void __launch_bounds__(256) knn_bbox_kernel(int N, const float* __restrict__ pts, unsigned int* __restrict__ lohi) {
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const float v = pts[3 * (size_t)i + k]; lo[k] = fminf(lo[k], v); hi[k] = fmaxf(hi[k], v); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        for (int o = 32; o > 0; o >>= 1) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], o)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(lohi + k, float_order(lo[k])); atomicMax(lohi + 3 + k, float_order(hi[k])); }
+    }
+}
+
+__device__ __forceinline__ int knn_cell(float v, float lo, float inv_h, int dim) {
+    const int c = (int)floorf((v - lo) * inv_h);
+    return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
+}
+
+__global__ void __launch_bounds__(256) knn_key_kernel(int N, const float* __restrict__ pts, KnnGrid g, uint32_t* __restrict__ keys) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int cx = knn_cell(pts[3 * (size_t)i], g.lo[0], g.inv_h, g.dim[0]), cy = knn_cell(pts[3 * (size_t)i + 1], g.lo[1], g.inv_h, g.dim[1]),
+              cz = knn_cell(pts[3 * (size_t)i + 2], g.lo[2], g.inv_h, g.dim[2]);
+    keys[i] = (uint32_t)((cz * g.dim[1] + cy) * g.dim[0] + cx);
+}
+
+// positions in cell order (float4: x, y, z, original index as bits) + [begin, end) of every cell
+__global__ void __launch_bounds__(256) knn_gather_kernel(int N, const float* __restrict__ pts, const uint32_t* __restrict__ keys_sorted,
+                                                         const uint32_t* __restrict__ ids_sorted, float4* __restrict__ spts,
+                                                         uint2* __restrict__ ranges) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const uint32_t id = ids_sorted[j], k = keys_sorted[j];
+    spts[j] = make_float4(pts[3 * (size_t)id], pts[3 * (size_t)id + 1], pts[3 * (size_t)id + 2], __uint_as_float(id));
+    if (j == 0) ranges[k].x = 0;
+    else {
+        const uint32_t kp = keys_sorted[j - 1];
+        if (kp != k) { ranges[kp].y = (uint32_t)j; ranges[k].x = (uint32_t)j; }
+    }
+    if (j == N - 1) ranges[k].y = (uint32_t)N;
+}
+
+// One lane per point (in cell order): grow a box of cells around the point's cell shell by shell; after every shell the
+// search stops if the third-best squared distance is not larger than the squared distance to the nearest face of the box
+// (faces on the boundary of the grid do not count: nothing lies beyond them).  Exact.
+__global__ void __launch_bounds__(256) knn_search_kernel(int N, KnnGrid g, const float4* __restrict__ spts, const uint2* __restrict__ ranges,
+                                                         float* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const float4 p = spts[j];
+    const int cx = knn_cell(p.x, g.lo[0], g.inv_h, g.dim[0]), cy = knn_cell(p.y, g.lo[1], g.inv_h, g.dim[1]),
+              cz = knn_cell(p.z, g.lo[2], g.inv_h, g.dim[2]);
+    float b0 = 3.4e38f, b1 = 3.4e38f, b2 = 3.4e38f;
+    auto visit = [&](int x, int y, int z) {
+        const uint2 rg = ranges[(size_t)(z * g.dim[1] + y) * g.dim[0] + x];
+        for (uint32_t k = rg.x; k < rg.y; ++k) {
+            if ((int)k == j) continue;
+            const float4 q = spts[k];
+            const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (d < b2) {
+                if (d < b1) { b2 = b1; if (d < b0) { b1 = b0; b0 = d; } else b1 = d; }
+                else b2 = d;
+            }
+        }
+    };
+    const int rmax = max(g.dim[0], max(g.dim[1], g.dim[2]));
+    for (int r = 0; r <= rmax; ++r) {
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, g.dim[0] - 1), y0 = max(cy - r, 0), y1 = min(cy + r, g.dim[1] - 1),
+                  z0 = max(cz - r, 0), z1 = min(cz + r, g.dim[2] - 1);
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y) {
+                if (abs(z - cz) == r || abs(y - cy) == r) {                  // a row on the shell: all of it
+                    for (int x = x0; x <= x1; ++x) visit(x, y, z);
+                } else {                                                     // an interior row: only its two ends are new
+                    if (cx - r >= 0) visit(cx - r, y, z);
+                    if (cx + r < g.dim[0]) visit(cx + r, y, z);
+                }
+            }
+        // distance from the point to the nearest face of the box that is not a face of the whole grid (nothing lies
+        // beyond those); g.slack absorbs the rounding of the face positions and of the cell assignment
+        float face = 3.4e38f;
+        if (cx - r > 0) face = fminf(face, p.x - (g.lo[0] + (float)(cx - r) * g.h));
+        if (cx + r < g.dim[0] - 1) face = fminf(face, g.lo[0] + (float)(cx + r + 1) * g.h - p.x);
+        if (cy - r > 0) face = fminf(face, p.y - (g.lo[1] + (float)(cy - r) * g.h));
+        if (cy + r < g.dim[1] - 1) face = fminf(face, g.lo[1] + (float)(cy + r + 1) * g.h - p.y);
+        if (cz - r > 0) face = fminf(face, p.z - (g.lo[2] + (float)(cz - r) * g.h));
+        if (cz + r < g.dim[2] - 1) face = fminf(face, g.lo[2] + (float)(cz + r + 1) * g.h - p.z);
+        if (face >= 3.0e38f) break;                                          // the box covers the whole grid
+        face -= g.slack;
+        if (face > 0.f && b2 <= face * face) break;
+    }
+    out[__float_as_uint(p.w)] = (b0 + b1 + b2) / 3.f;
+}
+}  // namespace
+
 extern "C" int vcr_knn3_mean_dist2(int N, const float* points, float* out, void* stream) {
     if (N <= 0) return 0;
-    hipLaunchKernelGGL(knn3_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, points, out);
-    VCR_HIP_CHECK(hipGetLastError());
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 2048) {                                         // small clouds (and N - 1 < 3 neighbours): brute force
+        hipLaunchKernelGGL(knn3_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, points, out);
+        VCR_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    // one-time initialisation: host round trips and hipMalloc are fine here
+    unsigned int* d_lohi = nullptr;
+    VCR_HIP_CHECK(hipMalloc((void**)&d_lohi, 6 * sizeof(unsigned int)));
+    unsigned int init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u}, got[6];
+    hipError_t e = hipMemcpyAsync(d_lohi, init, sizeof(init), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) { hipLaunchKernelGGL(knn_bbox_kernel, dim3(512), dim3(256), 0, st, N, points, d_lohi); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(got, d_lohi, sizeof(got), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_lohi);
+    if (e != hipSuccess) { vcr_set_error("vcr_knn3_mean_dist2: bounding box failed: %s", hipGetErrorString(e)); return 1; }
+    KnnGrid g;
+    float ext = 0.f;
+    for (int k = 0; k < 3; ++k) { g.lo[k] = float_unorder(got[k]); ext = fmaxf(ext, float_unorder(got[3 + k]) - g.lo[k]); }
+    if (!(ext > 0.f) || !(ext < 3.0e38f)) {                  // all points coincide (or non-finite input): every distance is 0 / brute force
+        hipLaunchKernelGGL(knn3_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, points, out);
+        VCR_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    int gdim = (int)cbrt((double)N / 2.0);                   // ~2 points per cell if the cloud filled its box
+    gdim = gdim < 1 ? 1 : (gdim > 256 ? 256 : gdim);
+    g.h = ext / (float)gdim * 1.0001f;
+    g.inv_h = 1.f / g.h;
+    g.slack = 4e-7f * (fmaxf(fmaxf(fabsf(g.lo[0]), fabsf(g.lo[1])), fabsf(g.lo[2])) + ext) + 1e-4f * g.h;
+    size_t ncell = 1;
+    for (int k = 0; k < 3; ++k) {
+        const int d = (int)floorf((float_unorder(got[3 + k]) - g.lo[k]) * g.inv_h) + 1;
+        g.dim[k] = d < 1 ? 1 : (d > gdim ? gdim : d);
+        ncell *= (size_t)g.dim[k];
+    }
+    int bits = 1;
+    while (((size_t)1 << bits) < ncell) ++bits;
+    const size_t nb = vcr_align(sizeof(uint32_t) * (size_t)N), pb = vcr_align(sizeof(uint2) * (size_t)N);
+    const size_t total = 3 * nb + 2 * pb + vcr_align(sizeof(float4) * (size_t)N) + vcr_align(sizeof(uint2) * ncell) +
+                         vcr_align(sizeof(uint32_t) * VCR_SORT_TOTALS_WORDS) + vcr_sort_scratch_bytes(N);
+    char* buf = nullptr;
+    VCR_HIP_CHECK(hipMalloc((void**)&buf, total));
+    char* c = buf;
+    uint32_t* keys = (uint32_t*)c; c += nb;
+    uint32_t* keys_s = (uint32_t*)c; c += nb;
+    uint32_t* ids_s = (uint32_t*)c; c += nb;
+    uint2* pa = (uint2*)c; c += pb;
+    uint2* pbuf = (uint2*)c; c += pb;
+    float4* spts = (float4*)c; c += vcr_align(sizeof(float4) * (size_t)N);
+    uint2* ranges = (uint2*)c; c += vcr_align(sizeof(uint2) * ncell);
+    uint32_t* totals = (uint32_t*)c; c += vcr_align(sizeof(uint32_t) * VCR_SORT_TOTALS_WORDS);
+    uint32_t* hist = (uint32_t*)c;
+    const int blocks = (N + 255) / 256;
+    int rc = 0;
+    e = hipMemsetAsync(ranges, 0, sizeof(uint2) * ncell, st);
+    if (e == hipSuccess) { hipLaunchKernelGGL(knn_key_kernel, dim3(blocks), dim3(256), 0, st, N, points, g, keys); e = hipGetLastError(); }
+    if (e == hipSuccess) rc = vcr_sort_pairs(N, keys, nullptr, nullptr, pa, pbuf, keys_s, ids_s, 0, bits, hist, totals, st, nullptr);
+    if (e == hipSuccess && !rc) {
+        hipLaunchKernelGGL(knn_gather_kernel, dim3(blocks), dim3(256), 0, st, N, points, keys_s, ids_s, spts, ranges);
+        hipLaunchKernelGGL(knn_search_kernel, dim3(blocks), dim3(256), 0, st, N, g, spts, ranges, out);
+        e = hipGetLastError();
+    }
+    const hipError_t es = hipStreamSynchronize(st);          // the scratch is freed below
+    (void)hipFree(buf);
+    if (rc) return 1;
+    if (e != hipSuccess || es != hipSuccess) { vcr_set_error("vcr_knn3_mean_dist2: %s", hipGetErrorString(e != hipSuccess ? e : es)); return 1; }
     return 0;
 }
 
@@ -258,6 +563,34 @@ extern "C" int vcr_adam_step(int ntensors, float* const* params, const float* co
     if (any_tail)
         hipLaunchKernelGGL(adam_tail_kernel, dim3(ntensors), dim3(64), 0, (hipStream_t)stream, pk, beta1, beta2, eps,
                            (float)bc1, (float)sqrt(bc2), grad_scale);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vcr_geometry_step(const VcrGeometryStep* args, void* stream) {
+    if (!args) { vcr_set_error("vcr_geometry_step: args is NULL"); return 1; }
+    const VcrGeometryStep& a = *args;
+    if (a.N <= 0) return 0;
+    if (!a.xyz || !a.scaling || !a.rotation || !a.opacity || !a.m_scaling || !a.v_scaling || !a.m_rotation || !a.v_rotation ||
+        !a.m_opacity || !a.v_opacity || (a.d_means3D && (!a.m_xyz || !a.v_xyz || a.step_xyz < 1)) || a.step_scaling < 1 ||
+        a.step_rotation < 1 || a.step_opacity < 1 ||
+        (a.d_normals && (!a.aux || !a.Rw2c)) || (a.scale_reg_sums && (!a.scale_reg_gout || !a.trans || !a.scale)) ||
+        (a.grad2d && (!a.radii || !a.accum || !a.denom || !a.max_radii)) ||
+        (a.next_scales && (!a.next_rots || !a.next_opac || (a.next_normals && (!a.next_campos || !a.next_Rw2c || !a.next_aux))))) {
+        vcr_set_error("vcr_geometry_step: inconsistent arguments"); return 1;
+    }
+    if ((((uintptr_t)a.rotation) | ((uintptr_t)a.m_rotation) | ((uintptr_t)a.v_rotation) | ((uintptr_t)a.d_rots) | ((uintptr_t)a.next_rots)) & 15) {
+        vcr_set_error("vcr_geometry_step: quaternion arrays must be 16-byte aligned"); return 1;
+    }
+    GeomBias gb;
+    const int steps[4] = {a.step_xyz > 0 ? a.step_xyz : 1, a.step_scaling, a.step_rotation, a.step_opacity};
+    const float lrs[4] = {a.lr_xyz, a.lr_scaling, a.lr_rotation, a.lr_opacity};
+    for (int k = 0; k < 4; ++k) {                        // same host arithmetic as vcr_adam_step
+        const double bc1 = 1.0 - pow((double)a.beta1, steps[k]), bc2 = 1.0 - pow((double)a.beta2, steps[k]);
+        gb.st[k] = lrs[k] / (float)bc1;
+        gb.bc2[k] = (float)sqrt(bc2);
+    }
+    hipLaunchKernelGGL(geometry_step_kernel, dim3((a.N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, gb);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }

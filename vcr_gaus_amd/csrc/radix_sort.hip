@@ -13,6 +13,10 @@
 //                   64; the peers of a digit inside a chunk come from one ballot per digit bit; per-wave running counts
 //                   are 16-bit, 2 x RADIX bytes per wave), reorders it through LDS so that the global writes are runs,
 //                   and scatters;
+//   * (key, value) pairs travel between the passes as ONE 8-byte record (uint2): the scatter of a pass then writes a
+//     run of equal digits as one contiguous piece of 8 x run bytes with one store per item instead of two 4-byte
+//     stores into two arrays (at 256 digits and 4096 items per workgroup a run is 16 items = one full 128-byte line
+//     instead of two half lines); only the first pass reads and the last pass writes separate arrays;
 //   * the element count may also live in DEVICE memory (`n_dev`, <= the host's n): grids are then sized for the host's
 //     upper bound and surplus workgroups return at once.
 // Nothing has to be zeroed by the caller.
@@ -33,7 +37,7 @@ __device__ __forceinline__ int64_t rs_count(int64_t n_host, const uint32_t* __re
     return n_dev ? (int64_t)*n_dev : n_host;
 }
 
-template <int BITS>
+template <int BITS, bool AOS>
 __global__ void __launch_bounds__(1024) rs_upsweep_kernel(int64_t n_host, const uint32_t* __restrict__ n_dev,
                                                                const uint32_t* __restrict__ keys, int shift, uint32_t mask,
                                                                uint32_t* __restrict__ hist) {
@@ -50,7 +54,7 @@ __global__ void __launch_bounds__(1024) rs_upsweep_kernel(int64_t n_host, const 
 #pragma unroll
     for (int c = 0; c < UC; ++c) {                         // (any order: counting only) -- all loads first
         const int64_t i = base + (int64_t)c * UT + t;
-        k[c] = i < n ? keys[i] : 0u;
+        k[c] = i < n ? keys[AOS ? 2 * i : i] : 0u;        // (AoS: the key is the first word of the 8-byte record)
     }
 #pragma unroll
     for (int c = 0; c < UC; ++c)
@@ -60,29 +64,50 @@ __global__ void __launch_bounds__(1024) rs_upsweep_kernel(int64_t n_host, const 
 }
 
 // hist[b][d] -> number of items with digit d in the blocks before b (exclusive scan down every digit column, in place);
-// totals[d] = the column sum.  One workgroup per 16 digit columns (rows are read in 64-byte pieces), 64 row groups.
+// totals[d] = the column sum.  One workgroup per 16 digit columns (rows are read in 64-byte pieces), 64 row groups of
+// consecutive blocks; a thread keeps its (at most 32) values in registers between the sum and the write-back, and all of
+// its loads are in flight together -- the first version looped `sum += hist[..]` (dependent round trips, twice) and took
+// 11 us for 256 KB.
 template <int BITS>
 __global__ void __launch_bounds__(1024) rs_scan_kernel(int64_t n_host, const uint32_t* __restrict__ n_dev,
                                                        uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
     constexpr int RADIX = 1 << BITS;
+    constexpr int KEEP = 32;                               // rows per thread held in registers (64 x 32 x 4096 = 8.4 M items)
     const int64_t n = rs_count(n_host, n_dev);
     const int nblk = (int)((n + RS_IPB - 1) / RS_IPB);
     __shared__ uint32_t part[64][17];
     const int dd = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int d = blockIdx.x * 16 + dd;
     const int per = (nblk + 63) / 64, b0 = rg * per, b1 = min(nblk, b0 + per);
+    uint32_t* col = hist + (size_t)b0 * RADIX + d;
+    const int cnt = max(b1 - b0, 0);
+    uint32_t v[KEEP];
     uint32_t sum = 0;
-    for (int b = b0; b < b1; ++b) sum += hist[(size_t)b * RADIX + d];
+    if (per <= KEEP) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) v[k] = k < cnt ? col[(size_t)k * RADIX] : 0u;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) sum += v[k];
+    } else {
+        for (int k = 0; k < cnt; ++k) sum += col[(size_t)k * RADIX];
+    }
     part[rg][dd] = sum;
     __syncthreads();
     uint32_t run = 0;
     for (int g = 0; g < rg; ++g) run += part[g][dd];
     if (rg == 63) totals[d] = run + sum;
-    for (int b = b0; b < b1; ++b) {
-        const size_t at = (size_t)b * RADIX + d;
-        const uint32_t c = hist[at];
-        hist[at] = run;
-        run += c;
+    if (per <= KEEP) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            if (k < cnt) col[(size_t)k * RADIX] = run;
+            run += v[k];
+        }
+    } else {
+        for (int k = 0; k < cnt; ++k) {
+            const uint32_t c = col[(size_t)k * RADIX];
+            col[(size_t)k * RADIX] = run;
+            run += c;
+        }
     }
 }
 
@@ -103,7 +128,9 @@ __device__ __forceinline__ uint32_t block_exclusive(uint32_t sum, uint32_t* wsum
     return base + inc - sum;
 }
 
-template <int BITS, bool IOTA>
+// IN: 0 = separate key / value arrays, 1 = key array + values 0..n-1, 2 = 8-byte (key, value) records in `keys_in`
+// OUT_AOS: 8-byte records into `keys_out`; else separate arrays (keys_out may be NULL: values only)
+template <int BITS, int IN, bool OUT_AOS>
 __global__ void __launch_bounds__(RsShape<BITS>::THREADS) rs_downsweep_kernel(int64_t n_host, const uint32_t* __restrict__ n_dev,
                                                                  const uint32_t* __restrict__ keys_in,
                                                                  const uint32_t* __restrict__ vals_in, int shift, int nbits,
@@ -134,8 +161,13 @@ __global__ void __launch_bounds__(RsShape<BITS>::THREADS) rs_downsweep_kernel(in
     for (int c = 0; c < CHUNKS; ++c) {
         const int64_t i = wbase + c * 64 + lane;
         const bool valid = i < n;
-        key[c] = valid ? keys_in[i] : 0xFFFFFFFFu;
-        val[c] = valid ? (IOTA ? (uint32_t)i : vals_in[i]) : 0u;
+        if (IN == 2) {
+            const uint2 kv = valid ? reinterpret_cast<const uint2*>(keys_in)[i] : make_uint2(0xFFFFFFFFu, 0u);
+            key[c] = kv.x; val[c] = kv.y;
+        } else {
+            key[c] = valid ? keys_in[i] : 0xFFFFFFFFu;
+            val[c] = valid ? (IN == 1 ? (uint32_t)i : vals_in[i]) : 0u;
+        }
     }
     uint32_t tot[PER], pre[PER];
     uint32_t tsum = 0;
@@ -213,8 +245,11 @@ __global__ void __launch_bounds__(RsShape<BITS>::THREADS) rs_downsweep_kernel(in
             if (j < nvalid) {
                 const uint2 kv = items[j - (int)lo];
                 const uint32_t dst = (uint32_t)j + gbase[(kv.x >> shift) & mask];
-                keys_out[dst] = kv.x;
-                vals_out[dst] = kv.y;
+                if (OUT_AOS) reinterpret_cast<uint2*>(keys_out)[dst] = kv;
+                else {
+                    if (keys_out) keys_out[dst] = kv.x;
+                    vals_out[dst] = kv.y;
+                }
             }
         }
     }
@@ -303,18 +338,25 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2* __
     }
 }
 
-template <int BITS>
+template <int BITS, int IN, bool OUT_AOS>
 void rs_pass(int64_t n, const uint32_t* n_dev, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int shift,
              int nbits, uint32_t* hist, uint32_t* totals, hipStream_t st) {
     constexpr int RADIX = 1 << BITS;
     const int nblk = (int)((n + RS_IPB - 1) / RS_IPB);
     constexpr int DT = RsShape<BITS>::THREADS;
-    hipLaunchKernelGGL((rs_upsweep_kernel<BITS>), dim3(nblk), dim3(1024), 0, st, n, n_dev, kin, shift, (1u << nbits) - 1u, hist);
+    hipLaunchKernelGGL((rs_upsweep_kernel<BITS, IN == 2>), dim3(nblk), dim3(1024), 0, st, n, n_dev, kin, shift, (1u << nbits) - 1u, hist);
     hipLaunchKernelGGL((rs_scan_kernel<BITS>), dim3(RADIX / 16), dim3(1024), 0, st, n, n_dev, hist, totals);
-    if (vin) hipLaunchKernelGGL((rs_downsweep_kernel<BITS, false>), dim3(nblk), dim3(DT), 0, st, n, n_dev, kin, vin, shift, nbits,
-                                hist, totals, kout, vout);
-    else hipLaunchKernelGGL((rs_downsweep_kernel<BITS, true>), dim3(nblk), dim3(DT), 0, st, n, n_dev, kin, vin, shift, nbits,
-                            hist, totals, kout, vout);
+    hipLaunchKernelGGL((rs_downsweep_kernel<BITS, IN, OUT_AOS>), dim3(nblk), dim3(DT), 0, st, n, n_dev, kin, vin, shift, nbits, hist,
+                       totals, kout, vout);
+}
+
+template <int BITS>
+void rs_pass_any(int in, bool out_aos, int64_t n, const uint32_t* n_dev, const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
+                 uint32_t* vout, int shift, int nbits, uint32_t* hist, uint32_t* totals, hipStream_t st) {
+#define VCR_RS(IN, OUT) rs_pass<BITS, IN, OUT>(n, n_dev, kin, vin, kout, vout, shift, nbits, hist, totals, st)
+    if (out_aos) { if (in == 0) VCR_RS(0, true); else if (in == 1) VCR_RS(1, true); else VCR_RS(2, true); }
+    else { if (in == 0) VCR_RS(0, false); else if (in == 1) VCR_RS(1, false); else VCR_RS(2, false); }
+#undef VCR_RS
 }
 
 }  // namespace
@@ -329,9 +371,8 @@ size_t vcr_sort_scratch_bytes(int64_t n) {
 // (VCR_SORT_DIGIT_BITS=11 selects 11-bit digits: 3 instead of 4 passes over the 32-bit depth keys).  Measured at 1 M keys
 // (profiles/r3_sort_ab.txt): 3 x 11 bits 88 us stand-alone / 146 us inside the step against 4 x 8 bits 79 / 137 us -- with
 // 2048 digits and 4096 items per workgroup a run of equal digits is 2 items long, so the scatter of the first passes
-// degenerates to single 4-byte stores, and the scan kernel works on 8 KB rows; the wide digits lose more per pass than the
+// degenerates to single stores, and the scan kernel works on 8 KB rows; the wide digits lose more per pass than the
 // saved pass returns.
-
 static int rs_plan(int bits, int out[4]) {
     static const int max_digit = [] { const char* e = getenv("VCR_SORT_DIGIT_BITS"); const int v = e ? atoi(e) : 8; return v < 8 ? 8 : (v > 11 ? 11 : v); }();
     int passes = bits <= 8 ? 1 : (bits <= 16 ? 2 : (bits <= 2 * max_digit ? 2 : (bits <= 3 * max_digit ? 3 : 4)));
@@ -342,27 +383,32 @@ static int rs_plan(int bits, int out[4]) {
     return passes;
 }
 
-// Sorts bits [begin_bit, end_bit) of the keys.  vals_in == nullptr means vals = 0..n-1.  The result lands in
-// (keys_out, vals_out); (keys_tmp, vals_tmp) is a second buffer pair of n words each; the inputs are left untouched.
-// `hist` holds vcr_sort_scratch_bytes(n); `totals`: VCR_SORT_TOTALS_WORDS words (need not be zeroed).  `n` is the host's
-// (upper bound of the) element count; `n_dev`, when not NULL, points to the actual count in device memory (<= n).
-int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_tmp, uint32_t* vals_tmp,
+int vcr_sort_passes(int bits) { int b[4]; return rs_plan(bits, b); }
+
+// Sorts bits [begin_bit, end_bit) of the keys, stably.  Input: separate arrays (keys_in, vals_in; vals_in == nullptr means
+// vals = 0..n-1), or 8-byte (key, value) records (pairs_in, then keys_in / vals_in are ignored).  Output: vals_out and, if
+// not NULL, keys_out (separate arrays, distinct from every other buffer).  (pair_a, pair_b): two buffers of n 8-byte records
+// for the intermediate passes (pair_b only with >= 3 passes, pair_a with >= 2); the inputs are left untouched.  `hist` holds
+// vcr_sort_scratch_bytes(n); `totals`: VCR_SORT_TOTALS_WORDS words (need not be zeroed).  `n` is the host's (upper bound of
+// the) element count; `n_dev`, when not NULL, points to the actual count in device memory (<= n).
+int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, const uint2* pairs_in, uint2* pair_a, uint2* pair_b,
                    uint32_t* keys_out, uint32_t* vals_out, int begin_bit, int end_bit, uint32_t* hist, uint32_t* totals,
                    hipStream_t st, const uint32_t* n_dev) {
     if (n <= 0) return 0;
     int bits[4];
     const int passes = rs_plan(end_bit - begin_bit, bits);
-    const uint32_t* kin = keys_in;
-    const uint32_t* vin = vals_in;
+    const uint32_t* kin = pairs_in ? reinterpret_cast<const uint32_t*>(pairs_in) : keys_in;
+    const uint32_t* vin = pairs_in ? nullptr : vals_in;
+    int in = pairs_in ? 2 : (vals_in ? 0 : 1);
     int shift = begin_bit;
     for (int p = 0; p < passes; ++p) {
-        const bool to_out = ((passes - 1 - p) & 1) == 0;             // the last pass writes (keys_out, vals_out)
-        uint32_t* kout = to_out ? keys_out : keys_tmp;
-        uint32_t* vout = to_out ? vals_out : vals_tmp;
-        if (bits[p] <= 8) rs_pass<8>(n, n_dev, kin, vin, kout, vout, shift, bits[p], hist, totals, st);
-        else rs_pass<11>(n, n_dev, kin, vin, kout, vout, shift, bits[p], hist, totals, st);
+        const bool last = p == passes - 1;
+        uint32_t* kout = last ? keys_out : reinterpret_cast<uint32_t*>((p & 1) ? pair_b : pair_a);
+        uint32_t* vout = last ? vals_out : nullptr;
+        if (bits[p] <= 8) rs_pass_any<8>(in, !last, n, n_dev, kin, vin, kout, vout, shift, bits[p], hist, totals, st);
+        else rs_pass_any<11>(in, !last, n, n_dev, kin, vin, kout, vout, shift, bits[p], hist, totals, st);
         shift += bits[p];
-        kin = kout; vin = vout;
+        kin = kout; vin = nullptr; in = 2;
     }
     VCR_HIP_CHECK(hipGetLastError());
     return 0;

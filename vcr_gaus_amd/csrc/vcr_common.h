@@ -160,17 +160,17 @@ int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const in
                                    hipStream_t st);
 size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits);
 size_t vcr_duplicate_status_bytes(int N);
-int vcr_depth_sort(int N, const uint32_t* depth_key, uint32_t* tmp_k, uint32_t* tmp_v, uint32_t* key_sorted,
-                   uint32_t* ids_sorted, uint32_t* totals, void* temp, hipStream_t st);
+int vcr_depth_sort(int N, const uint32_t* depth_key, uint2* pair_a, uint2* pair_b, uint32_t* ids_sorted, uint32_t* totals,
+                   void* temp, hipStream_t st);
 int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const uint32_t* ids_sorted,
-                           unsigned long long* status, int64_t R /* emitted instances */, int tile_bits, uint32_t* keys_a, uint32_t* vals_a,
-                           uint32_t* keys_t, uint32_t* vals_t, uint32_t* keys_b, uint32_t* point_list, uint2* ranges,
-                           uint32_t* tile_order, uint32_t* meta, int num_tiles, uint32_t* totals, void* temp,
-                           size_t temp_bytes, hipStream_t st);
+                           unsigned long long* status, int64_t R /* emitted instances */, int tile_bits, uint2* inst, uint2* pair_a,
+                           uint2* pair_b, uint32_t* keys_b, uint32_t* point_list, uint2* ranges, uint32_t* tile_order,
+                           uint32_t* meta, int num_tiles, uint32_t* totals, void* temp, size_t temp_bytes, hipStream_t st);
 // radix_sort.hip: hand-written stable radix sort of (u32 key, u32 value) pairs and the block-scheduling order
 #define VCR_SORT_TOTALS_WORDS 2048            // digit totals of one pass (the widest digit has 11 bits); need not be zeroed
 size_t vcr_sort_scratch_bytes(int64_t n);
-int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_tmp, uint32_t* vals_tmp,
+int vcr_sort_passes(int bits);
+int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, const uint2* pairs_in, uint2* pair_a, uint2* pair_b,
                    uint32_t* keys_out, uint32_t* vals_out, int begin_bit, int end_bit, uint32_t* hist, uint32_t* totals,
                    hipStream_t st, const uint32_t* n_dev = nullptr);
 int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, uint32_t* meta, int64_t instances, bool lpt, bool snake,

@@ -27,7 +27,8 @@ def unit_seed(device):
 
 class _FusedLosses(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, out, scaling_raw, xyz, gt_image, gt_normal, mask, intr, wvec, active, exp_t, depth_max, trans, scale):
+    def forward(ctx, out, scaling_raw, xyz, gt_image, gt_normal, mask, intr, wvec, active, exp_t, depth_max, trans, scale,
+                sink=None):
         lib = _lib.load()
         ctx.set_materialize_grads(False)          # (no zero-filled gradient for the non-differentiable `res` output)
         o = out.detach().contiguous()
@@ -80,6 +81,7 @@ class _FusedLosses(torch.autograd.Function):
         ctx.save_for_backward(o, gi, part, sums, sr, xz, gn, m, wvec, trans, scale)
         ctx.meta = (H, W, C, tuple(intr), tuple(active), float(exp_t), float(depth_max), n2, n3, nbits)
         ctx.scale_key = id(scaling_raw) if DEFER_SCALE_GRAD else None
+        ctx.sink = sink
         ctx.mark_non_differentiable(res)
         return total, res
 
@@ -88,7 +90,7 @@ class _FusedLosses(torch.autograd.Function):
         if ctx.sums_entry is not None:
             ctx.sums_entry[1] = False               # (the reduction results are read below, on this stream, before any reuse)
         if g_total is None:
-            return (None,) * 13
+            return (None,) * 14
         lib = _lib.load()
         o, gi, part, sums, sr, xz, gn, m, wvec, trans, scale = ctx.saved_tensors
         H, W, C, intr, active, exp_t, depth_max, n2, n3, nbits = ctx.meta
@@ -115,7 +117,10 @@ class _FusedLosses(torch.autograd.Function):
         else:
             dout[3:7].zero_()
         d_sc = None
-        if active[2]:
+        if active[2] and ctx.sink is not None and ctx.sink.armed and ctx.sink.scale_reg is None:
+            # fused static tail: the geometry step forms the l1_scale gradient itself from these factors
+            ctx.sink.scale_reg = dict(gout=gp(2), sums=s_scale, trans=trans, scale=scale, keep=(seeds, sums, sr, xz))
+        elif active[2]:
             d_sc = torch.empty_like(sr)
             _lib.check(lib.vcr_scale_reg_backward(sr.shape[0], sr.data_ptr(), xz.data_ptr(), trans.data_ptr(), scale.data_ptr(),
                                                   s_scale, gp(2), d_sc.data_ptr(), st))
@@ -123,7 +128,7 @@ class _FusedLosses(torch.autograd.Function):
             from .gaussian_model import PENDING_SCALE_GRAD
             PENDING_SCALE_GRAD[ctx.scale_key] = d_sc        # added by the activation backward of the same graph
             d_sc = None
-        return (dout, d_sc) + (None,) * 11
+        return (dout, d_sc) + (None,) * 12
 
 
 class _LossVals(dict):
@@ -153,6 +158,15 @@ class _LossVals(dict):
         return dict.__iter__(self)
 
 
+def scale_grad_from_factors(f):
+    """The l1_scale gradient [N,3] from the factors a `GeometrySink` holds (the path taken when no geometry step consumed them)."""
+    _, _, sr, xz = f["keep"]
+    d_sc = torch.empty_like(sr)
+    _lib.check(_lib.load().vcr_scale_reg_backward(sr.shape[0], sr.data_ptr(), xz.data_ptr(), f["trans"].data_ptr(), f["scale"].data_ptr(),
+                                                 f["sums"], f["gout"], d_sc.data_ptr(), _lib.stream_of(sr)))
+    return d_sc
+
+
 def fused_losses(out, model, cam, weights, it, optim_cfg, extent, mask=None):
     """-> (total, {name: value}) for the losses of `weights` that this node covers (`NAMES`)."""
     w = [float(weights.get(n, 0.0)) for n in NAMES]
@@ -169,7 +183,7 @@ def fused_losses(out, model, cam, weights, it, optim_cfg, extent, mask=None):
     depth_max = extent * optim_cfg.mask_depth_thr if optim_cfg.mask_depth_thr > 0 else 0.0
     total, res = _FusedLosses.apply(out, model._scaling, model._xyz, cam.original_image, getattr(cam, "normal", None), mask,
                                     cam.intr_scalars, cache[key], tuple(active), optim_cfg.exp_t, depth_max, model.trans,
-                                    model.scale)
+                                    model.scale, getattr(model, "_geom_sink", None))
     vals = _LossVals({"l1": res[0]})
     vals.ssim_index = res[1]
     for k in range(2, 6):

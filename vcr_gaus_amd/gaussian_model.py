@@ -30,9 +30,21 @@ GROUPS = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "obj_dc"]
 PENDING_SCALE_GRAD = {}
 
 
+class GeometrySink:
+    """Hand-over between one iteration's backward and `FusedAdam.geometry_step` (the fused static tail of the step): when a
+    model carries an ARMED sink, the backward of its fused activation does not launch its kernel but leaves the upstream
+    gradients (w.r.t. activated scales / rotations / opacities / camera normals) and what it saved here, and the fused loss
+    node leaves the factors of the l1_scale gradient instead of forming it.  One object per iteration, owned by the
+    trainer (`model._geom_sink`); nothing process-global."""
+    __slots__ = ("armed", "grads", "saved", "scale_reg")
+
+    def __init__(self):
+        self.armed, self.grads, self.saved, self.scale_reg = True, None, None, None
+
+
 class _FusedActivate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, scaling, rotation, opacity, xyz, campos, R_w2c, want_normal):
+    def forward(ctx, scaling, rotation, opacity, xyz, campos, R_w2c, want_normal, sink=None):
         lib = _lib.load()
         N = xyz.shape[0]
         dev = xyz.device
@@ -49,6 +61,7 @@ class _FusedActivate(torch.autograd.Function):
                                             nrm.data_ptr() if want_normal else None, aux.data_ptr(), _lib.stream_of(xyz)))
         ctx.save_for_backward(sr, rr, orr, Rw, aux)
         ctx.want_normal = want_normal
+        ctx.sink = sink
         ctx.scale_key = id(scaling)
         if want_normal:
             return scales, rots, opac, nrm
@@ -64,6 +77,10 @@ class _FusedActivate(torch.autograd.Function):
             return None if t is None else t.contiguous().float().data_ptr()
 
         keep = [None if t is None else t.contiguous().float() for t in (d_scales, d_rots, d_opac, d_nrm)]
+        if ctx.sink is not None and ctx.sink.armed and ctx.sink.grads is None:
+            # fused static tail: `FusedAdam.geometry_step` applies this adjoint together with Adam in one pass
+            ctx.sink.grads, ctx.sink.saved = keep, (sr, rr, orr, Rw, aux)
+            return (None,) * 8
         ds, dr, do = torch.empty_like(sr), torch.empty_like(rr), torch.empty_like(orr)
         extra = PENDING_SCALE_GRAD.pop(ctx.scale_key, None)
         if extra is not None and tuple(extra.shape) != tuple(sr.shape):      # (a stale entry under a recycled id())
@@ -72,12 +89,13 @@ class _FusedActivate(torch.autograd.Function):
                                              *[None if t is None else t.data_ptr() for t in keep],
                                              None if extra is None else extra.data_ptr(),
                                              ds.data_ptr(), dr.data_ptr(), do.data_ptr(), _lib.stream_of(sr)))
-        return ds, dr, do, None, None, None, None
+        return ds, dr, do, None, None, None, None, None
 
 
 def fused_activate(pc, camera_center, R_w2c, want_normal=True):
     """-> (scales[N,3], rotations[N,4], opacity[N,1], normals_cam[N,3]) from the raw parameters."""
-    return _FusedActivate.apply(pc._scaling, pc._rotation, pc._opacity, pc._xyz, camera_center, R_w2c, want_normal)
+    return _FusedActivate.apply(pc._scaling, pc._rotation, pc._opacity, pc._xyz, camera_center, R_w2c, want_normal,
+                                getattr(pc, "_geom_sink", None))
 
 
 class FusedAdam:
@@ -133,6 +151,51 @@ class FusedAdam:
         if only is not None:
             for g in live:
                 g["params"][0].grad = None
+
+    @torch.no_grad()
+    def geometry_step(self, model, sink, grad2d=None, radii=None):
+        """The static tail of an iteration in ONE launch (`vcr_geometry_step`): adjoint of the fused activation + l1_scale
+        gradient (from `sink`) -> densification statistics (`grad2d` [N,3] = `means2D_densify.grad`, `radii`; None = skip)
+        -> Adam on xyz / scaling / rotation / opacity.  Same arithmetic as activate-backward + `add_densification_stats` +
+        `step()` on those groups; their `.grad` must not be set elsewhere (`_xyz.grad` is consumed and cleared here)."""
+        lib = _lib.load()
+        groups = {g["name"]: g for g in self.param_groups}
+        keep, (sr, rr, orr, Rw, aux) = sink.grads, sink.saved
+        d_scales, d_rots, d_opac, d_nrm = keep
+        N = model._xyz.shape[0]
+        if N == 0:
+            return
+        for name, raw in (("scaling", sr), ("rotation", rr), ("opacity", orr)):
+            if raw.data_ptr() != groups[name]["params"][0].data_ptr():
+                raise RuntimeError(f"geometry_step: the backward saw another `{name}` tensor than the optimizer holds")
+        gx = model._xyz.grad
+        st = {k: self._state(groups[k]) for k in ("xyz", "scaling", "rotation", "opacity")}
+        for k in st:
+            if k != "xyz" or gx is not None:
+                st[k]["step"] += 1
+        ptr = lambda t: None if t is None else t.data_ptr()
+        gxc = None if gx is None else gx.contiguous()
+        sreg = sink.scale_reg
+        a = _lib.VcrGeometryStep(
+            N=N, step_xyz=st["xyz"]["step"] if gx is not None else 0, step_scaling=st["scaling"]["step"],
+            step_rotation=st["rotation"]["step"], step_opacity=st["opacity"]["step"],
+            xyz=model._xyz.data_ptr(), scaling=sr.data_ptr(), rotation=rr.data_ptr(), opacity=orr.data_ptr(),
+            d_means3D=ptr(gxc), d_scales=ptr(d_scales), d_rots=ptr(d_rots), d_opac=ptr(d_opac), d_normals=ptr(d_nrm),
+            aux=aux.data_ptr(), Rw2c=Rw.data_ptr(),
+            scale_reg_gout=None if sreg is None else sreg["gout"], scale_reg_sums=None if sreg is None else sreg["sums"],
+            trans=None if sreg is None else sreg["trans"].data_ptr(), scale=None if sreg is None else sreg["scale"].data_ptr(),
+            m_xyz=st["xyz"]["exp_avg"].data_ptr(), v_xyz=st["xyz"]["exp_avg_sq"].data_ptr(),
+            m_scaling=st["scaling"]["exp_avg"].data_ptr(), v_scaling=st["scaling"]["exp_avg_sq"].data_ptr(),
+            m_rotation=st["rotation"]["exp_avg"].data_ptr(), v_rotation=st["rotation"]["exp_avg_sq"].data_ptr(),
+            m_opacity=st["opacity"]["exp_avg"].data_ptr(), v_opacity=st["opacity"]["exp_avg_sq"].data_ptr(),
+            lr_xyz=float(groups["xyz"]["lr"]), lr_scaling=float(groups["scaling"]["lr"]), lr_rotation=float(groups["rotation"]["lr"]),
+            lr_opacity=float(groups["opacity"]["lr"]), beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+            grad2d=ptr(grad2d), radii=ptr(radii),
+            accum=None if grad2d is None else model.xyz_gradient_accum.data_ptr(),
+            denom=None if grad2d is None else model.denom.data_ptr(),
+            max_radii=None if grad2d is None else model.max_radii2D.data_ptr())
+        _lib.check(lib.vcr_geometry_step(C.byref(a), _lib.stream_of(model._xyz)))
+        model._xyz.grad = None
 
     @torch.no_grad()
     def step_sh_from_rgb(self, drgb, dirs, sh_degree, stream=None):

@@ -65,6 +65,10 @@ class Trainer:
         self._factorised_base = self.factorised_sh
         self.side = None
         self._pending_sh = None          # (drgb, view_dirs, sh_degree) of the last backward, not yet applied
+        # Fused static tail (round 3): on iterations without densify / prune / reset surgery a single process runs the adjoint
+        # of the fused activation, the l1_scale gradient, the densification statistics and Adam on xyz / scaling / rotation /
+        # opacity as ONE kernel (`FusedAdam.geometry_step`) instead of five.  VCR_NO_FUSED_GEOMETRY=1 keeps the modular form.
+        self.fuse_geometry = not os.environ.get("VCR_NO_FUSED_GEOMETRY")
         # third stream: depth keys + depth sort beside the projection (two-stream form only).  Measured: neutral at 1-2 M
         # Gaussians (1.61 vs 1.61, 2.50-2.58 vs 2.49-2.58 ms/step), -4 % at 5 M (4.53 vs 4.74), where the 8 sort launches
         # over 5 M keys are long enough to matter: used from 3 M Gaussians on.
@@ -433,28 +437,52 @@ class Trainer:
                              self._launch_pending_sh if (overlap and not fuse) else None,
                              self._pending_sh_update if fuse else None,
                              self.sort_stream if (overlap and m._xyz.shape[0] >= self.sort_stream_min_gaussians) else None)
-        data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True, geometry=not fused, raster_options=opts)
-        if self._pending_sh is not None:         # the render did not go through the two-stream path (e.g. no Gaussians)
-            self.join_side()
+        surgery = (it < cfg.optim.densify_until_iter and it > cfg.optim.densify_from_iter
+                   and it % cfg.optim.densification_interval == 0) \
+            or it % cfg.optim.opacity_reset_interval == 0 or it in cfg.optim.prune.iterations \
+            or (cfg.model.white_background and it == cfg.optim.densify_from_iter)
         from . import fused_losses, gaussian_model
-        fused_losses.DEFER_SCALE_GRAD = True        # l1_scale's gradient joins the activation backward's kernel (same graph)
-        left, ok = None, False
+        # the fused static tail needs every gradient path into scaling / rotation / opacity to pass through the fused
+        # activation node (the fused loss node guarantees that), un-reduced gradients (one process) and unchanged rows
+        sink = None
+        if self.fuse_geometry and fused and not surgery and self.world == 1 and not getattr(self, "force_collectives", False) \
+                and m._xyz.is_cuda and m._xyz.shape[0] > 0 and not cfg.pipline.compute_cov3D_python:
+            sink = gaussian_model.GeometrySink()
+        m._geom_sink = sink
         try:
-            loss = self._compute_loss(data, cam)
-            loss.backward(fused_losses.unit_seed(loss.device))
-            ok = True
+            data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True, geometry=not fused, raster_options=opts)
+            if self._pending_sh is not None:     # the render did not go through the two-stream path (e.g. no Gaussians)
+                self.join_side()
+            fused_losses.DEFER_SCALE_GRAD = True    # l1_scale's gradient joins the activation backward's kernel (same graph)
+            left, ok = None, False
+            try:
+                loss = self._compute_loss(data, cam)
+                loss.backward(fused_losses.unit_seed(loss.device))
+                ok = True
+            finally:
+                fused_losses.DEFER_SCALE_GRAD = False
+                left = gaussian_model.PENDING_SCALE_GRAD.pop(id(m._scaling), None)     # never survives the step, also on errors
         finally:
-            fused_losses.DEFER_SCALE_GRAD = False
-            left = gaussian_model.PENDING_SCALE_GRAD.pop(id(m._scaling), None)     # never survives the step, also on errors
+            m._geom_sink = None
+            if sink is not None:
+                sink.armed = False
+        if sink is not None and sink.grads is None and sink.scale_reg is not None:
+            left = fused_losses.scale_grad_from_factors(sink.scale_reg)        # (no activation backward ran: ordinary path)
         if ok and left is not None:                 # (no activation backward consumed it: add it the ordinary way)
             m._scaling.grad = left if m._scaling.grad is None else m._scaling.grad + left
+        geom = sink is not None and sink.grads is not None
         with torch.no_grad():
-            surgery = (it < cfg.optim.densify_until_iter and it > cfg.optim.densify_from_iter
-                       and it % cfg.optim.densification_interval == 0) \
-                or it % cfg.optim.opacity_reset_interval == 0 or it in cfg.optim.prune.iterations \
-                or (cfg.model.white_background and it == cfg.optim.densify_from_iter)
             self._exchange_grads(overlap, surgery, data["raster"])
-            if it < cfg.optim.densify_until_iter:
+            if geom:
+                # activation adjoint + l1_scale gradient + densification statistics + Adam on the four geometry groups
+                stats = it < cfg.optim.densify_until_iter
+                vp = data["viewspace_points_densify"]
+                m.optimizer.geometry_step(m, sink, grad2d=vp.grad.contiguous() if (stats and vp.grad is not None) else None,
+                                          radii=data["radii"] if stats else None)
+                if stats and it > cfg.optim.densify_from_iter and "countlist" in data:                  # `trainer.py:350-356`
+                    cl = data["countlist"]
+                    self.visi_list = cl if self.visi_list is None else self.visi_list + cl
+            if it < cfg.optim.densify_until_iter and not geom:
                 self._densify_stats(data)
                 if it > cfg.optim.densify_from_iter and "countlist" in data and not self._stats_dirty:        # `trainer.py:350-356`
                     cl = data["countlist"]                # (data parallel: `_densify_stats` accumulated it with the other deltas)
