@@ -429,22 +429,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 
             if (S > 0) srec[4 * 64 + lane] = qs;
         }
         __builtin_amdgcn_wave_barrier();
-        // Shading + gradient of one survivor whose staged record sits in R0..R3 (see the forward kernel for the staging).
-        // Branch-free inside: lanes without a hit run with alpha = 0, which makes T, Bsuf and every slot a no-op / zero.
-        // Slots are RAW sums; preprocess_bwd applies the per-Gaussian constants (GradRec in vcr_common.h).
-#define VCR_SHADE_BWD(R, B)                                                                                              \
-        do {                                                                                                             \
-            const float4 r0 = R##0, r1 = R##1, r2 = R##2, r3 = R##3; const int sb_ = (B);                                \
-            const uint32_t idx1 = (uint32_t)chunk * 64u + (uint32_t)sb_ + 1u;                                            \
-            const f2 gxy = {r0.x, r0.y}, sAC = {r0.z, r0.w};                                                             \
-            const f2 d = gxy - fxy;                                                                                      \
-            f2 u; float hs;                                                                                              \
-            const float e = gauss_exponent(d, sAC, r1.x, r1.y, u, hs);                                                   \
-            const float araw = __builtin_amdgcn_exp2f(e);                                                                \
-            const bool hit = idx1 <= lastc && hs <= 0.f && araw >= VCR_ALPHA_MIN;                                        \
-            const unsigned long long hitm_ = __builtin_amdgcn_ballot_w64(hit);                                           \
-            VCR_COUNT_HITS(65, hitm_);                                                                                   \
-            if (hitm_ != 0) {                                                                                            \
+        // Gradient slots of one (pixel, Gaussian) pair: expects r1..r3 (staged record), d, u, araw and `hit` in scope; defines
+        // gid, v[8] (16 raw slots, GradRec order) and vs[S]; updates T and Bsuf.  Lanes without a hit produce zeros.
+#define VCR_BWD_MATH(R)                                                                                                  \
             const f2 c01 = {r2.x, r2.y}, c2n = {r2.z, r2.w}, n12 = {r3.x, r3.y};                                         \
             const float zc = r1.z, pl = r1.w;                                                                            \
             const uint32_t gid = __float_as_uint(r3.z);                                                                  \
@@ -498,7 +485,24 @@ _Pragma("unroll")                                                               
                 v[7] = pk_fma(splat(k2), ryz, ww * g56);                                                                 \
 _Pragma("unroll")                                                                                                        \
                 for (int k = 0; k < S; ++k) vs[k] = w * g[8 + k];                                                        \
-            }                                                                                                            \
+            }
+        // Shading + gradient of one survivor whose staged record sits in R0..R3 (see the forward kernel for the staging).
+        // Branch-free inside: lanes without a hit run with alpha = 0, which makes T, Bsuf and every slot a no-op / zero.
+        // Slots are RAW sums; preprocess_bwd applies the per-Gaussian constants (GradRec in vcr_common.h).
+#define VCR_SHADE_BWD(R, B)                                                                                              \
+        do {                                                                                                             \
+            const float4 r0 = R##0, r1 = R##1, r2 = R##2, r3 = R##3; const int sb_ = (B);                                \
+            const uint32_t idx1 = (uint32_t)chunk * 64u + (uint32_t)sb_ + 1u;                                            \
+            const f2 gxy = {r0.x, r0.y}, sAC = {r0.z, r0.w};                                                             \
+            const f2 d = gxy - fxy;                                                                                      \
+            f2 u; float hs;                                                                                              \
+            const float e = gauss_exponent(d, sAC, r1.x, r1.y, u, hs);                                                   \
+            const float araw = __builtin_amdgcn_exp2f(e);                                                                \
+            const bool hit = idx1 <= lastc && hs <= 0.f && araw >= VCR_ALPHA_MIN;                                        \
+            const unsigned long long hitm_ = __builtin_amdgcn_ballot_w64(hit);                                           \
+            VCR_COUNT_HITS(65, hitm_);                                                                                   \
+            if (hitm_ != 0) {                                                                                            \
+            VCR_BWD_MATH(R);                                                                                             \
             if (VCR_BWD_SPARSE_HITS > 0 && __popcll(hitm_) <= VCR_BWD_SPARSE_HITS) {                                    \
                 /* one or two pixels hit: no wave reduction -- the hitting lanes add their 16 values themselves            */ \
                 if (hit) {                                                                                               \
@@ -551,6 +555,205 @@ _Pragma("unroll")                                                               
     }
 }
 
+// ================= backward, row-packed: four 4x4 sub-blocks of the quad walk their OWN survivor lists ======================
+// The survivors of the 8x8 culling hit 10 of the 64 pixels on average (profiles/r3_hit_histogram_metric.txt) -- the wave
+// shades 64 lanes for them all the same.  Here lane l = 16 r + i owns pixel (4 (r & 1) + (i & 3), 4 (r >> 1) + (i >> 2)) of
+// the quad: DPP row r is the 4x4 sub-block r.  The cullers test each list entry against the four sub-blocks' live boxes
+// (four ballots), and the shading loop then advances the four rows INDEPENDENTLY -- each row pops its own next survivor
+// (per-lane LDS address, a broadcast read within the row), so an iteration carries up to four different Gaussians and the
+// loop runs max_r |list_r| times instead of |union_r list_r|.  The 16 slots reduce inside the row only (mirror butterfly on
+// DPP, no cross-row traffic) and lane i of every row adds slot i of ITS Gaussian: one atomic instruction per iteration,
+// as before.  T / Bsuf are per-pixel state, so rows need not agree on where they are in the list.
+__device__ __forceinline__ PixelMap pixel_of_thread_rows(int tile, int gx, int W, int H, int sub) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = lane >> 4, i = lane & 15;
+    PixelMap p;
+    p.x = (tile % gx) * VCR_TILE + (wv & 1) * 8 + (r & 1) * 4 + (i & 3);
+    p.y = (tile / gx) * VCR_TILE + (wv >> 1) * 8 + (r >> 1) * 4 + (i >> 2);
+    p.inside = p.x < W && p.y < H && (sub < 0 || r == sub);      // split work items: the wave owns row `sub` only
+    p.pix = p.y * W + p.x;
+    return p;
+}
+
+// bounding box of the live lanes of one row (bit i = pixel (i & 3, i >> 2) of the 4x4 block at (X0, Y0))
+__device__ __forceinline__ void live_box16(unsigned live, float X0, float Y0, float& bx0, float& by0, float& bw, float& bh) {
+    const int y0 = __builtin_ctz(live) >> 2, y1 = (31 - __builtin_clz(live)) >> 2;
+    unsigned c = live | (live >> 8);
+    c |= c >> 4;
+    const unsigned cols = c & 0xFu;
+    const int x0 = __builtin_ctz(cols), x1 = 31 - __builtin_clz(cols);
+    bx0 = X0 + (float)x0; by0 = Y0 + (float)y0; bw = (float)(x1 - x0); bh = (float)(y1 - y0);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+
+// Sum 16 per-lane values (slot 2j = v[j].x, 2j+1 = v[j].y) over the 16 lanes of each DPP row; lane i of the row returns the
+// row total of slot i.  Halving butterfly on involutive lane permutations (row_mirror, row_half_mirror, reversed quad,
+// swapped pairs): at each level a lane keeps the half of its live slots that its position selects and receives the
+// partner's copy of the same slots.
+__device__ __forceinline__ float row_reduce16(const f2 v[8], int lane) {
+    const bool h1 = lane & 8, h2 = lane & 4, h3 = lane & 2, h4 = lane & 1;
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[2 * j]     = (h1 ? v[4 + j].x : v[j].x) + dpp_get<0x140>(h1 ? v[j].x : v[4 + j].x);      // row_mirror
+        a[2 * j + 1] = (h1 ? v[4 + j].y : v[j].y) + dpp_get<0x140>(h1 ? v[j].y : v[4 + j].y);
+    }
+    float b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = (h2 ? a[4 + j] : a[j]) + dpp_get<0x141>(h2 ? a[j] : a[4 + j]);   // row_half_mirror
+    float c[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) c[j] = (h3 ? b[2 + j] : b[j]) + dpp_get<0x1B>(h3 ? b[j] : b[2 + j]);    // quad_perm [3,2,1,0]
+    return (h4 ? c[1] : c[0]) + dpp_get<0xB1>(h4 ? c[0] : c[1]);                                       // quad_perm [1,0,3,2]
+}
+
+template <int S, bool ISECT, int ND>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) composite_bwd_rows_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
+                                                               const float* __restrict__ semv,
+                                                               const uint32_t* __restrict__ point_list,
+                                                               const uint2* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ meta,
+                                                               int num_tiles, const float* __restrict__ final_T,
+                                                               const uint32_t* __restrict__ n_contrib,
+                                                               const float* __restrict__ moments,
+                                                               const float* __restrict__ dL_dout, GradRec* __restrict__ sgrad,
+                                                               float* __restrict__ sgrad_sem) {
+    const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
+    int sub;
+    const int tile = work_item(tile_order, meta, num_tiles, sub);
+    if (tile < 0) return;
+    const PixelMap pm = pixel_of_thread_rows(tile, gx, a.W, a.H, sub);
+    const uint2 range = ranges[tile];
+    const int P = a.H * a.W;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = lane >> 4;
+    constexpr bool SEM_IN_REC = false;
+    constexpr int WREC = S > 0 ? 320 : 256;
+    __shared__ float4 s_rec_all[4 * WREC];
+    float4* const srec = s_rec_all + wv * WREC;
+    const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8);
+    const float Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8);
+    const f2 fxy = {(float)pm.x, (float)pm.y};
+    float rx = 0.f, ry = 0.f, rz = 1.f;
+    if (ISECT && pm.inside) { rx = a.dirs[pm.pix]; ry = a.dirs[P + pm.pix]; rz = a.dirs[2 * P + pm.pix]; }
+
+    float g[8 + (S > 0 ? S : 0)];
+#pragma unroll
+    for (int c = 0; c < 8 + S; ++c) g[c] = pm.inside ? dL_dout[c * (size_t)P + pm.pix] : 0.f;
+    float gm2 = 0.f;
+    if (ND == 2 && pm.inside) { g[3] += dL_dout[(8 + S) * (size_t)P + pm.pix]; gm2 = dL_dout[(9 + S) * (size_t)P + pm.pix]; }
+    const float Tf = pm.inside ? final_T[pm.pix] : 1.f;
+    float gm1 = 0.f;
+    const float zc_map = VCR_ZFAR / (VCR_ZFAR - VCR_ZNEAR);
+    if (ND == 1 && pm.inside) {
+        const float gd = dL_dout[(8 + S) * (size_t)P + pm.pix];
+        const float m1 = moments[pm.pix], m2 = moments[P + pm.pix];
+        gm1 = -2.f * m1 * gd; gm2 = (1.f - Tf) * gd; g[7] += m2 * gd;
+    }
+    const uint32_t lastc = pm.inside ? n_contrib[pm.pix] : 0u;
+    const float bgdot = Tf * (a.bg[0] * g[0] + a.bg[1] * g[1] + a.bg[2] * g[2]);
+    uint32_t maxc = lastc;
+    for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, o));
+    if (maxc == 0) return;                                 // wave-uniform
+    float T = Tf, Bsuf = bgdot;
+    const f2 g01 = {g[0], g[1]}, g24 = {g[2], g[4]}, g56 = {g[5], g[6]}, ryz = {ry, rz};
+
+    int chunk = (int)((maxc - 1) / 64);
+    uint32_t id, nid; float4 q0, q1, q2, q3, qs = {0.f, 0.f, 0.f, 0.f}; bool valid, nvalid;
+    const uint32_t lim = range.x + maxc;
+    VCR_LOAD_ID(range.x + (uint32_t)chunk * 64u + lane, lim, id, valid);
+    VCR_GATHER_REC(id, q0, q1, q2, q3);
+    VCR_GATHER_SEM(id, qs);
+    VCR_LOAD_ID(chunk > 0 ? range.x + (uint32_t)(chunk - 1) * 64u + lane : lim, lim, nid, nvalid);
+    for (; chunk >= 0; --chunk) {
+        uint32_t nnid; float4 nq0, nq1, nq2, nq3, nqs = {0.f, 0.f, 0.f, 0.f}; bool nnvalid;
+        VCR_GATHER_REC(nid, nq0, nq1, nq2, nq3);
+        VCR_GATHER_SEM(nid, nqs);
+        VCR_LOAD_ID(chunk > 1 ? range.x + (uint32_t)(chunk - 2) * 64u + lane : lim, lim, nnid, nnvalid);
+        // cull against the live box of each 4x4 sub-block; one survivor mask per row
+        const unsigned long long live = __builtin_amdgcn_ballot_w64(lastc > (uint32_t)chunk * 64u);
+        unsigned long long mr[4];
+        bool keep = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned lr = (unsigned)(live >> (16 * r)) & 0xFFFFu;
+            bool k = false;
+            if (lr != 0) {                                   // wave-uniform
+                float bx0, by0, bw, bh;
+                live_box16(lr, X0 + (float)((r & 1) * 4), Y0 + (float)((r >> 1) * 4), bx0, by0, bw, bh);
+                k = valid && quad_touch(q0, q1, bx0, by0, bw, bh);
+            }
+            mr[r] = __builtin_amdgcn_ballot_w64(k);
+            keep |= k;
+        }
+        if (keep) {
+            srec[0 * 64 + lane] = make_float4(q0.x, q0.y, -VCR_L2E * q1.x, -VCR_L2E * q1.z);
+            srec[1 * 64 + lane] = make_float4(-VCR_L2E * q1.y, __builtin_amdgcn_logf(q0.w), q0.z, q1.w);
+            srec[2 * 64 + lane] = make_float4(q2.x, q2.y, q2.z, q3.x);
+            srec[3 * 64 + lane] = make_float4(q3.y, q3.z, __uint_as_float(id), 0.f);
+            if (S > 0) srec[4 * 64 + lane] = qs;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long many = mr[0] | mr[1] | mr[2] | mr[3];
+        if (many && !(VCR_KO & 1)) {
+            const int iters = max(max(__popcll(mr[0]), __popcll(mr[1])), max(__popcll(mr[2]), __popcll(mr[3])));
+            unsigned long long mrow = row == 0 ? mr[0] : (row == 1 ? mr[1] : (row == 2 ? mr[2] : mr[3]));
+            // a row whose list is exhausted keeps shading a staged (finite) record with hit = false
+            int b = 63 - __builtin_clzll(many);
+            bool act;
+#define VCR_ROW_NEXT(B, ACT)                                                           \
+            do {                                                                        \
+                ACT = mrow != 0;                                                        \
+                B = ACT ? 63 - __builtin_clzll(mrow) : B;                               \
+                mrow = ACT ? mrow & ~(1ull << B) : 0ull;                                \
+            } while (0)
+#define VCR_SHADE_BWD_ROWS(R, B, ACT)                                                                                     \
+            do {                                                                                                           \
+                const float4 r0 = R##0, r1 = R##1, r2 = R##2, r3 = R##3;                                                   \
+                const uint32_t idx1 = (uint32_t)chunk * 64u + (uint32_t)(B) + 1u;                                          \
+                const f2 gxy = {r0.x, r0.y}, sAC = {r0.z, r0.w};                                                           \
+                const f2 d = gxy - fxy;                                                                                    \
+                f2 u; float hs;                                                                                            \
+                const float e = gauss_exponent(d, sAC, r1.x, r1.y, u, hs);                                                 \
+                const float araw = __builtin_amdgcn_exp2f(e);                                                              \
+                const bool hit = (ACT) && idx1 <= lastc && hs <= 0.f && araw >= VCR_ALPHA_MIN;                             \
+                const unsigned long long hitm_ = __builtin_amdgcn_ballot_w64(hit);                                         \
+                if (hitm_ != 0) {                                                                                          \
+                    VCR_BWD_MATH(R);                                                                                       \
+                    const float tot = row_reduce16(v, lane);                                                               \
+                    if (tot != 0.f) atomicAdd(reinterpret_cast<float*>(sgrad + gid) + (lane & 15), tot);                   \
+                    if (S > 0) {                                                                                           \
+                        float ts = 0.f;                                                                                    \
+_Pragma("unroll")                                                                                                          \
+                        for (int k = 0; k < S; ++k) { const float t = row_sum16(vs[k]); ts = (lane & 15) == k ? t : ts; }  \
+                        if ((lane & 15) < S && ts != 0.f) atomicAdd(sgrad_sem + (size_t)gid * S + (lane & 15), ts);        \
+                    }                                                                                                      \
+                }                                                                                                          \
+            } while (0)
+            float4 A0, A1, A2, A3, A4 = {0.f, 0.f, 0.f, 0.f}, B0, B1, B2, B3, B4 = {0.f, 0.f, 0.f, 0.f};
+            int nb = b; bool nact;
+            VCR_ROW_NEXT(b, act);
+            VCR_LDS_FETCH(A, b);
+            for (int it = 0;;) {
+                nb = b;
+                VCR_ROW_NEXT(nb, nact);
+                VCR_LDS_FETCH(B, nb);
+                VCR_SHADE_BWD_ROWS(A, b, act);
+                if (++it >= iters) break;
+                b = nb;
+                VCR_ROW_NEXT(b, act);
+                VCR_LDS_FETCH(A, b);
+                VCR_SHADE_BWD_ROWS(B, nb, nact);
+                if (++it >= iters) break;
+            }
+        }
+        id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; qs = nqs; valid = nvalid; nid = nnid; nvalid = nnvalid;
+    }
+}
+
 template <int S, bool ISECT, int ND>
 int launch_fwd_fc(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o, int tiles,
                   hipStream_t st) {
@@ -582,9 +785,16 @@ int launch_fwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
 template <bool ISECT, int ND>
 int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, const float* dL_dout, GradRec* sgrad,
                  float* sgrad_sem, int tiles, hipStream_t st) {
+    static const bool rows = []() { const char* e = getenv("VCR_BWD_ROWS"); return e ? atoi(e) != 0 : true; }();
 #define VCR_BWD(SS)                                                                                              \
-    hipLaunchKernelGGL((composite_bwd_v2_kernel<SS, ISECT, ND>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem,  \
-                       b.point_list, b.ranges, b.tile_order, b.meta, tiles, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem)
+    do {                                                                                                         \
+        if (rows)                                                                                                \
+            hipLaunchKernelGGL((composite_bwd_rows_kernel<SS, ISECT, ND>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
+                               b.point_list, b.ranges, b.tile_order, b.meta, tiles, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem); \
+        else                                                                                                     \
+            hipLaunchKernelGGL((composite_bwd_v2_kernel<SS, ISECT, ND>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
+                               b.point_list, b.ranges, b.tile_order, b.meta, tiles, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem); \
+    } while (0)
     switch (a.S) {
         case 0: VCR_BWD(0); break;
         case 1: VCR_BWD(1); break;
