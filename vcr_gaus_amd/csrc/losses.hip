@@ -385,14 +385,20 @@ struct GaussWin { float w[11]; };
 // One workgroup = 32x16 output pixels of one channel.  The (32+10)x(16+10) halo of both images is staged in LDS and the 11x11
 // window is evaluated separably with REGISTER sliding windows: every lane produces 4 adjacent outputs in the horizontal pass (14
 // loaded values feed 4 x 11 taps) and 2 in the vertical pass, ~3x fewer LDS reads per output pixel than the one-output-per-
-// lane form (LDS-bound: 84 us at 1080p).  Zero padding as F.conv2d(padding=5).
+// lane form (LDS-bound: 84 us at 1080p).  The five window sums travel in natural pairs -- (a, b), (a^2, b^2) and a b alone --
+// on packed fp32 (v_pk_fma_f32: 3 instructions per tap instead of 5; the kernel is VALU-bound).  Zero padding as
+// F.conv2d(padding=5).
 // sums[0] += sum |a-b| ; sums[1] += sum ssim_map.  If `part` != null stores d ssim / d{mu1, sigma1^2, sigma12}.
+typedef float lf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lf2 lpk_fma(lf2 a, lf2 b, lf2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 __global__ void __launch_bounds__(256) l1_ssim_fwd_kernel(int H, int W, GaussWin gw, const float* __restrict__ img1,
                                                           const float* __restrict__ img2, double* __restrict__ sums,
                                                           float* __restrict__ part) {
-    __shared__ float s_a[SSIM_HH][SSIM_HS];
-    __shared__ float s_b[SSIM_HH][SSIM_HS];
-    __shared__ float s_h[5][SSIM_HH][SSIM_TX + 1];
+    __shared__ lf2 s_ab[SSIM_HH][SSIM_HS];                 // (a, b)
+    __shared__ lf2 s_hm[SSIM_HH][SSIM_TX + 1];             // row sums of (a, b)
+    __shared__ lf2 s_hq[SSIM_HH][SSIM_TX + 1];             // row sums of (a^2, b^2)
+    __shared__ float s_hx[SSIM_HH][SSIM_TX + 1];           // row sums of a b
     const int c = blockIdx.z, x0 = blockIdx.x * SSIM_TX, y0 = blockIdx.y * SSIM_TY;
     const size_t P = (size_t)H * W;
     const float* A = img1 + c * P;
@@ -400,50 +406,52 @@ __global__ void __launch_bounds__(256) l1_ssim_fwd_kernel(int H, int W, GaussWin
     for (int t = threadIdx.x; t < SSIM_HW * SSIM_HH; t += 256) {
         const int ly = t / SSIM_HW, lx = t % SSIM_HW, gx = x0 + lx - SSIM_R, gy = y0 + ly - SSIM_R;
         const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
-        s_a[ly][lx] = in ? A[(size_t)gy * W + gx] : 0.f;
-        s_b[ly][lx] = in ? B[(size_t)gy * W + gx] : 0.f;
+        s_ab[ly][lx] = in ? lf2{A[(size_t)gy * W + gx], B[(size_t)gy * W + gx]} : lf2{0.f, 0.f};
     }
     __syncthreads();
     // horizontal pass: item = (halo row, group of 4 output columns)
     for (int it = threadIdx.x; it < SSIM_HH * (SSIM_TX / 4); it += 256) {
         const int ly = it / (SSIM_TX / 4), lx0 = (it % (SSIM_TX / 4)) * 4;
-        float a[14], b[14];
+        lf2 m[4], q[4];
+        float x[4];
 #pragma unroll
-        for (int k = 0; k < 14; ++k) { a[k] = s_a[ly][lx0 + k]; b[k] = s_b[ly][lx0 + k]; }
-        float m1[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f}, q11[4] = {0.f, 0.f, 0.f, 0.f},
-              q22[4] = {0.f, 0.f, 0.f, 0.f}, q12[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < 4; ++o) { m[o] = lf2{0.f, 0.f}; q[o] = lf2{0.f, 0.f}; x[o] = 0.f; }
 #pragma unroll
         for (int k = 0; k < 14; ++k) {
-            const float aa = a[k] * a[k], bb = b[k] * b[k], ab = a[k] * b[k];
+            const lf2 ab = s_ab[ly][lx0 + k];
+            const lf2 sq = ab * ab;
+            const float cr = ab.x * ab.y;
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 if (k - o >= 0 && k - o < 11) {
                     const float w = gw.w[k - o];
-                    m1[o] += w * a[k]; m2[o] += w * b[k]; q11[o] += w * aa; q22[o] += w * bb; q12[o] += w * ab;
+                    m[o] = lpk_fma(lf2{w, w}, ab, m[o]); q[o] = lpk_fma(lf2{w, w}, sq, q[o]); x[o] += w * cr;
                 }
             }
         }
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            s_h[0][ly][lx0 + o] = m1[o]; s_h[1][ly][lx0 + o] = m2[o]; s_h[2][ly][lx0 + o] = q11[o];
-            s_h[3][ly][lx0 + o] = q22[o]; s_h[4][ly][lx0 + o] = q12[o];
-        }
+        for (int o = 0; o < 4; ++o) { s_hm[ly][lx0 + o] = m[o]; s_hq[ly][lx0 + o] = q[o]; s_hx[ly][lx0 + o] = x[o]; }
     }
     __syncthreads();
-    // vertical pass: lane = (column, group of 4 output rows)
+    // vertical pass: lane = (column, group of SSIM_VO output rows)
     const int lx = threadIdx.x & 31, ly0 = (threadIdx.x >> 5) * SSIM_VO;
-    float r[5][SSIM_VO];
+    lf2 rm[SSIM_VO], rq[SSIM_VO];
+    float rx[SSIM_VO];
+    {
+        lf2 cm[10 + SSIM_VO], cq[10 + SSIM_VO];
+        float cx[10 + SSIM_VO];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        float col[10 + SSIM_VO];
-#pragma unroll
-        for (int k = 0; k < 10 + SSIM_VO; ++k) col[k] = s_h[q][ly0 + k][lx];
+        for (int k = 0; k < 10 + SSIM_VO; ++k) { cm[k] = s_hm[ly0 + k][lx]; cq[k] = s_hq[ly0 + k][lx]; cx[k] = s_hx[ly0 + k][lx]; }
 #pragma unroll
         for (int o = 0; o < SSIM_VO; ++o) {
-            float t = 0.f;
+            lf2 tm = {0.f, 0.f}, tq = {0.f, 0.f};
+            float tx = 0.f;
 #pragma unroll
-            for (int k = 0; k < 11; ++k) t += gw.w[k] * col[o + k];
-            r[q][o] = t;
+            for (int k = 0; k < 11; ++k) {
+                const float w = gw.w[k];
+                tm = lpk_fma(lf2{w, w}, cm[o + k], tm); tq = lpk_fma(lf2{w, w}, cq[o + k], tq); tx += w * cx[o + k];
+            }
+            rm[o] = tm; rq[o] = tq; rx[o] = tx;
         }
     }
     float l1 = 0.f, sv_sum = 0.f;
@@ -452,7 +460,7 @@ __global__ void __launch_bounds__(256) l1_ssim_fwd_kernel(int H, int W, GaussWin
     for (int o = 0; o < SSIM_VO; ++o) {
         const int gy = y0 + ly0 + o;
         if (gx < W && gy < H) {
-            const float m1 = r[0][o], m2 = r[1][o], q11 = r[2][o], q22 = r[3][o], q12 = r[4][o];
+            const float m1 = rm[o].x, m2 = rm[o].y, q11 = rq[o].x, q22 = rq[o].y, q12 = rx[o];
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
             const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
             const float s11 = q11 - m11, s22 = q22 - m22, s12 = q12 - m12;
@@ -460,7 +468,8 @@ __global__ void __launch_bounds__(256) l1_ssim_fwd_kernel(int H, int W, GaussWin
             const float iCD = 1.f / (Cd * Dd);
             const float sv = An * Bn * iCD;
             sv_sum += sv;
-            l1 += fabsf(s_a[ly0 + o + SSIM_R][lx + SSIM_R] - s_b[ly0 + o + SSIM_R][lx + SSIM_R]);
+            const lf2 ctr = s_ab[ly0 + o + SSIM_R][lx + SSIM_R];
+            l1 += fabsf(ctr.x - ctr.y);
             if (part) {
                 // ssim = A B / (C D) with sigma terms expanded through mu1: total derivative w.r.t. mu1 at fixed
                 // raw moments q11,q12:  s11 = q11 - mu1^2, s12 = q12 - mu1 mu2
@@ -476,54 +485,57 @@ __global__ void __launch_bounds__(256) l1_ssim_fwd_kernel(int H, int W, GaussWin
     block_accumulate<2>(sums + 2, v);
 }
 
-// dimg1(p) = gl1 * sign(a-b) + gss * sum_q w(q-p) [ dm1(q) + 2 a(p) dq11(q) + b(p) dq12(q) ]      (same tiling)
+// dimg1(p) = gl1 * sign(a-b) + gss * sum_q w(q-p) [ dm1(q) + 2 a(p) dq11(q) + b(p) dq12(q) ]      (same tiling; the three
+// planes as one packed pair + one scalar)
 __global__ void __launch_bounds__(256) l1_ssim_bwd_kernel(int H, int W, GaussWin gw, const float* __restrict__ img1,
                                                           const float* __restrict__ img2, const float* __restrict__ part,
                                                           const float* __restrict__ g_l1, const float* __restrict__ g_ssim,
                                                           float wl1, float wss, float* __restrict__ dimg1) {
-    __shared__ float s_p[3][SSIM_HH][SSIM_HS];
-    __shared__ float s_h[3][SSIM_HH][SSIM_TX + 1];
+    __shared__ lf2 s_p01[SSIM_HH][SSIM_HS];
+    __shared__ float s_p2[SSIM_HH][SSIM_HS];
+    __shared__ lf2 s_h01[SSIM_HH][SSIM_TX + 1];
+    __shared__ float s_h2[SSIM_HH][SSIM_TX + 1];
     const int c = blockIdx.z, x0 = blockIdx.x * SSIM_TX, y0 = blockIdx.y * SSIM_TY;
     const size_t P = (size_t)H * W;
     for (int t = threadIdx.x; t < SSIM_HW * SSIM_HH; t += 256) {
         const int ly = t / SSIM_HW, lx = t % SSIM_HW, gx = x0 + lx - SSIM_R, gy = y0 + ly - SSIM_R;
         const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
         const size_t o = c * P + (size_t)gy * W + gx;
-        s_p[0][ly][lx] = in ? part[o] : 0.f;
-        s_p[1][ly][lx] = in ? part[3 * P + o] : 0.f;
-        s_p[2][ly][lx] = in ? part[6 * P + o] : 0.f;
+        s_p01[ly][lx] = in ? lf2{part[o], part[3 * P + o]} : lf2{0.f, 0.f};
+        s_p2[ly][lx] = in ? part[6 * P + o] : 0.f;
     }
     __syncthreads();
     for (int it = threadIdx.x; it < SSIM_HH * (SSIM_TX / 4); it += 256) {
         const int ly = it / (SSIM_TX / 4), lx0 = (it % (SSIM_TX / 4)) * 4;
+        lf2 p01[14];
+        float p2[14];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            float p[14];
+        for (int k = 0; k < 14; ++k) { p01[k] = s_p01[ly][lx0 + k]; p2[k] = s_p2[ly][lx0 + k]; }
 #pragma unroll
-            for (int k = 0; k < 14; ++k) p[k] = s_p[q][ly][lx0 + k];
+        for (int o = 0; o < 4; ++o) {
+            lf2 t01 = {0.f, 0.f};
+            float t2 = 0.f;
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                float t = 0.f;
-#pragma unroll
-                for (int k = 0; k < 11; ++k) t += gw.w[k] * p[o + k];
-                s_h[q][ly][lx0 + o] = t;
-            }
+            for (int k = 0; k < 11; ++k) { const float w = gw.w[k]; t01 = lpk_fma(lf2{w, w}, p01[o + k], t01); t2 += w * p2[o + k]; }
+            s_h01[ly][lx0 + o] = t01; s_h2[ly][lx0 + o] = t2;
         }
     }
     __syncthreads();
     const int lx = threadIdx.x & 31, ly0 = (threadIdx.x >> 5) * SSIM_VO;
-    float r[3][SSIM_VO];
+    lf2 r01[SSIM_VO];
+    float r2[SSIM_VO];
+    {
+        lf2 c01[10 + SSIM_VO];
+        float c2[10 + SSIM_VO];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        float col[10 + SSIM_VO];
-#pragma unroll
-        for (int k = 0; k < 10 + SSIM_VO; ++k) col[k] = s_h[q][ly0 + k][lx];
+        for (int k = 0; k < 10 + SSIM_VO; ++k) { c01[k] = s_h01[ly0 + k][lx]; c2[k] = s_h2[ly0 + k][lx]; }
 #pragma unroll
         for (int o = 0; o < SSIM_VO; ++o) {
-            float t = 0.f;
+            lf2 t01 = {0.f, 0.f};
+            float t2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < 11; ++k) t += gw.w[k] * col[o + k];
-            r[q][o] = t;
+            for (int k = 0; k < 11; ++k) { const float w = gw.w[k]; t01 = lpk_fma(lf2{w, w}, c01[o + k], t01); t2 += w * c2[o + k]; }
+            r01[o] = t01; r2[o] = t2;
         }
     }
     const int gx = x0 + lx;
@@ -537,7 +549,7 @@ __global__ void __launch_bounds__(256) l1_ssim_bwd_kernel(int H, int W, GaussWin
             const float a = img1[oo], b = img2[oo];
             const float df = a - b;
             const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-            dimg1[oo] = kl1 * sg + kss * (r[0][o] + 2.f * a * r[1][o] + b * r[2][o]);
+            dimg1[oo] = kl1 * sg + kss * (r01[o].x + 2.f * a * r01[o].y + b * r2[o]);
         }
     }
 }
