@@ -917,3 +917,8 @@ def test_fused_semantic_loss_equals_conv_plus_cross_entropy(device, S, K):
     assert abs(res[0][0] - res[1][0]) < 2e-6 * max(1.0, abs(res[0][0]))
     for a, b in zip(res[0][1:], res[1][1:]):
         assert torch.allclose(a, b, rtol=2e-4, atol=1e-8), float((a - b).abs().max())
+    # a label outside [0, K) is refused, as F.cross_entropy refuses it (the kernel alone would count it as zero loss)
+    bad = lab.clone()
+    bad[3, 4] = K
+    with pytest.raises(ValueError, match="labels span"):
+        semantic_loss(sem0.to(device), c, bad.to(device))

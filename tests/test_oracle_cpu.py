@@ -341,3 +341,22 @@ def test_missing_library_is_a_loud_error_not_a_fallback(tmp_path):
     env = dict(os.environ, VCR_LIB=str(tmp_path / "absent.so"), PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "LOUD True" in out.stdout, out.stdout + out.stderr
+
+
+def test_fused_loss_path_is_chosen_by_the_losses_active_at_the_iteration():
+    """`Trainer.active_extra_losses`: a configured weight alone does not take the step off the fused loss node (reference `dtu`
+    configuration: distortion = 1000 from the start, applied after `close_depth_from_iter`, `trainer.py:295-303`)."""
+    from types import SimpleNamespace
+    from vcr_gaus_amd.config import make_config
+    from vcr_gaus_amd.trainer import Trainer
+    cfg = make_config("dtu")
+    me = SimpleNamespace(cfg=cfg, weights={k: v for k, v in cfg.optim.loss_weight.items() if v})
+    assert Trainer.active_extra_losses(me, 1) == [] and Trainer.active_extra_losses(me, cfg.optim.close_depth_from_iter) == []
+    assert Trainer.active_extra_losses(me, cfg.optim.close_depth_from_iter + 1) == ["distortion"]
+    cfg = make_config("tnt", optim={"close_depth_from_iter": 500, "curv_from_iter": 500,
+                                    "loss_weight": {"entropy": 0.1, "curv": 0.05, "depth_var": 2.0}})
+    me = SimpleNamespace(cfg=cfg, weights={k: v for k, v in cfg.optim.loss_weight.items() if v})
+    early = Trainer.active_extra_losses(me, 1)
+    assert early == ["entropy"]
+    late = Trainer.active_extra_losses(me, 10 ** 6)
+    assert "depth_var" in late and "entropy" in late and ("curv" in late) == ("depth_normal" in me.weights)

@@ -102,7 +102,7 @@ def test_one_training_step_matches_oracle(device, preset, fused):
     check(*run_case(device, preset, fused, iteration=1))
 
 
-@pytest.mark.parametrize("preset,two_stream", [("dtu_c3", False), ("tnt", True)])
+@pytest.mark.parametrize("preset,two_stream", [("dtu_c3", False), ("tnt", True), ("dtu", False)])
 def test_one_training_step_with_the_fused_tail_matches_oracle(device, preset, two_stream):
     """The default single-GPU step: activation adjoint + l1_scale gradient + densification statistics + Adam on the
     geometry groups in ONE kernel (`FusedAdam.geometry_step`).  Losses, SH gradients, the densification gradient and the
@@ -110,6 +110,11 @@ def test_one_training_step_with_the_fused_tail_matches_oracle(device, preset, tw
     tr, data, before, grads, ref, got = run_case(device, preset, True, iteration=1, two_stream=two_stream, fused_tail=True,
                                                  overrides={"densify_until_iter": 100})
     assert all(grads.get(k) is None for k in ("xyz", "scaling", "rotation", "opacity"))       # really the fused path
+    # (`dtu`: the reference's configuration carries distortion = 1000, applied after iteration 15 000 -- until then the step
+    #  is the fused one and the rasterizer does not produce the distortion channel)
+    assert data["render_out"].shape[0] == 8 and tr.active_extra_losses(1) == []
+    if preset == "dtu":
+        assert tr.active_extra_losses(15001) == ["distortion"]
     check(tr, data, before, grads, ref, got)
     m = tr.model
     vis = ref["radii"] > 0

@@ -64,11 +64,13 @@ class _RenderOut(dict):
 
 
 def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_color=None, return_normal=True,
-           is_all=True, dirs=None, mask_depth_thr=0.8, lazy_mask=False, geometry=True, raster_options=None):
+           is_all=True, dirs=None, mask_depth_thr=0.8, lazy_mask=False, geometry=True, raster_options=None, dist_channels=True):
     """Background tensor (bg_color) must be on the GPU.  Returns the reference's dict:
     render[3,H,W] depth[1,H,W] normal[H,W,3] est_normal[H,W,3] alpha[1,H,W] viewspace_points[N,3]
     viewspace_points_densify[N,3] visibility_filter[N] mask[H,W] radii[N] (+render_sem); beyond the reference: "raster", the
-    call's `RasterRecord` (V, R; the SH-gradient factors after an `sh_grad="rgb"` backward).  `raster_options`: `RasterOptions`."""
+    call's `RasterRecord` (V, R; the SH-gradient factors after an `sh_grad="rgb"` backward).  `raster_options`: `RasterOptions`.
+    `dist_channels=False`: skip the distortion / depth-variance channels the configuration asks for (the trainer does while
+    their losses are not active yet)."""
     dev = pc.get_xyz.device
     # gradient holders for the 2D means (`:31-37`); leaves, so `.grad` is populated without the reference's `+ 0` copies
     grad_on = torch.is_grad_enabled()
@@ -78,8 +80,8 @@ def render(viewpoint_camera, pc, cfg, bg_color, scaling_modifier=1.0, override_c
 
     rs = _settings(viewpoint_camera, pc, bg_color, scaling_modifier, cfg.pipline.debug, 0)
     lw = cfg.optim.loss_weight
-    want_var = getattr(lw, "depth_var", 0) > 0
-    want_dist = getattr(lw, "distortion", 0) > 0 and not want_var
+    want_var = dist_channels and getattr(lw, "depth_var", 0) > 0
+    want_dist = dist_channels and getattr(lw, "distortion", 0) > 0 and not want_var
     rasterizer = GaussianRasterizer(raster_settings=rs, num_dist=2 if want_var else (1 if want_dist else None),
                                     options=raster_options)
 

@@ -299,8 +299,29 @@ class _SemanticCE(torch.autograd.Function):
         return dsem, dW.view(ctx.shapes[0]), db.view(ctx.shapes[1]), None
 
 
+_CHECKED_LABELS = {}
+
+
+def _check_label_range(labels, K):
+    """`F.cross_entropy` refuses a target outside [0, K) (device-side assert); the fused kernel would silently count such a pixel
+    as zero loss while still dividing by all pixels.  Label images are per-camera constants, so the range is checked ONCE per
+    tensor (one min / max read-back), not per step.  `ignore_index` is not supported (the reference does not pass one)."""
+    key = (labels.data_ptr(), labels.numel(), int(labels._version), int(K))
+    if _CHECKED_LABELS.get(id(labels)) == key:
+        return
+    if labels.numel():
+        lo, hi = int(labels.min()), int(labels.max())
+        if lo < 0 or hi >= K:
+            raise ValueError(f"semantic_loss: labels span [{lo}, {hi}] but the classifier has {K} classes "
+                             "(F.cross_entropy would refuse them too)")
+    if len(_CHECKED_LABELS) > 4096:
+        _CHECKED_LABELS.clear()
+    _CHECKED_LABELS[id(labels)] = key
+
+
 def semantic_loss(sem_planes, classifier, labels):
     """`F.cross_entropy(classifier(sem)[0].permute(1, 2, 0).view(-1, K), labels.view(-1)) / log(K)`
     (`gaussian_renderer/__init__.py:146-148`, `trainer.py:304-307`) with the 1x1-conv classifier, the log-softmax and the
     NLL fused: sem_planes [S,H,W] = rows 8..8+S of the rasterizer output, classifier = the model's Conv2d(S, K, 1)."""
+    _check_label_range(labels, classifier.weight.shape[0])
     return _SemanticCE.apply(sem_planes, classifier.weight, classifier.bias, labels)

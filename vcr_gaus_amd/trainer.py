@@ -143,8 +143,22 @@ class Trainer:
         return picked
 
     # ---- losses (`trainer.py:233-321`) -------------------------------------------------------------------
+    def active_extra_losses(self, it):
+        """The losses OUTSIDE the fused loss node that contribute at iteration `it` (a weight alone does not make one active:
+        the reference's `dtu` configuration carries distortion = 1000 from the start but applies it after
+        `close_depth_from_iter`, `trainer.py:295-303`).  While the list is empty the step takes the fused node and the
+        rasterizer skips the distortion / depth-variance channels."""
+        cfg, w = self.cfg, self.weights
+        act = []
+        if it > cfg.optim.close_depth_from_iter:
+            act += [k for k in ("distortion", "depth_var") if k in w]
+        act += [k for k in ("entropy", "mono_depth") if k in w]
+        if "curv" in w and "depth_normal" in w and it > cfg.optim.dnormal_from_iter and it > getattr(cfg.optim, "curv_from_iter", 0):
+            act.append("curv")
+        return act
+
     def _compute_loss(self, data, cam):
-        extra = [k for k in ("distortion", "depth_var", "entropy", "mono_depth", "curv") if k in self.weights]
+        extra = self.active_extra_losses(self.current_iteration)
         if not extra and "render_out" in data and getattr(self, "use_fused_losses", True):
             from .fused_losses import fused_losses          # one autograd node for the whole image-space loss
             total, vals = fused_losses(data["render_out"], self.model, cam, self.weights, self.current_iteration,
@@ -425,8 +439,8 @@ class Trainer:
             m.oneupSHdegree()
         cam = self.cameras[self._next_cameras()[self.rank]]
         bg = self.bg_table[it % self.bg_table.shape[0]] if cfg.optim.random_background else self.background
-        fused = getattr(self, "use_fused_losses", True) and not any(
-            k in self.weights for k in ("distortion", "depth_var", "entropy", "mono_depth", "curv"))
+        extra = self.active_extra_losses(it)
+        fused = getattr(self, "use_fused_losses", True) and not extra
         from .rasterizer import RasterOptions
         overlap = self.overlap_sh and m._xyz.shape[0] >= self.overlap_min_gaussians
         self.factorised_sh = self._factorised_base or overlap
@@ -450,7 +464,8 @@ class Trainer:
             sink = gaussian_model.GeometrySink()
         m._geom_sink = sink
         try:
-            data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True, geometry=not fused, raster_options=opts)
+            data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True, geometry=not fused, raster_options=opts,
+                          dist_channels="distortion" in extra or "depth_var" in extra)
             if self._pending_sh is not None:     # the render did not go through the two-stream path (e.g. no Gaussians)
                 self.join_side()
             fused_losses.DEFER_SCALE_GRAD = True    # l1_scale's gradient joins the activation backward's kernel (same graph)
