@@ -133,6 +133,33 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
+// SH -> RGB of one Gaussian (before the + 0.5 / clamp) together with its derivative w.r.t. the MEAN through the normalised view
+// direction d = (mean - campos) il:  M[c] = il (I - d d^T) sum_k grad(basis_k)(d) sh[k][c]  (GeomState::cjac).  `SH` is indexable
+// as SH[3 k + c] (a global row or the block's LDS row).
+#define VCR_SH_COLOUR_JAC(DEG, NB, SH, DX, DY, DZ, IL, C0, C1, C2, MOUT)                                                  \
+    do {                                                                                                                    \
+        float b_[16], bx_[16], by_[16], bz_[16];                                                                            \
+        sh_basis<true>((DEG), (DX), (DY), (DZ), b_, bx_, by_, bz_);                                                         \
+        float jx_[3] = {0.f, 0.f, 0.f}, jy_[3] = {0.f, 0.f, 0.f}, jz_[3] = {0.f, 0.f, 0.f};                                \
+        float cc_[3] = {0.5f, 0.5f, 0.5f};                                                                                  \
+_Pragma("unroll")                                                                                                           \
+        for (int k = 0; k < 16; ++k) {                                                                                      \
+            if (k < (NB)) {                                                                                                 \
+_Pragma("unroll")                                                                                                           \
+                for (int c = 0; c < 3; ++c) {                                                                               \
+                    const float v_ = (SH)[3 * k + c];                                                                       \
+                    cc_[c] += b_[k] * v_; jx_[c] += bx_[k] * v_; jy_[c] += by_[k] * v_; jz_[c] += bz_[k] * v_;              \
+                }                                                                                                           \
+            }                                                                                                               \
+        }                                                                                                                   \
+        C0 = cc_[0]; C1 = cc_[1]; C2 = cc_[2];                                                                              \
+_Pragma("unroll")                                                                                                           \
+        for (int c = 0; c < 3; ++c) {                                                                                       \
+            const float dot_ = (DX) * jx_[c] + (DY) * jy_[c] + (DZ) * jz_[c];                                               \
+            (MOUT)[c] = make_float4((jx_[c] - (DX) * dot_) * (IL), (jy_[c] - (DY) * dot_) * (IL), (jz_[c] - (DZ) * dot_) * (IL), 0.f); \
+        }                                                                                                                   \
+    } while (0)
+
 
 // ---- cooperative SH staging ------------------------------------------------------------------------------
 // A lane-per-Gaussian read of 48 consecutive floats is a 192-byte-stride access: every load instruction of
@@ -263,21 +290,16 @@ __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const
         float dx = p[0] - cam.c[0], dy = p[1] - cam.c[1], dz = p[2] - cam.c[2];
         const float il = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
         dx *= il; dy *= il; dz *= il;
-        float b[16];
-        sh_basis<false>(a.sh_degree, dx, dy, dz, b, nullptr, nullptr, nullptr);
         const float* sh = STAGE ? (s_sh + threadIdx.x * SH_ROW) : (a.shs + (size_t)i * a.K * 3);
         const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
-        float c0 = 0.5f, c1 = 0.5f, c2 = 0.5f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if (k < nb) {
-                c0 += b[k] * sh[3 * k]; c1 += b[k] * sh[3 * k + 1]; c2 += b[k] * sh[3 * k + 2];
-            }
-        }
+        float c0, c1, c2;
+        float4 M[3];
+        VCR_SH_COLOUR_JAC(a.sh_degree, nb, sh, dx, dy, dz, il, c0, c1, c2, M);
         if (c0 < 0.f) { c0 = 0.f; clampbits |= 1; }
         if (c1 < 0.f) { c1 = 0.f; clampbits |= 2; }
         if (c2 < 0.f) { c2 = 0.f; clampbits |= 4; }
         rec.r = c0; rec.g = c1; rec.b = c2;
+        g.cjac[3 * (size_t)i] = M[0]; g.cjac[3 * (size_t)i + 1] = M[1]; g.cjac[3 * (size_t)i + 2] = M[2];
     }
     rec.px = px; rec.py = py; rec.z = pr.t[2]; rec.opacity = a.opacities[i];
     rec.ca = cc * idet; rec.cb = -cb * idet; rec.cc = ca * idet;
@@ -364,17 +386,12 @@ __global__ void __launch_bounds__(256) colour_fwd_kernel(VcrRasterArgs a, GeomSt
         float dx = a.means3D[3 * (size_t)i] - c[0], dy = a.means3D[3 * (size_t)i + 1] - c[1], dz = a.means3D[3 * (size_t)i + 2] - c[2];
         const float il = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
         dx *= il; dy *= il; dz *= il;
-        float b[16];
-        sh_basis<false>(a.sh_degree, dx, dy, dz, b, nullptr, nullptr, nullptr);
         const float* sh = STAGE ? (s_sh + threadIdx.x * SH_ROW) : (a.shs + (size_t)i * a.K * 3);
         const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
-        float c0 = 0.5f, c1 = 0.5f, c2 = 0.5f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if (k < nb) {
-                c0 += b[k] * sh[3 * k]; c1 += b[k] * sh[3 * k + 1]; c2 += b[k] * sh[3 * k + 2];
-            }
-        }
+        float c0, c1, c2;
+        float4 M[3];
+        VCR_SH_COLOUR_JAC(a.sh_degree, nb, sh, dx, dy, dz, il, c0, c1, c2, M);
+        g.cjac[3 * (size_t)i] = M[0]; g.cjac[3 * (size_t)i + 1] = M[1]; g.cjac[3 * (size_t)i + 2] = M[2];
         uint8_t clampbits = 0;
         if (c0 < 0.f) { c0 = 0.f; clampbits |= 1; }
         if (c1 < 0.f) { c1 = 0.f; clampbits |= 2; }
@@ -391,10 +408,6 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
     extern __shared__ __attribute__((aligned(16))) float s_sh[];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int blk_base = blockIdx.x * 256, blk_cnt = min(256, a.N - blk_base);
-    if (STAGE) {
-        stage_sh_in(a, blk_base, blk_cnt, s_sh);
-        __syncthreads();
-    }
     const bool live = i < a.N;
     const size_t i3 = 3 * (size_t)(live ? i : 0);
     const bool vis = live && radii[i] > 0;
@@ -494,24 +507,23 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
             float dx = p[0] - cam.c[0], dy = p[1] - cam.c[1], dz = p[2] - cam.c[2];
             const float il = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
             dx *= il; dy *= il; dz *= il;
-            float b[16], bx[16], by[16], bz[16];
-            sh_basis<true>(a.sh_degree, dx, dy, dz, b, bx, by, bz);
-            float* shrow = STAGE ? (s_sh + threadIdx.x * SH_ROW) : nullptr;     // own row: read, then overwritten
-            const float* sh = STAGE ? shrow : (a.shs + (size_t)i * a.K * 3);
-            float* dsh = STAGE ? shrow : (io.dL_dshs ? io.dL_dshs + (size_t)i * a.K * 3 : nullptr);
-            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+            // colour -> mean through the view direction: M was stored with the colour (GeomState::cjac), so the 192 B of SH
+            // coefficients are not read here; the SH gradient itself (only when asked for) is basis (x) dL/drgb
+            float* dsh = STAGE ? (s_sh + threadIdx.x * SH_ROW) : (io.dL_dshs ? io.dL_dshs + (size_t)i * a.K * 3 : nullptr);
+            if (dsh) {
+                float b[16];
+                sh_basis<false>(a.sh_degree, dx, dy, dz, b, nullptr, nullptr, nullptr);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k < nb) {
-                    const float w = sh[3 * k] * dcol[0] + sh[3 * k + 1] * dcol[1] + sh[3 * k + 2] * dcol[2];
-                    ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;
-                    if (dsh) { dsh[3 * k] = b[k] * dcol[0]; dsh[3 * k + 1] = b[k] * dcol[1]; dsh[3 * k + 2] = b[k] * dcol[2]; }
+                for (int k = 0; k < 16; ++k) {
+                    if (k < nb) { dsh[3 * k] = b[k] * dcol[0]; dsh[3 * k + 1] = b[k] * dcol[1]; dsh[3 * k + 2] = b[k] * dcol[2]; }
                 }
+                for (int k = nb; k < a.K; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
             }
-            if (dsh) for (int k = nb; k < a.K; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
             if (io.view_dirs) { io.view_dirs[i3] = dx; io.view_dirs[i3 + 1] = dy; io.view_dirs[i3 + 2] = dz; }
-            const float dot = dx * ddx + dy * ddy + dz * ddz;       // through normalize()
-            dp[0] += (ddx - dx * dot) * il; dp[1] += (ddy - dy * dot) * il; dp[2] += (ddz - dz * dot) * il;
+            const float4 m0 = g.cjac[3 * (size_t)i], m1 = g.cjac[3 * (size_t)i + 1], m2 = g.cjac[3 * (size_t)i + 2];
+            dp[0] += dcol[0] * m0.x + dcol[1] * m1.x + dcol[2] * m2.x;
+            dp[1] += dcol[0] * m0.y + dcol[1] * m1.y + dcol[2] * m2.y;
+            dp[2] += dcol[0] * m0.z + dcol[1] * m1.z + dcol[2] * m2.z;
         }
         // Sigma = (R s)(R s)^T
         if (!a.cov3D_precomp) {
@@ -811,14 +823,12 @@ __global__ void __launch_bounds__(256) sh_update_colour_kernel(VcrRasterArgs a, 
             const float* c = a.campos;
             float dx = a.means3D[3 * (size_t)i] - c[0], dy = a.means3D[3 * (size_t)i + 1] - c[1], dz = a.means3D[3 * (size_t)i + 2] - c[2];
             const float il = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
-            float b[16];
-            sh_basis<false>(a.sh_degree, dx * il, dy * il, dz * il, b, nullptr, nullptr, nullptr);
+            dx *= il; dy *= il; dz *= il;
             const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
-            float c0 = 0.5f, c1 = 0.5f, c2 = 0.5f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k < nb) { c0 += b[k] * row[3 * k]; c1 += b[k] * row[3 * k + 1]; c2 += b[k] * row[3 * k + 2]; }
-            }
+            float c0, c1, c2;
+            float4 M[3];
+            VCR_SH_COLOUR_JAC(a.sh_degree, nb, row, dx, dy, dz, il, c0, c1, c2, M);
+            g.cjac[3 * (size_t)i] = M[0]; g.cjac[3 * (size_t)i + 1] = M[1]; g.cjac[3 * (size_t)i + 2] = M[2];
             uint8_t clampbits = 0;
             if (c0 < 0.f) { c0 = 0.f; clampbits |= 1; }
             if (c1 < 0.f) { c1 = 0.f; clampbits |= 2; }
@@ -951,7 +961,7 @@ int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const in
                                    const float* sgrad_sem, VcrBackwardIO& io, hipStream_t st) {
     if (a.N == 0) return 0;
     const int blocks = (a.N + 255) / 256;
-    if (a.shs && a.K == SH_K)
+    if (a.shs && a.K == SH_K && io.dL_dshs)        // (LDS rows only for the coalesced write-back of a materialised SH gradient)
         hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(256), 256 * SH_ROW * sizeof(float), st, a, g, radii,
                            sgrad, sgrad_sem, io);
     else

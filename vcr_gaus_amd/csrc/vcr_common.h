@@ -60,9 +60,13 @@ struct GeomState {
                          //     VCR_RECT_MASK_TILES tiles: {MASKED | xmin | ymin << 10 | (w-1) << 20 | (h-1) << 25, bit k set when
                          //     tile (xmin + k % w, ymin + k / w) can be reached (exact rejection, tile_touch)}; larger ones:
                          //     {xmin | ymin << 10, w | h << 16}, every tile emitted; {0, 0} = culled
+    float4* cjac;        // [N][3] d(colour channel c) / d(mean), through the normalised view direction (written with the colour by
+                         //     whichever kernel evaluates SH -> RGB): the projection backward forms the colour -> mean adjoint
+                         //     from these 48 B instead of re-reading the 192 B of SH coefficients
     static size_t bytes(int N, int S) {
         return vcr_align(sizeof(GeomRec) * (size_t)N) + vcr_align(sizeof(float) * (size_t)N * (S > 0 ? S : 1)) +
-               vcr_align(sizeof(uint32_t) * (size_t)N) + vcr_align((size_t)N) + vcr_align(sizeof(uint2) * (size_t)N);
+               vcr_align(sizeof(uint32_t) * (size_t)N) + vcr_align((size_t)N) + vcr_align(sizeof(uint2) * (size_t)N) +
+               vcr_align(sizeof(float4) * 3 * (size_t)N);
     }
     static GeomState view(void* p, int N, int S) {
         GeomState g;
@@ -71,7 +75,8 @@ struct GeomState {
         g.sem = (float*)c;        c += vcr_align(sizeof(float) * (size_t)N * (S > 0 ? S : 1));
         g.tiles = (uint32_t*)c;   c += vcr_align(sizeof(uint32_t) * (size_t)N);
         g.clamped = (uint8_t*)c;  c += vcr_align((size_t)N);
-        g.rect = (uint2*)c;
+        g.rect = (uint2*)c;       c += vcr_align(sizeof(uint2) * (size_t)N);
+        g.cjac = (float4*)c;
         return g;
     }
 };
