@@ -32,6 +32,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="metric_1m_1080p")
+    ap.add_argument("--preset", default="tnt", help="loss / schedule configuration of the step: tnt (the headline line), dtu (the "
+                    "reference's DTU configuration: distortion loss configured, active after iteration 15 000), dtu_c3, 360")
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-context", action="store_true", help="skip the untimed context measurements (dense / full-frame variants, "
@@ -306,7 +308,7 @@ def main():
     if smult != 1.0:
         raw["scaling"] = raw["scaling"] + math.log(smult)
     cams = synthetic.make_cameras(max(args.views, world), W, H, focal, radius=synthetic.camera_radius(args.workload), device=dev)
-    trainer = BenchTrainer(raw, cams, dev, world=world, rank=rank)
+    trainer = BenchTrainer(raw, cams, dev, world=world, rank=rank, preset=args.preset)
 
     def sync():
         if world > 1:
@@ -361,7 +363,7 @@ def main():
             "value_is": "views/s = optimizer iterations/s x views per iteration (n_gpus); equal to iters/s on one GPU",
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "scale_mult": smult, "gaussians": n, "width": W, "height": H, "sh_degree": 3,
+            "config": {"workload": args.workload, "preset": args.preset, "scale_mult": smult, "gaussians": n, "width": W, "height": H, "sh_degree": 3,
                        "views_per_step": world, "tile_instances_R": R, "emitted_instances": trainer.last_E, "visible_V": trainer.last_V,
                        "max_tile_len": shape["max_tile_len"], "covered_pixels": shape["covered_pixels"],
                        "exchange": trainer.exchange(), "step": trainer.describe()},

@@ -8,6 +8,7 @@ cd $R
 for wl in c2_dtu_300k_800x600 c4_tnt_2m_1080p c5_360_5m_1600x1200 dense_1m_1080p fullframe_1m_1080p; do
     python bench.py --workload $wl --steps 30 --warmup 10 --no-cpu-baseline --no-context > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
 done
+python bench.py --workload c2_dtu_300k_800x600 --preset dtu --steps 30 --warmup 10 --no-cpu-baseline --no-context > $OUT/bench_c2_preset_dtu.json 2> $OUT/bench_c2_preset_dtu.err
 python bench.py --steps 50 --warmup 10 > $OUT/bench_metric.json 2> $OUT/bench_metric.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-context > $OUT/bench_traced.json 2> $OUT/bench_traced.err
