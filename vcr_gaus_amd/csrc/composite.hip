@@ -585,172 +585,6 @@ __device__ __forceinline__ void live_box16(unsigned live, float X0, float Y0, fl
     bx0 = X0 + (float)x0; by0 = Y0 + (float)y0; bw = (float)(x1 - x0); bh = (float)(y1 - y0);
 }
 
-// ================= forward, row-packed (same scheme as the backward below; FC == 0 only) =====================================
-template <int S, bool ISECT, int ND>
-__global__ void __launch_bounds__(256) composite_fwd_rows_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
-                                                               const float* __restrict__ semv,
-                                                               const uint32_t* __restrict__ point_list,
-                                                               const uint2* __restrict__ ranges,
-                                                               const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ meta,
-                                                               int num_tiles, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                               float* __restrict__ moments, float* __restrict__ out) {
-    const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
-    int sub;
-    const int tile = work_item(tile_order, meta, num_tiles, sub);
-    if (tile < 0) return;
-    const PixelMap pm = pixel_of_thread_rows(tile, gx, a.W, a.H, sub);
-    const uint2 range = ranges[tile];
-    const int P = a.H * a.W;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = lane >> 4;
-    constexpr bool SEM_IN_REC = S > 0 && S <= 2;
-    constexpr int WREC = (S > 0 && !SEM_IN_REC) ? 320 : 256;
-    __shared__ float4 s_rec_all[4 * WREC];
-    float4* const srec = s_rec_all + wv * WREC;
-    const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8);
-    const float Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8);
-    const f2 fxy = {(float)pm.x, (float)pm.y};
-    float rx = 0.f, ry = 0.f, rz = 1.f;
-    if (ISECT && pm.inside) { rx = a.dirs[pm.pix]; ry = a.dirs[P + pm.pix]; rz = a.dirs[2 * P + pm.pix]; }
-
-    float T = 1.f;
-    f2 acc_c01 = {0.f, 0.f}, acc_c2n = {0.f, 0.f}, acc_n12 = {0.f, 0.f}, acc_da = {0.f, 0.f};
-    float SM[S > 0 ? S : 1];
-#pragma unroll
-    for (int k = 0; k < S; ++k) SM[k] = 0.f;
-    float M1 = 0.f, M2 = 0.f;
-    const float zc_map = VCR_ZFAR / (VCR_ZFAR - VCR_ZNEAR);
-    uint32_t last = 0;
-    bool done = !pm.inside;
-
-    uint32_t pos = range.x;
-    uint32_t id, nid; float4 q0, q1, q2, q3, qs = {0.f, 0.f, 0.f, 0.f}; bool valid, nvalid;
-    VCR_LOAD_ID(pos + lane, range.y, id, valid);
-    VCR_GATHER_REC(id, q0, q1, q2, q3);
-    if (!SEM_IN_REC) VCR_GATHER_SEM(id, qs);
-    VCR_LOAD_ID(pos + 64 + lane, range.y, nid, nvalid);
-    while (pos < range.y) {
-        uint32_t nnid; float4 nq0, nq1, nq2, nq3, nqs = {0.f, 0.f, 0.f, 0.f}; bool nnvalid;
-        const uint32_t npos = pos + 64;
-        VCR_GATHER_REC(nid, nq0, nq1, nq2, nq3);
-        if (!SEM_IN_REC) VCR_GATHER_SEM(nid, nqs);
-        VCR_LOAD_ID(npos + 64 + lane, range.y, nnid, nnvalid);
-        const unsigned long long live = __builtin_amdgcn_ballot_w64(!done);
-        unsigned long long mr[4];
-        bool keep = false;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const unsigned lr = (unsigned)(live >> (16 * r)) & 0xFFFFu;
-            bool k = false;
-            if (lr != 0) {                                   // wave-uniform
-                float bx0, by0, bw, bh;
-                live_box16(lr, X0 + (float)((r & 1) * 4), Y0 + (float)((r >> 1) * 4), bx0, by0, bw, bh);
-                k = valid && quad_touch(q0, q1, bx0, by0, bw, bh);
-            }
-            mr[r] = __builtin_amdgcn_ballot_w64(k);
-            keep |= k;
-        }
-        if (keep) {
-            srec[0 * 64 + lane] = make_float4(q0.x, q0.y, -VCR_L2E * q1.x, -VCR_L2E * q1.z);
-            srec[1 * 64 + lane] = make_float4(-VCR_L2E * q1.y, __builtin_amdgcn_logf(q0.w), q0.z, q1.w);
-            srec[2 * 64 + lane] = make_float4(q2.x, q2.y, q2.z, q3.x);
-            srec[3 * 64 + lane] = SEM_IN_REC ? make_float4(q3.y, q3.z, q2.w, q3.w) : make_float4(q3.y, q3.z, __uint_as_float(id), 0.f);
-            if (S > 0 && !SEM_IN_REC) srec[4 * 64 + lane] = qs;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const unsigned long long many = mr[0] | mr[1] | mr[2] | mr[3];
-        if (many) {
-            const int iters = max(max(__popcll(mr[0]), __popcll(mr[1])), max(__popcll(mr[2]), __popcll(mr[3])));
-            unsigned long long mrow = row == 0 ? mr[0] : (row == 1 ? mr[1] : (row == 2 ? mr[2] : mr[3]));
-            int b = __builtin_ctzll(many);                   // exhausted rows keep shading a staged record with hit = false
-            bool act;
-#define VCR_ROW_NEXT_F(B, ACT)                                                         \
-            do {                                                                        \
-                ACT = mrow != 0;                                                        \
-                B = ACT ? __builtin_ctzll(mrow) : B;                                    \
-                mrow = mrow & (mrow - 1);                                               \
-            } while (0)
-#define VCR_SHADE_FWD_ROWS(R, B, ACT)                                                                                    \
-            do {                                                                                                         \
-                const float4 r0 = R##0, r1 = R##1, r2 = R##2, r3 = R##3;                                                 \
-                const f2 gxy = {r0.x, r0.y}, sAC = {r0.z, r0.w};                                                         \
-                f2 u; float hs;                                                                                          \
-                const float e = gauss_exponent(gxy - fxy, sAC, r1.x, r1.y, u, hs);                                       \
-                const float alpha = fminf(VCR_ALPHA_MAX, __builtin_amdgcn_exp2f(e));                                     \
-                bool hit = (ACT) && !done && hs <= 0.f && alpha >= VCR_ALPHA_MIN;                                        \
-                const float test_T = fmaf(-alpha, T, T);                                                                 \
-                if (hit && test_T < VCR_T_EPS) { done = true; hit = false; }                                             \
-                const float w = hit ? alpha * T : 0.f;                                                                   \
-                const f2 c01 = {r2.x, r2.y}, c2n = {r2.z, r2.w}, n12 = {r3.x, r3.y};                                     \
-                float dep = r1.z;                                                                                        \
-                if (ISECT) {                                                                                             \
-                    const float den = c2n.y * rx + n12.x * ry + n12.y * rz;                                              \
-                    if (den > VCR_PLANE_EPS) dep = r1.w * fast_rcp(den) * rz;                                            \
-                }                                                                                                        \
-                const f2 ww = splat(w);                                                                                  \
-                acc_c01 = pk_fma(ww, c01, acc_c01);                                                                      \
-                acc_c2n = pk_fma(ww, c2n, acc_c2n);                                                                      \
-                acc_n12 = pk_fma(ww, n12, acc_n12);                                                                      \
-                acc_da = pk_fma(ww, f2{dep, 1.f}, acc_da);                                                               \
-                if (ND == 2) M2 += w * dep * dep;                                                                        \
-                if (ND == 1) {                                                                                           \
-                    const float md = -zc_map * VCR_ZNEAR * fast_rcp(dep);                                                \
-                    M1 += w * md; M2 += w * md * md;                                                                     \
-                }                                                                                                        \
-                if (S > 0) {                                                                                             \
-                    const float4 r4_ = SEM_IN_REC ? make_float4(r3.z, r3.w, 0.f, 0.f) : R##4;                            \
-                    const float sv_[4] = {r4_.x, r4_.y, r4_.z, r4_.w};                                                   \
-_Pragma("unroll")                                                                                                        \
-                    for (int k = 0; k < S; ++k) SM[k] += w * sv_[k];                                                     \
-                }                                                                                                        \
-                T = hit ? test_T : T;                                                                                    \
-                last = hit ? pos - range.x + (uint32_t)(B) + 1u : last;                                                  \
-            } while (0)
-            float4 A0, A1, A2, A3, A4 = {0.f, 0.f, 0.f, 0.f}, B0, B1, B2, B3, B4 = {0.f, 0.f, 0.f, 0.f};
-            int nb; bool nact;
-            VCR_ROW_NEXT_F(b, act);
-            VCR_LDS_FETCH(A, b);
-            for (int it = 0;;) {
-                nb = b;
-                VCR_ROW_NEXT_F(nb, nact);
-                VCR_LDS_FETCH(B, nb);
-                VCR_SHADE_FWD_ROWS(A, b, act);
-                if (++it >= iters) break;
-                b = nb;
-                VCR_ROW_NEXT_F(b, act);
-                VCR_LDS_FETCH(A, b);
-                VCR_SHADE_FWD_ROWS(B, nb, nact);
-                if (++it >= iters) break;
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(!done) == 0) break;        // every pixel of the quad has T < 1e-4
-        pos = npos; id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; qs = nqs; valid = nvalid; nid = nnid; nvalid = nnvalid;
-    }
-    if (pm.inside) {
-        const float C0 = acc_c01.x, C1 = acc_c01.y, C2 = acc_c2n.x, N0 = acc_c2n.y, N1 = acc_n12.x, N2 = acc_n12.y;
-        const float D = acc_da.x, A = acc_da.y;
-        final_T[pm.pix] = T;
-        n_contrib[pm.pix] = last;
-        out[0 * (size_t)P + pm.pix] = C0 + T * a.bg[0];
-        out[1 * (size_t)P + pm.pix] = C1 + T * a.bg[1];
-        out[2 * (size_t)P + pm.pix] = C2 + T * a.bg[2];
-        out[3 * (size_t)P + pm.pix] = D;
-        out[4 * (size_t)P + pm.pix] = N0;
-        out[5 * (size_t)P + pm.pix] = N1;
-        out[6 * (size_t)P + pm.pix] = N2;
-        out[7 * (size_t)P + pm.pix] = A;
-#pragma unroll
-        for (int k = 0; k < S; ++k) out[(8 + k) * (size_t)P + pm.pix] = SM[k];
-        if (ND == 2) {
-            out[(8 + S) * (size_t)P + pm.pix] = D;
-            out[(9 + S) * (size_t)P + pm.pix] = M2;
-        }
-        if (ND == 1) {
-            out[(8 + S) * (size_t)P + pm.pix] = A * M2 - M1 * M1;
-            moments[pm.pix] = M1; moments[P + pm.pix] = M2;
-        }
-    }
-}
-
 template <int CTRL>
 __device__ __forceinline__ float dpp_get(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
@@ -961,13 +795,6 @@ int launch_fwd_fc(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im
 #define VCR_FWD(FC, NDD)                                                                                          \
     hipLaunchKernelGGL((composite_fwd_v2_kernel<S, ISECT, FC, NDD>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
                        b.point_list, b.ranges, b.tile_order, b.meta, tiles, im.final_T, im.n_contrib, im.moments, o.out, o.count, o.score)
-    static const bool rows = []() { const char* e = getenv("VCR_FWD_ROWS"); return e ? atoi(e) != 0 : false; }();
-    if (a.f_count == 0 && rows) {
-        hipLaunchKernelGGL((composite_fwd_rows_kernel<S, ISECT, ND>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem,
-                           b.point_list, b.ranges, b.tile_order, b.meta, tiles, im.final_T, im.n_contrib, im.moments, o.out);
-        VCR_HIP_CHECK(hipGetLastError());
-        return 0;
-    }
     switch (a.f_count) {
         case 0: VCR_FWD(0, ND); break;
         case 1: case 2: VCR_FWD(1, 0); break;
