@@ -141,6 +141,10 @@ __device__ unsigned int g_hithist[130];
 #endif
 
 
+#ifndef VCR_ROWS_WAVES
+#define VCR_ROWS_WAVES 3         // row-packed backward, waves per SIMD: 3 -> 0.388 ms at the metric scene, 4 -> 0.399, 5 -> 0.47 (spills);
+                                 // c5 0.893 / 0.960, dense 0.551 / 0.570 for 3 / 4 (profiles/r3_ab_waves.sh)
+#endif
 #ifndef VCR_FWD_WAVES
 #define VCR_FWD_WAVES 0          // 0: compiler's choice (79 VGPRs, 6 waves per SIMD)
 #endif
@@ -621,7 +625,7 @@ __device__ __forceinline__ float row_reduce16(const f2 v[8], int lane) {
 }
 
 template <int S, bool ISECT, int ND>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) composite_bwd_rows_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_ROWS_WAVES))) composite_bwd_rows_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
                                                                const float* __restrict__ semv,
                                                                const uint32_t* __restrict__ point_list,
                                                                const uint2* __restrict__ ranges,
