@@ -1,4 +1,6 @@
 """Training losses, HIP-backed.  Function names follow the reference's `tools/loss_utils.py`."""
+import weakref
+
 import torch
 
 from . import _lib
@@ -307,7 +309,8 @@ def _check_label_range(labels, K):
     as zero loss while still dividing by all pixels.  Label images are per-camera constants, so the range is checked ONCE per
     tensor (one min / max read-back), not per step.  `ignore_index` is not supported (the reference does not pass one)."""
     key = (labels.data_ptr(), labels.numel(), int(labels._version), int(K))
-    if _CHECKED_LABELS.get(id(labels)) == key:
+    seen = _CHECKED_LABELS.get(id(labels))
+    if seen is not None and seen[0] == key and seen[1]() is labels:          # (the weak reference guards against a recycled id)
         return
     if labels.numel():
         lo, hi = int(labels.min()), int(labels.max())
@@ -316,7 +319,7 @@ def _check_label_range(labels, K):
                              "(F.cross_entropy would refuse them too)")
     if len(_CHECKED_LABELS) > 4096:
         _CHECKED_LABELS.clear()
-    _CHECKED_LABELS[id(labels)] = key
+    _CHECKED_LABELS[id(labels)] = (key, weakref.ref(labels))
 
 
 def semantic_loss(sem_planes, classifier, labels):
