@@ -283,9 +283,32 @@ def schedule_inclusive(trainer, iters=200):
             "what": "same step as `value` with densify_and_prune every 100 iterations (and its visibility passes) inside the window"}
 
 
+def relaunch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-exec THIS command as N ranks (one process per GPU) through
+    torch.distributed.run on the loop-back address, stream rank 0's JSON line through and exit with the launcher's code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def switches():
+    """Every VCR_* / NCCL_* / RCCL_* environment switch that is set: the product kernels read a few experiment switches at load
+    time, so the line says which build of the step it measured."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith(("VCR_", "NCCL_", "RCCL_"))}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} rank(s)"
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
@@ -366,7 +389,8 @@ def main():
             "config": {"workload": args.workload, "preset": args.preset, "scale_mult": smult, "gaussians": n, "width": W, "height": H, "sh_degree": 3,
                        "views_per_step": world, "tile_instances_R": R, "emitted_instances": trainer.last_E, "visible_V": trainer.last_V,
                        "max_tile_len": shape["max_tile_len"], "covered_pixels": shape["covered_pixels"],
-                       "exchange": trainer.exchange(), "step": trainer.describe()},
+                       "exchange": trainer.exchange(), "step": trainer.describe(), "ranks": world,
+                       "dist_backend": (dist.get_backend() if world > 1 else None), "env_switches": switches()},
             "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": per_step[0], "max": per_step[-1],
                         "note": "per-step GPU-timeline spread (events after every step); `value` uses the wall clock of all K steps"},
             "raster_mpix_per_s": world * P / (raster_fwd_ms * 1e-3) / 1e6 if raster_fwd_ms > 0 else None,

@@ -83,8 +83,9 @@ def render(raw, cam, cfg, extent, bg, dirs, sh_degree, num_dist=0):
                 viewspace_points=m2, viewspace_points_densify=m2d, stats=st)
 
 
-def losses(data, raw, cam, cfg, it, trans, scale):
-    """`trainer.py:233-321` -> (dict of losses, weighted total)."""
+def losses(data, raw, cam, cfg, it, trans, scale, classifier=None):
+    """`trainer.py:233-321` -> (dict of losses, weighted total).  `classifier`: (weight [K,S,1,1], bias [K]) of the 1x1
+    convolution over the rendered semantic planes (`gaussian_renderer/__init__.py:149-152`, `trainer.py:304-307`)."""
     w = {k: v for k, v in cfg.optim.loss_weight.items() if v}
     dt = raw["xyz"].dtype
     gt_image = cam.original_image.cpu().to(dt)
@@ -114,6 +115,11 @@ def losses(data, raw, cam, cfg, it, trans, scale):
         L["distortion"] = edge_aware_map(gt_image, data["distortion"]).mean()
     if "depth_var" in w and it > cfg.optim.close_depth_from_iter and "depth_var" in data:
         L["depth_var"] = edge_aware_map(gt_image, data["depth_var"]).mean()
+    if "semantic" in w and classifier is not None and data["out"].shape[0] > 8:
+        cw, cb = classifier
+        S = cw.shape[1]
+        logits = F.conv2d(data["out"][8:8 + S][None], cw.to(dt), cb.to(dt))[0].permute(1, 2, 0)          # [H, W, cls]
+        L["semantic"] = F.cross_entropy(logits.reshape(-1, cw.shape[0]), cam.mask.cpu().reshape(-1).long()) / math.log(cw.shape[0])
     total = sum(L[k] * w[k] for k in w if k in L)
     return L, total
 

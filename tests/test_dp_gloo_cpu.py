@@ -312,3 +312,33 @@ def test_visibility_and_importance_passes_shard_cameras(tmp_path):
         cnt = cnt + torch.randint(0, 9, (N,), generator=g, dtype=torch.int32)
         imp = imp + torch.rand(N, generator=g)
     assert torch.equal(r0["cnt"], cnt) and torch.allclose(r0["imp"], imp, atol=1e-5) and torch.equal(r1["cnt"], cnt)
+
+
+def test_bench_gpus_flag_relaunches_itself_as_n_ranks(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE re-executes the same command line through torch.distributed.run with N
+    processes on the loop-back address and exits with the launcher's return code (host logic only: no GPU, nothing is run)."""
+    import importlib
+    import subprocess
+    import sys
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_run(cmd, env=None, **k):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # a launcher that started a different number of ranks than --gpus is an error, not a silently smaller job
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(AssertionError, match="--gpus 4"):
+        bench.main()

@@ -148,3 +148,27 @@ def test_two_ranks_equal_one_process_accumulating_the_same_cameras(device, tmp_p
         sig = acc[k].abs() > 1e-3 * acc[k].abs().max()        # first Adam step = -lr * sign(g): compare where g is not ~0
         assert float((one - two).abs()[sig].max()) <= 2e-2 * lrs[k], (k, float((one - two).abs()[sig].max()), lrs[k])
         assert float((one - two).abs().max()) <= 2.0 * lrs[k] * 1.001
+
+
+def test_bench_launches_the_ranks_it_is_asked_for(device):
+    """`python bench.py --gpus 2` WITHOUT a launcher must produce two ranks itself (`--gpus` was parsed and never
+    used).  On this one-GPU box the two ranks share the device over gloo (VCR_DIST_BACKEND); the line must say n_gpus = 2,
+    two ranks, views/s = 2 x iterations/s and the factorised exchange of the multi-rank path."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VCR_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "c1_10k_256", "--no-cpu-baseline", "--no-context"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                       # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["config"]["views_per_step"] == 2
+    assert line["config"]["dist_backend"] == "gloo" and line["config"]["env_switches"]["VCR_DIST_BACKEND"] == "gloo"
+    assert abs(line["views_per_s"] - 2 * line["iters_per_s"]) < 1e-6 * line["views_per_s"]
+    assert line["config"]["exchange"].startswith("factorised")
+    assert line["scaling"] == "weak" and line["value"] == line["views_per_s"]

@@ -74,13 +74,15 @@ def test_v_imp_score_matches_reference(tag):
 def _restored(device):
     cfg = make_config("tnt")
     cfg.model.enable_semantic, cfg.model.ch_sem_feat, cfg.model.num_cls = True, 2, 2
-    ckpt, it = torch.load(os.path.join(G, "g10_chkpnt3.pth"), map_location="cpu", weights_only=False)
+    from vcr_gaus_amd.trainer import load_capture
+    ckpt, it = load_capture(os.path.join(G, "g10_chkpnt3.pth"))          # weights_only: no code from the file is executed
     m = GaussianModel(cfg.model)
-    m.restore(ckpt, cfg.optim, device=device)
     nxt = load("g10_chkpnt3_next_step.npz")
-    with torch.no_grad():                               # (the classifier's weights travel in model.pth, not in the checkpoint)
+    m.classifier = torch.nn.Conv2d(2, 2, kernel_size=1)   # (the classifier's weights travel in model.pth, not in the checkpoint:
+    with torch.no_grad():                               #  loaded BEFORE restore(), as the reference's load_ply path does)
         m.classifier.weight.copy_(nxt["classifier_weight"])
         m.classifier.bias.copy_(nxt["classifier_bias"])
+    m.restore(ckpt, cfg.optim, device=device)
     return m, ckpt, it, nxt, cfg
 
 
@@ -122,6 +124,7 @@ def test_capture_loads_into_torch_adam_and_continues_like_the_reference():
                                                                 for v in sd["state"].values())
     # a round trip through this repo's own loader keeps everything (done first: torch's optimizer aliases the tensors it loads)
     m2 = GaussianModel(cfg.model)
+    m2.classifier = torch.nn.Conv2d(2, 2, kernel_size=1)
     m2.restore(cap, cfg.optim, device="cpu")
     for name, st in m.optimizer.state.items():
         s2 = m2.optimizer.state[name]
@@ -155,6 +158,41 @@ def test_legacy_name_keyed_optimizer_state_still_loads():
     before = {k: v["exp_avg"].clone() for k, v in m.optimizer.state.items()}
     m.optimizer.load_state_dict(legacy)
     assert all(torch.equal(m.optimizer.state[k]["exp_avg"], v) for k, v in before.items())
+    # a legacy file saved before the first step has an EMPTY state: it is recognised by its groups (no `params` lists) and
+    # its learning rates -- including the classifier's two single-tensor groups -- are taken over
+    empty = dict(state={}, param_groups=[dict(name=g["name"], lr=0.25 + i) for i, g in enumerate(m.optimizer.param_groups)])
+    m.optimizer.load_state_dict(empty)
+    assert m.optimizer.state == {} and [g["lr"] for g in m.optimizer.param_groups] == [0.25 + i for i in range(len(m.optimizer.param_groups))]
+    # moments of a legacy file land on the parameter's device in float32, and a wrong shape is refused
+    half = {k: dict(step=3, exp_avg=v.double(), exp_avg_sq=v.double()) for k, v in before.items()}
+    m.optimizer.load_state_dict(dict(state=half, param_groups=legacy["param_groups"]))
+    assert all(v["exp_avg"].dtype == torch.float32 for v in m.optimizer.state.values())
+    bad = dict(half, xyz=dict(step=3, exp_avg=torch.zeros(5, 3), exp_avg_sq=torch.zeros(5, 3)))
+    with pytest.raises(ValueError, match="shape"):
+        m.optimizer.load_state_dict(dict(state=bad, param_groups=legacy["param_groups"]))
+
+
+def test_restore_without_a_classifier_skips_its_moments_and_says_so():
+    """The checkpoint holds the classifier's Adam moments but not its weights (they live in the reference's model.pth): a
+    classifier created by `restore()` is random, so its saved moments are dropped and a warning is raised; without `num_cls`
+    the call refuses to guess."""
+    from vcr_gaus_amd.trainer import load_capture
+    cfg = make_config("tnt")
+    ckpt, _ = load_capture(os.path.join(G, "g10_chkpnt3.pth"))
+    cfg.model.enable_semantic, cfg.model.ch_sem_feat, cfg.model.num_cls = True, 2, 2
+    m = GaussianModel(cfg.model)
+    with pytest.warns(UserWarning, match="randomly initialised"):
+        m.restore(ckpt, cfg.optim, device="cpu")
+    assert "classifier.weight" not in m.optimizer.state and "xyz" in m.optimizer.state
+    cfg.model.num_cls = 0
+    with pytest.raises(ValueError, match="num_cls"):
+        GaussianModel(cfg.model).restore(ckpt, cfg.optim, device="cpu")
+    # with the classifier in place before restore() its moments are kept
+    cfg.model.num_cls = 2
+    m2 = GaussianModel(cfg.model)
+    m2.classifier = torch.nn.Conv2d(2, 2, kernel_size=1)
+    m2.restore(ckpt, cfg.optim, device="cpu")
+    assert m2.optimizer.state["classifier.weight"]["step"] == 3
 
 
 @pytest.mark.gpu

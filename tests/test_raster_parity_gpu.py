@@ -6,6 +6,8 @@ max(4, 1e-3*H*W) pixels (the alpha>=1/255 and T<1e-4 cut-offs are discontinuous,
 rounding flip at one pixel moves all channels of that pixel by up to 4e-3); gradients: max-norm relative
 error <= 1e-4 x 5 per tensor against the fp64 autograd oracle (fp32 atomics accumulate in arbitrary order).
 """
+import math
+
 import pytest
 import torch
 
@@ -315,3 +317,65 @@ def test_edge_equal_depths_and_opacity_extremes(device):
     assert float(ref[7].max()) > 0.999                            # saturated pixels exist
     for k in ["means3D", "opac", "scales", "rots", "shs", "normals"]:
         util.assert_grads_close(hl[k].grad, rl[k].grad, k)
+
+
+@pytest.mark.parametrize("num_dist", [1, 2])
+def test_num_dist_through_the_drop_in_module_with_the_reference_call_sequence(device, num_dist):
+    """The reference's UNCHANGED render() (`gaussian_renderer/__init__.py:43-59,107-123,154-162`) builds
+    `GaussianRasterizer(raster_settings=...)` with nothing else, calls it with its 13 keywords (SH as ONE [N,16,3] tensor,
+    `inside=None`) and reads `rendered_out[-1:]` as the distortion map / `[-2:-1]`, `[-1:]` as the depth moments -- the number
+    of trailing channels is the fork's compile-time NUM_DIST (README.md:152-155).  Here that constant is
+    `diff_gaussian_rasterization.set_num_dist` (or VCR_NUM_DIST): replay exactly that sequence and compare what the reference
+    would slice, and the gradients through it, with the oracle."""
+    import diff_gaussian_rasterization as D
+    cam, inp, dirs = util.make_case(2500, 96, 64, 80.0, seed=29, scale_mult=6.0)
+    bg = torch.tensor([0.2, 0.1, 0.4])
+    (ref, _, _), rl = util.oracle_forward(cam, inp, dirs, bg, dtype=torch.float64, requires_grad=True, num_dist=num_dist)
+    alpha_r = ref[7:8]
+
+    def sliced(rendered_out, rendered_alpha):        # what `:154-162` derives
+        if num_dist == 2:
+            d1, d2 = rendered_out[-2:-1], rendered_out[-1:]
+            return d2 / rendered_alpha - (d1 / rendered_alpha) ** 2
+        return rendered_out[-1:]
+
+    covered = (alpha_r > 0.5).double()
+    g = torch.Generator().manual_seed(8)
+    wgt = torch.rand(1, 64, 96, generator=g, dtype=torch.float64) * covered * (1.0 if num_dist == 2 else 1e4)
+    (sliced(ref, alpha_r) * wgt).sum().backward()
+    old = D.set_num_dist(num_dist)
+    try:
+        assert D.get_num_dist() == num_dist
+        mv = lambda t: t.detach().float().to(device)
+        leaf = {k: mv(v).requires_grad_(True) for k, v in inp.items() if v is not None}
+        screenspace_points = torch.zeros_like(leaf["means3D"], requires_grad=True) + 0
+        screenspace_points_densify = torch.zeros_like(leaf["means3D"], requires_grad=True) + 0
+        screenspace_points.retain_grad()
+        screenspace_points_densify.retain_grad()
+        raster_settings = D.GaussianRasterizationSettings(
+            image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(cam.FoVx * 0.5),
+            tanfovy=math.tan(cam.FoVy * 0.5), bg=bg.to(device), scale_modifier=1.0, viewmatrix=cam.world_view_transform.to(device),
+            projmatrix=cam.full_proj_transform.to(device), sh_degree=3, campos=cam.camera_center.to(device), prefiltered=False,
+            debug=False, f_count=0)
+        rasterizer = D.GaussianRasterizer(raster_settings=raster_settings)
+        rendered_out, radii = rasterizer(
+            means3D=leaf["means3D"], means2D=screenspace_points, means2D_densify=screenspace_points_densify, shs=leaf["shs"],
+            colors_precomp=None, normals_precomp=leaf["normals"], semantics_precomp=None, opacities=leaf["opac"],
+            scales=leaf["scales"], rotations=leaf["rots"], cov3D_precomp=None, dirs=dirs.to(device), inside=None)
+    finally:
+        D.set_num_dist(old)
+    assert rendered_out.shape[0] == 8 + num_dist == ref.shape[0]
+    chs = [3, 1, 3, 1]
+    rendered_image, rendered_depth, rendered_normal, rendered_alpha = rendered_out[:sum(chs)].split(chs, dim=0)
+    assert util.bad_pixels(rendered_out[:8], ref[:8]) <= util.pixel_budget(ref)
+    got = sliced(rendered_out, rendered_alpha)
+    want = sliced(ref, alpha_r)
+    sel = covered.bool()
+    assert util.frac_bad(got.cpu()[sel], want[sel], 2e-3, 1e-8 if num_dist == 1 else 1e-5) < 2e-3
+    (got * wgt.float().to(device)).sum().backward()
+    for k in ["means3D", "normals", "opac", "scales", "rots", "shs"]:
+        e = util.rel_err(leaf[k].grad, rl[k].grad)
+        assert e < 2e-3, f"grad {k}: rel err {e}"
+    assert screenspace_points_densify.grad is not None and screenspace_points.grad.shape == (2500, 3)
+    # and the default stays what the reference's TNT / 360 configurations expect: no trailing channel
+    assert D.get_num_dist() == old

@@ -170,15 +170,14 @@ class FusedAdam:
                 raise RuntimeError(f"geometry_step: the backward saw another `{name}` tensor than the optimizer holds")
         gx = model._xyz.grad
         st = {k: self._state(groups[k]) for k in ("xyz", "scaling", "rotation", "opacity")}
-        for k in st:
-            if k != "xyz" or gx is not None:
-                st[k]["step"] += 1
+        # the counters are advanced only once the launch has been accepted: a failed call must not shift the bias correction
+        nxt = {k: st[k]["step"] + (1 if (k != "xyz" or gx is not None) else 0) for k in st}
         ptr = lambda t: None if t is None else t.data_ptr()
         gxc = None if gx is None else gx.contiguous()
         sreg = sink.scale_reg
         a = _lib.VcrGeometryStep(
-            N=N, step_xyz=st["xyz"]["step"] if gx is not None else 0, step_scaling=st["scaling"]["step"],
-            step_rotation=st["rotation"]["step"], step_opacity=st["opacity"]["step"],
+            N=N, step_xyz=nxt["xyz"] if gx is not None else 0, step_scaling=nxt["scaling"],
+            step_rotation=nxt["rotation"], step_opacity=nxt["opacity"],
             xyz=model._xyz.data_ptr(), scaling=sr.data_ptr(), rotation=rr.data_ptr(), opacity=orr.data_ptr(),
             d_means3D=ptr(gxc), d_scales=ptr(d_scales), d_rots=ptr(d_rots), d_opac=ptr(d_opac), d_normals=ptr(d_nrm),
             aux=aux.data_ptr(), Rw2c=Rw.data_ptr(),
@@ -195,6 +194,8 @@ class FusedAdam:
             denom=None if grad2d is None else model.denom.data_ptr(),
             max_radii=None if grad2d is None else model.max_radii2D.data_ptr())
         _lib.check(lib.vcr_geometry_step(C.byref(a), _lib.stream_of(model._xyz)))
+        for k in st:
+            st[k]["step"] = nxt[k]
         model._xyz.grad = None
 
     @torch.no_grad()
@@ -306,12 +307,21 @@ class FusedAdam:
         for g in self.param_groups:
             by_wire.setdefault(self._wire_name(g["name"]), []).append(g)
         self.state = {}
-        if sd["state"] and not all(isinstance(k, int) for k in sd["state"]):          # legacy: state keyed by group name
+        legacy = any("params" not in g for g in sd["param_groups"]) or \
+            (sd["state"] and not all(isinstance(k, int) for k in sd["state"]))
+        if legacy:                                              # older files of this repo: state keyed by group name
+            mine = {g["name"]: g for g in self.param_groups}
             for k, v in sd["state"].items():
-                self.state[k] = dict(step=int(v["step"]), exp_avg=v["exp_avg"], exp_avg_sq=v["exp_avg_sq"])
+                if k not in mine:
+                    continue
+                p = mine[k]["params"][0]
+                if tuple(v["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state of {k!r} has shape {tuple(v['exp_avg'].shape)}, parameter {tuple(p.shape)}")
+                mv = lambda t: t.detach().to(device=p.device, dtype=torch.float32).contiguous()
+                self.state[k] = dict(step=int(round(float(v["step"]))), exp_avg=mv(v["exp_avg"]), exp_avg_sq=mv(v["exp_avg_sq"]))
             lrs = {g["name"]: g["lr"] for g in sd["param_groups"]}
             for g in self.param_groups:
-                g["lr"] = lrs.get(g["name"], g["lr"])
+                g["lr"] = float(lrs.get(g["name"], g["lr"]))
             return
         for wg in sd["param_groups"]:
             mine = by_wire.get(wg.get("name"))
@@ -794,8 +804,17 @@ class GaussianModel:
             self.enable_semantic = True
             self._objects_dc = mk(obj_dc)
             self.ch_sem_feat = int(obj_dc.shape[-1])
-            self.num_cls = self.num_cls or 2
-            if self.classifier is None:          # (its weights travel in the reference's model.pth, not in the checkpoint)
+            fresh_classifier = self.classifier is None
+            if fresh_classifier:
+                # the classifier's WEIGHTS travel in the reference's model.pth, not in the checkpoint
+                # (`scene/gaussian_model.py:304-311`); the checkpoint only holds their Adam moments.  A classifier created
+                # here is randomly initialised: its saved moments belong to other weights and are NOT restored.
+                if not self.num_cls:
+                    raise ValueError("restore(): the checkpoint carries semantic features but the model has no classifier and "
+                                     "cfg.num_cls is unset -- load / construct the classifier (model.pth) before restore()")
+                import warnings
+                warnings.warn("restore(): no classifier loaded before the checkpoint; a randomly initialised one is created and "
+                              "its optimizer state in the checkpoint is skipped (load model.pth first to resume semantics)")
                 self.classifier = torch.nn.Conv2d(self.ch_sem_feat, self.num_cls, kernel_size=1)
             self.classifier = self.classifier.to(dev)
         else:
@@ -805,3 +824,6 @@ class GaussianModel:
         self.training_setup(training_args)
         self.xyz_gradient_accum, self.denom = acc.detach().to(dev).float(), den.detach().to(dev).float()
         self.optimizer.load_state_dict(opt)
+        if obj_dc is not None and obj_dc.numel() > 0 and fresh_classifier:
+            for k in ("classifier.weight", "classifier.bias"):
+                self.optimizer.state.pop(k, None)

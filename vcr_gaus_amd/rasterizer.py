@@ -7,6 +7,7 @@ the arithmetic is in libvcr_raster.so (HIP, gfx950) reached through ctypes.
 from typing import NamedTuple, Optional
 
 import ctypes as _ct
+import os as _os
 
 import torch
 import torch.nn as nn
@@ -114,7 +115,35 @@ class RasterRecord:
         return out
 
 
-NUM_DIST = 0      # trailing channels, the fork's compile-time `NUM_DIST` (README.md:155): 0, 1 = distortion, 2 = sum w d, sum w d^2
+def _num_dist_from_env():
+    v = _os.environ.get("VCR_NUM_DIST", "0")
+    if v not in ("0", "1", "2"):
+        raise RuntimeError(f"vcr_raster: VCR_NUM_DIST={v!r}; expected 0, 1 (distortion) or 2 (depth moments)")
+    return int(v)
+
+
+# Trailing output channels of a `GaussianRasterizer(raster_settings=...)` built WITHOUT `num_dist` -- i.e. by the reference's
+# unchanged render(), which reads `rendered_out[-1:]` as the distortion map or `[-2:-1]`, `[-1:]` as the depth moments
+# (`gaussian_renderer/__init__.py:154-162`).  In the fork this is the compile-time constant `NUM_DIST` of
+# cuda_rasterizer/config.h (README.md:152-155: "set NUM_DIST = 1 ... and reinstall"); here it is a run-time setting of the
+# module: environment VCR_NUM_DIST at import, or `diff_gaussian_rasterization.set_num_dist(n)`.
+#   0  no trailing channel (C = 8 + S)
+#   1  depth distortion                          -> cfg.optim.loss_weight.distortion > 0 (the DTU configuration)
+#   2  depth moments sum w d, sum w d^2          -> cfg.optim.loss_weight.depth_var > 0
+NUM_DIST = _num_dist_from_env()
+
+
+def set_num_dist(n):
+    """Run-time counterpart of editing `NUM_DIST` in the fork's config.h and reinstalling.  Returns the previous value."""
+    global NUM_DIST
+    if n not in (0, 1, 2):
+        raise ValueError("num_dist must be 0, 1 (distortion) or 2 (depth moments)")
+    old, NUM_DIST = NUM_DIST, int(n)
+    return old
+
+
+def get_num_dist():
+    return NUM_DIST
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -163,7 +192,6 @@ class _RasterizeGaussians(torch.autograd.Function):
         out = torch.empty((C if fc == 0 else 3, H, W), dtype=torch.float32, device=dev) if fc != 3 else None
         radii = torch.empty(N, dtype=torch.int32, device=dev)      # fully written by the preprocess kernel
         count = torch.zeros(N, dtype=torch.int32, device=dev) if fc != 0 else None
-        import os as _os
         if fc == 0 and _os.environ.get("VCR_TIMING"):       # experiment builds only (-DVCR_TIMING)
             count = torch.zeros(((H + 15) // 16) * ((W + 15) // 16) * 32, dtype=torch.int32, device=dev)
             rec.timing = count

@@ -24,6 +24,17 @@ from .loss_utils import (curv_loss, edge_aware_mean, entropy_regulariser, l1_ssi
                          semantic_loss)
 
 
+def load_capture(path):
+    """`torch.load(path, weights_only=True)` of a `(GaussianModel.capture(), iteration)` file.  The reference's own files hold a
+    few numpy scalars beside the tensors (`spatial_lr_scale`, learning rates from `get_expon_lr_func`), so numpy's scalar
+    reconstructor and dtype classes are allow-listed -- data only, no code."""
+    import numpy as np
+    from torch.serialization import safe_globals
+    allow = [np._core.multiarray.scalar, np.dtype] + [type(np.dtype(t)) for t in (np.float64, np.float32, np.int64, np.int32)]
+    with safe_globals(allow):
+        return torch.load(path, map_location="cpu", weights_only=True)
+
+
 class Trainer:
     def __init__(self, cfg, model, cameras, extent, device, world=1, rank=0, dirs=None, seed=0, force_factorised=False,
                  overlap_sh=None, overlap_min_gaussians=400_000):
@@ -380,10 +391,17 @@ class Trainer:
         if self.rank == 0:
             torch.save(state, path)
 
-    def load_checkpoint(self, path):
-        """Resume from a `chkpntN.pth` written by `save_checkpoint` or by the reference's trainer."""
+    def load_checkpoint(self, path, trust_pickle=False):
+        """Resume from a `chkpntN.pth` written by `save_checkpoint` or by the reference's trainer.  The captured tuple holds
+        tensors, numbers and dicts only, so the file is read with `weights_only=True`; `trust_pickle=True` falls back to the
+        reference's unrestricted `torch.load` (`trainer.py:170`), which EXECUTES code from the file -- only for files you wrote."""
         self.join_side()
-        model_params, first_iter = torch.load(path, map_location="cpu", weights_only=False)
+        try:
+            model_params, first_iter = load_capture(path)
+        except Exception:
+            if not trust_pickle:
+                raise
+            model_params, first_iter = torch.load(path, map_location="cpu", weights_only=False)
         self.model.restore(model_params, self.cfg.optim, device=self.device)
         self.model.extent = self.extent
         self.current_iteration = int(first_iter)
@@ -494,6 +512,12 @@ class Trainer:
                 vp = data["viewspace_points_densify"]
                 m.optimizer.geometry_step(m, sink, grad2d=vp.grad.contiguous() if (stats and vp.grad is not None) else None,
                                           radii=data["radii"] if stats else None)
+                # the one-kernel tail has applied Adam to these groups; a gradient that reached them by another path (a loss
+                # built on the plain getters) would be applied a SECOND time by optimizer.step() below
+                stray = [k for k in ("_scaling", "_rotation", "_opacity") if getattr(m, k).grad is not None]
+                if stray:
+                    raise RuntimeError(f"fused geometry tail: {stray} received a gradient outside the fused activation node; "
+                                       "set Trainer.fuse_geometry = False for losses on the plain getters")
                 if stats and it > cfg.optim.densify_from_iter and "countlist" in data:                  # `trainer.py:350-356`
                     cl = data["countlist"]
                     self.visi_list = cl if self.visi_list is None else self.visi_list + cl
