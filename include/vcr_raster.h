@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 15
+#define VCR_ABI_VERSION 16
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -54,7 +54,10 @@ typedef struct VcrRasterArgs {
     int32_t S;            /* semantic channels in semantics_precomp (0..4) */
     int32_t K;            /* SH coefficients stored per Gaussian in `shs` ((max_sh_degree+1)^2) */
     int32_t sh_degree;    /* active degree 0..3 */
-    int32_t f_count;      /* 0 render, 1 count+score+image, 2 same (countlist), 3 count only */
+    int32_t f_count;      /* 0 render, 1 count+score+image, 2 same (countlist), 3 count only; 4 (extension): like 3, but
+                             count[i] is SET to 1 when Gaussian i contributes to any pixel instead of being incremented by
+                             the number of pixels -- all that the consumer of the visibility passes reads (`> 0`,
+                             tools/prune.py:64-66) */
     int32_t num_dist;     /* trailing channels: 0 none; 1 depth distortion A*M2 - M1^2 of the mapped depth
                              m = far/(far-near)*(1-near/d) (2DGS form; near .01, far 100); 2 depth moments (sum w d, sum w d^2) */
     int32_t debug;
@@ -86,6 +89,15 @@ typedef struct VcrRasterArgs {
     const VcrShUpdate* sh_update;   /* optional, with colour_stream: see VcrShUpdate */
     void* sort_stream;          /* optional third HIP stream: the depth keys and the depth sort of the N Gaussians run there,
                                    beside the projection, and are joined before the tile instances are emitted */
+    int32_t quad_lists;         /* 0: tile instances are binned per 16x16 tile, the four 8x8-quad waves of a tile share its
+                                   list.  1: binned per 8x8 quad -- the exact rejection of the projection runs per quad, the sort
+                                   key is the quad index (2 more bits), every compositing wave walks the list of ITS quad only:
+                                   no entry is gathered or culled four times (-33 % HBM fetch of both compositing kernels at
+                                   1 M Gaussians / 1080p) at the price of 1.3-1.6x sort entries when footprints are small and
+                                   up to 4x when they cover whole tiles.  Same image, same gradients (positions in a list are
+                                   internal to a forward / backward pair; the backward follows the forward's choice).  Pays for
+                                   small footprints (R / V below ~4 tiles per visible Gaussian); images up to 8192 pixels. */
+    int32_t pad_;
 } VcrRasterArgs;
 
 /* Forward outputs.  `out`, `radii`, counters are caller-allocated. */
@@ -139,6 +151,38 @@ const char* vcr_last_error(void);
  * behind GaussianRasterizer.forward, gaussian_renderer/__init__.py:107) */
 int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* out,
                           vcr_alloc_fn alloc, void* user, void* stream);
+/* The visibility passes of a densification step (trainer.py:357-370,688-702; tools/prune.py:51-69 `get_visi_list`): the
+ * reference renders `sample_cams.num` (TNT: 200) virtual cameras with f_count = 3, one rasterizer call each, and sums the
+ * per-Gaussian counters.  Here ONE call takes all B cameras (same resolution): geometry-only projection (no SH -> RGB),
+ * depth order, instance emission, tile sort and count-only compositing of up to `inflight` cameras run concurrently on
+ * internal HIP streams (forked from / joined into `stream`), the host reads the instance counts of a camera while the
+ * later cameras' front halves run, and the counters accumulate on the device.
+ *   flags_only = 0: count[i] += number of pixels over all B cameras where Gaussian i passed the alpha and transmittance
+ *                   tests -- identical to B calls of vcr_rasterize_forward with f_count = 3;
+ *   flags_only = 1: count[i] = 1 if that number is > 0 (f_count = 4), else untouched.
+ * Buffers come from `alloc` (tag VCR_BUF_SCRATCH) and may be released when the call returns. */
+typedef struct VcrVisibilityBatch {
+    int32_t N, H, W, B;
+    int32_t flags_only;
+    int32_t inflight;             /* cameras in flight (= buffer sets), 0 = 8, at most 16; they share up to 8 internal streams */
+    int32_t quad_lists;           /* as VcrRasterArgs.quad_lists */
+    float scale_modifier;
+    const float* tanfovx;         /* HOST [B] */
+    const float* tanfovy;         /* HOST [B] */
+    const float* viewmatrix;      /* device [B,4,4] world_view_transform of every camera */
+    const float* projmatrix;      /* device [B,4,4] full_proj_transform */
+    const float* campos;          /* device [B,3] */
+    const float* means3D;         /* [N,3] */
+    const float* opacities;       /* [N] */
+    const float* scales;          /* [N,3] or NULL */
+    const float* rotations;       /* [N,4] or NULL */
+    const float* cov3D_precomp;   /* [N,6] or NULL (exactly one of scales+rotations / cov3D_precomp) */
+    int32_t* count;               /* [N] device, accumulated */
+    int64_t* num_rendered;        /* optional HOST [B]: 3-sigma tile instances of every camera */
+    int32_t* num_visible;         /* optional HOST [B]: Gaussians with radii > 0 */
+} VcrVisibilityBatch;
+int vcr_visibility_batch(const VcrVisibilityBatch* args, vcr_alloc_fn alloc, void* user, void* stream);
+
 /* replaces diff_gaussian_rasterization._C.rasterize_gaussians_backward (reached from
  * loss.backward(), trainer.py:338) */
 int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* io,

@@ -342,3 +342,59 @@ def test_bench_gpus_flag_relaunches_itself_as_n_ranks(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "2")
     with pytest.raises(AssertionError, match="--gpus 4"):
         bench.main()
+
+
+def rs_ag_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vcr_gaus_amd.rasterizer import RasterRecord
+    res = {}
+    for algo in ("allreduce", "rs_ag"):
+        m = _sh_model()
+        tr = Trainer(make_config("tnt"), m, [_Cam(i) for i in range(9)], 1.0, torch.device("cpu"), world=world, rank=rank, seed=3,
+                     exchange=algo)
+        for mode in ("serial", "deferred"):
+            cams = tr._next_cameras()
+            view_data(cams[rank], m)
+            rec = RasterRecord()
+            rec.drgb, rec.view_dirs = torch.randn(N, 3, generator=torch.Generator().manual_seed(500 + cams[rank])), torch.zeros(N, 3)
+            if mode == "serial":
+                def rebuild(drgb_all, campos_all, m=m):
+                    g = sum(_basis_outer(m._xyz.detach(), campos_all[v], drgb_all[v], 3) for v in range(drgb_all.shape[0]))
+                    return g[:, :1].contiguous(), g[:, 1:].contiguous()
+                tr._sh_grads_from_rgb = rebuild
+                tr._exchange_grads(False, True, rec)                  # (surgery step: serial exchange, no early feature step)
+            else:
+                tr._exchange_grads(True, False, rec)
+            res[(algo, mode)] = dict(gx=m._xyz.grad.clone(), go=m._opacity.grad.clone(), ex=tr.last_exchange,
+                                     numel=m._xyz.grad.numel() + m._opacity.grad.numel())
+            m.optimizer.step()
+            for g in m.optimizer.param_groups:
+                g["params"][0].grad = None
+            tr.join_side()
+        res[(algo, "params")] = dict(xyz=m._xyz.detach().clone(), op=m._opacity.detach().clone(), dc=m._features_dc.detach().clone())
+    torch.save(res, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reduce_scatter_all_gather_exchange_equals_the_all_reduce(tmp_path, world):
+    """`Trainer(exchange="rs_ag")`: the geometry bucket goes through reduce-scatter + all-gather (padded to a multiple of
+    the ranks: world 3 exercises the padding) instead of one all-reduce -- same summed gradients on every rank, in the
+    serial and in the deferred (two-stream) form, and the replicas end with the same parameters."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "rsag.pt")
+    mp.spawn(rs_ag_worker, args=(world, port, out), nprocs=world, join=True)
+    rs = [torch.load(out + f".{r}") for r in range(world)]
+    for mode in ("serial", "deferred"):
+        a, b = rs[0][("allreduce", mode)], rs[0][("rs_ag", mode)]
+        assert b["ex"].endswith("+rs_ag") and not a["ex"].endswith("+rs_ag")
+        assert torch.allclose(a["gx"], b["gx"], rtol=1e-6, atol=1e-7) and torch.allclose(a["go"], b["go"], rtol=1e-6, atol=1e-7)
+        for r in range(1, world):                                  # every rank holds the same sums
+            assert torch.equal(rs[r][("rs_ag", mode)]["gx"], b["gx"]) and torch.equal(rs[r][("rs_ag", mode)]["go"], b["go"])
+    if world == 3:
+        assert rs[0][("rs_ag", "serial")]["numel"] % 3 != 0          # (the bucket really needed padding)
+    for k in ("xyz", "op", "dc"):
+        assert torch.allclose(rs[0][("allreduce", "params")][k], rs[0][("rs_ag", "params")][k], rtol=1e-6, atol=1e-7)
+        for r in range(1, world):
+            assert torch.equal(rs[r][("rs_ag", "params")][k], rs[0][("rs_ag", "params")][k])

@@ -922,3 +922,63 @@ def test_fused_semantic_loss_equals_conv_plus_cross_entropy(device, S, K):
     bad[3, 4] = K
     with pytest.raises(ValueError, match="labels span"):
         semantic_loss(sem0.to(device), c, bad.to(device))
+
+
+def test_batched_visibility_equals_the_per_camera_passes(device):
+    """`vcr_visibility_batch` (B cameras in one call: geometry-only projection, several cameras in flight on internal
+    streams, buffer sets re-used, counters accumulated on the device) against the reference's form -- one f_count = 3 render
+    per camera, `countlist`s summed (`tools/prune.py:51-69`): identical integers, for every number of cameras in flight; the
+    flag form equals `sum > 0`; cameras of two resolutions in one list; and the sum against the oracle's counts."""
+    from vcr_gaus_amd import synthetic
+    from vcr_gaus_amd.gaussian_renderer import visi_acc_render, visibility_counts
+    from vcr_gaus_amd.rasterizer import visibility_batch
+    from vcr_gaus_amd.trainer import make_synthetic_trainer
+    raw = synthetic.make_gaussians(6000, seed=3)
+    raw["scaling"] = raw["scaling"] + 1.1
+    cams = synthetic.make_cameras(21, 112, 80, 95.0, device=device) + synthetic.make_cameras(5, 64, 96, 70.0, radius=2.2, device=device)
+    tr = make_synthetic_trainer(raw, cams[:3], device)
+    m, pipe = tr.model, tr.cfg.pipline
+    ref = torch.zeros(6000, dtype=torch.int32, device=device)
+    per_cam_R = []
+    for cam in cams:
+        pkg = visi_acc_render(cam, m, pipe, tr.background)
+        ref += pkg["countlist"]
+    assert int((ref > 0).sum()) > 1000
+    got = visibility_counts(cams, m, pipe)
+    assert got.dtype == torch.int32 and torch.equal(got, ref)
+    flags = visibility_counts(cams, m, pipe, flags_only=True)
+    assert torch.equal(flags, (ref > 0).int())
+    # accumulation into a caller's tensor, and every in-flight depth (1 set ... more sets than cameras)
+    from vcr_gaus_amd.gaussian_renderer import fused_activate, _cam_rotation
+    import math as _m
+    sc, ro, op = fused_activate(m, cams[0].camera_center, _cam_rotation(cams[0], device), False)
+    big = cams[:21]
+    vm = torch.stack([c.world_view_transform for c in big]); pm = torch.stack([c.full_proj_transform for c in big])
+    cc = torch.stack([c.camera_center for c in big])
+    tx, ty = [_m.tan(c.FoVx * 0.5) for c in big], [_m.tan(c.FoVy * 0.5) for c in big]
+    want = torch.zeros_like(ref)
+    for cam in big:
+        want += visi_acc_render(cam, m, pipe, tr.background)["countlist"]
+    for inflight in (1, 3, 4, 8, 16, 64):
+        acc = torch.full((6000,), 7, dtype=torch.int32, device=device)
+        cnt, R, V = visibility_batch(vm, pm, cc, tx, ty, 80, 112, m.get_xyz, op, sc, ro, inflight=inflight, count=acc)
+        assert cnt is acc and torch.equal(acc - 7, want), inflight
+        assert len(R) == 21 and all(r > 0 for r in R) and all(0 < v <= 6000 for v in V)
+    # the plain forward accepts the flag mode too (f_count = 4: count SET to 1)
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    cam = cams[2]
+    rs = GaussianRasterizationSettings(image_height=80, image_width=112, tanfovx=_m.tan(cam.FoVx * 0.5), tanfovy=_m.tan(cam.FoVy * 0.5),
+                                       bg=tr.background, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+                                       projmatrix=cam.full_proj_transform, sh_degree=0, campos=cam.camera_center, f_count=4)
+    c3, _ = GaussianRasterizer(rs)(means3D=m.get_xyz, means2D=None, opacities=op, shs=m._features_dc, shs_rest=m._features_rest,
+                                   scales=sc, rotations=ro)
+    # against the oracle (single camera: the counts of f_count = 3 are those of the count render)
+    from tests import util
+    cam_c, inp, dirs = util.make_case(3000, 96, 64, 80.0, seed=9, scale_mult=6.0)
+    (rc, _, _, _, _), _ = util.oracle_forward(cam_c, inp, dirs, torch.zeros(3), f_count=1, use_normals=False)
+    mv = lambda t: t.float().to(device)
+    cnt, _, _ = visibility_batch(mv(cam_c.world_view_transform)[None], mv(cam_c.full_proj_transform)[None], mv(cam_c.camera_center)[None],
+                                 [_m.tan(cam_c.FoVx * 0.5)], [_m.tan(cam_c.FoVy * 0.5)], 64, 96, mv(inp["means3D"]), mv(inp["opac"]),
+                                 mv(inp["scales"]), mv(inp["rots"]))
+    assert float((cnt.cpu() != rc).double().mean()) < 1e-3
+    assert int(c3.max()) == 1 and torch.equal(c3 > 0, visi_acc_render(cam, m, pipe, tr.background)["countlist"] > 0)

@@ -379,3 +379,49 @@ def test_num_dist_through_the_drop_in_module_with_the_reference_call_sequence(de
     assert screenspace_points_densify.grad is not None and screenspace_points.grad.shape == (2500, 3)
     # and the default stays what the reference's TNT / 360 configurations expect: no trailing channel
     assert D.get_num_dist() == old
+
+
+@pytest.mark.parametrize("case", ["small", "ragged_big_footprints", "semantic_dist"])
+def test_quad_granular_binning_gives_the_same_render_and_gradients(device, case):
+    """`RasterOptions.quad_lists`: tile instances binned per 8x8 quad, every compositing wave walks its own list.  Every pixel
+    sees the same Gaussians in the same order, so the image is bit-identical to the per-tile form and the gradients agree to
+    the order of the fp32 atomics; both against the oracle as well.  Cases: the small parity scene; an image whose sides are
+    no multiples of 8 with footprints from a few pixels to most of the frame (cell masks of 32 and 64 bits and unmasked
+    rectangles); semantic channels + depth moments."""
+    from vcr_gaus_amd.rasterizer import RasterOptions
+    if case == "small":
+        cam, inp, dirs = util.make_case(3000, 96, 64, 80.0, seed=31, scale_mult=6.0)
+        nd = 0
+    elif case == "ragged_big_footprints":
+        cam, inp, dirs = util.make_case(1500, 203, 117, 150.0, seed=32, scale_mult=5.0)
+        g = torch.Generator().manual_seed(1)
+        inp["scales"] = inp["scales"] * torch.exp(2.2 * torch.rand(1500, 1, generator=g) ** 3)       # a tail of screen-filling ones
+        nd = 0
+    else:
+        cam, inp, dirs = util.make_case(2500, 96, 64, 80.0, seed=33, scale_mult=6.0, sem=2)
+        nd = 2
+    bg = torch.tensor([0.3, 0.2, 0.1])
+    (ref, _, _), rl = util.oracle_forward(cam, inp, dirs, bg, dtype=torch.float64, requires_grad=True, num_dist=nd)
+    gen = torch.Generator().manual_seed(4)
+    wgt = torch.randn(ref.shape, generator=gen, dtype=torch.float64)
+    (ref * wgt).sum().backward()
+    outs, leaves = [], []
+    for ql in (False, True):
+        (out, radii), hl = util.hip_forward(cam, inp, dirs, bg, device, requires_grad=True, num_dist=nd,
+                                            options=RasterOptions(quad_lists=ql))
+        (out * wgt.float().to(device)).sum().backward()
+        outs.append((out.detach(), radii)); leaves.append(hl)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert leaves[0]["record"].R == leaves[1]["record"].R and leaves[0]["record"].V == leaves[1]["record"].V
+    assert leaves[1]["record"].emitted >= leaves[0]["record"].emitted > 0          # (quads: at least one entry per reached tile)
+    assert util.bad_pixels(outs[1][0][:8], ref[:8]) <= util.pixel_budget(ref)
+    keys = ["means3D", "shs", "opac", "scales", "rots", "normals"] + (["sem"] if case == "semantic_dist" else [])
+    for k in keys:
+        assert util.rel_err(leaves[1][k].grad, leaves[0][k].grad) < 2e-5, k
+        if case != "ragged_big_footprints":
+            util.assert_grads_close(leaves[1][k].grad, rl[k].grad, k)
+    assert util.rel_err(leaves[1]["m2d"].grad, leaves[0]["m2d"].grad) < 2e-5
+    # count modes follow the same lists
+    (c0, _), _ = util.hip_forward(cam, inp, dirs, bg, device, f_count=3, use_normals=False)
+    (c1, _), _ = util.hip_forward(cam, inp, dirs, bg, device, f_count=3, use_normals=False, options=RasterOptions(quad_lists=True))
+    assert torch.equal(c0, c1)

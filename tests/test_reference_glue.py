@@ -191,19 +191,22 @@ def test_product_glue_matches_the_reference(device, monkeypatch, pre, fused):
     cfg, cam = c.config(), c.camera(device)
     model = GaussianModel(cfg.model)
     model.create_from_params(c.raw(), spatial_lr_scale=1.0, device=device)
+    model.trans, model.scale = torch.zeros(3, device=device), torch.ones(3, device=device)
     model.active_sh_degree = c.sh_degree
     if c.sem_on:
         with torch.no_grad():
-            model.classifier.weight.copy_(c.t("cls_w", device))
-            model.classifier.bias.copy_(c.t("cls_b", device))
+            model.classifier.weight.copy_(c.t("cls_w", device).float())
+            model.classifier.bias.copy_(c.t("cls_b", device).float())
     model.training_setup(cfg.optim)
-    dirs = c.t("dirs", device)
+    dirs = c.t("dirs", device).float()
     tr = Trainer(cfg, model, [cam], float(c["extent"]), device, dirs=dirs, overlap_sh=False)
     tr.current_iteration = c.it
     tr.use_fused_losses = fused
     extra = tr.active_extra_losses(c.it)
     takes_fused = fused and not extra
-    g = lambda k: c.t(k, device)
+    def g(k):                                      # the fixture is fp64; the product computes in fp32
+        v = c.t(k, device)
+        return v.float() if v.is_floating_point() else v
     dsh = torch.cat([g("grad_f_dc"), g("grad_f_rest")], 1)            # d/d shs = the raw SH gradients (get_features is a cat)
     box = dict(out=g("rendered_out"), radii=g("radii"),
                dargs=dict(means3D=g("darg_means3D"), means2D=g("darg_means2D"), means2D_densify=g("darg_means2D_densify"),

@@ -16,7 +16,7 @@ c_int_p = C.POINTER(C.c_int32)
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 BUF_GEOM, BUF_BINNING, BUF_IMAGE, BUF_SCRATCH = 0, 1, 2, 3
-ABI_VERSION = 15         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
+ABI_VERSION = 16         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
 
 
 class VcrShUpdate(C.Structure):
@@ -59,6 +59,7 @@ class VcrRasterArgs(C.Structure):
         ("normals_precomp", C.c_void_p), ("semantics_precomp", C.c_void_p), ("opacities", C.c_void_p),
         ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("dirs", C.c_void_p),
         ("colour_stream", C.c_void_p), ("colour_stream_hook", C.c_void_p), ("colour_stream_hook_user", C.c_void_p), ("sh_update", C.c_void_p), ("sort_stream", C.c_void_p),
+        ("quad_lists", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -68,6 +69,14 @@ class VcrForwardOut(C.Structure):
         ("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p),
         ("num_rendered", C.c_int64), ("num_visible", C.c_int32), ("max_tile_len", C.c_int32), ("num_emitted", C.c_int64),
     ]
+
+
+class VcrVisibilityBatch(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("B", C.c_int32), ("flags_only", C.c_int32),
+                ("inflight", C.c_int32), ("quad_lists", C.c_int32), ("scale_modifier", C.c_float), ("tanfovx", c_float_p), ("tanfovy", c_float_p)] + \
+               [(k, C.c_void_p) for k in ("viewmatrix", "projmatrix", "campos", "means3D", "opacities", "scales", "rotations",
+                                          "cov3D_precomp", "count")] + \
+               [("num_rendered", C.POINTER(C.c_int64)), ("num_visible", c_int_p)]
 
 
 class VcrBackwardIO(C.Structure):
@@ -87,6 +96,7 @@ SYMBOLS = {
     "vcr_last_error": (C.c_char_p, []),
     "vcr_rasterize_forward": (C.c_int, [C.POINTER(VcrRasterArgs), C.POINTER(VcrForwardOut), ALLOC_FN, C.c_void_p, C.c_void_p]),
     "vcr_rasterize_backward": (C.c_int, [C.POINTER(VcrRasterArgs), C.POINTER(VcrBackwardIO), ALLOC_FN, C.c_void_p, C.c_void_p]),
+    "vcr_visibility_batch": (C.c_int, [C.POINTER(VcrVisibilityBatch), ALLOC_FN, C.c_void_p, C.c_void_p]),
     "vcr_activate_forward": (C.c_int, [C.c_int] + [C.c_void_p] * 12),
     "vcr_activate_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 14),
     "vcr_sort_pairs_u32_scratch_bytes": (C.c_size_t, [C.c_int64]),

@@ -30,29 +30,31 @@ constexpr int DUP_ROUNDS = 4;                       // Gaussians per thread: 102
 // `status`: one zeroed 64-bit word per block; `ticket`: one zeroed word.
 __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, const uint32_t* __restrict__ ids_sorted,
                                                         unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket,
-                                                        const uint2* __restrict__ rect, uint2* __restrict__ inst_out,
-                                                        uint2* __restrict__ ranges, int num_tiles) {
+                                                        const uint2* __restrict__ rect, const uint32_t* __restrict__ rect_hi,
+                                                        uint2* __restrict__ inst_out, uint2* __restrict__ ranges, int num_tiles,
+                                                        int gx_keys) {
     __shared__ uint32_t s_gend[4][64], s_start[4][64], s_id[4][64];
     __shared__ int s_xmin[4][64], s_ymin[4][64], s_w[4][64];
     __shared__ uint32_t s_wtot[DUP_ROUNDS][4], s_prefix, s_bid;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int gx = (W + VCR_TILE - 1) / VCR_TILE;
+    const int gx = gx_keys;                             // keys per row: tiles, or 8x8 cells in quad-list mode (rect is in the same unit)
     for (int t = blockIdx.x * 256 + threadIdx.x; t < num_tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);   // empty tiles
     if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
     __syncthreads();
     const int bid = (int)s_bid;
     // round r of this block covers the Gaussians base + r*256 + tid of the depth order
     const int base = bid * (256 * DUP_ROUNDS);
-    uint32_t id[DUP_ROUNDS], cnt[DUP_ROUNDS], inc[DUP_ROUNDS];
+    uint32_t id[DUP_ROUNDS], cnt[DUP_ROUNDS], inc[DUP_ROUNDS], mhi[DUP_ROUNDS];
     uint2 rc[DUP_ROUNDS];
 #pragma unroll
     for (int r = 0; r < DUP_ROUNDS; ++r) {
         const int gi = base + r * 256 + (int)threadIdx.x;
-        id[r] = 0; cnt[r] = 0; rc[r] = make_uint2(0u, 0u);
+        id[r] = 0; cnt[r] = 0; mhi[r] = 0; rc[r] = make_uint2(0u, 0u);
         if (gi < N) {
             id[r] = ids_sorted[gi];
             rc[r] = rect[id[r]];                          // {0, 0} for culled Gaussians
-            cnt[r] = (rc[r].x & VCR_RECT_MASKED) ? (uint32_t)__popc(rc[r].y) : (rc[r].y & 0xFFFFu) * (rc[r].y >> 16);
+            if ((rc[r].x & (VCR_RECT_MASKED | VCR_RECT_MASK64)) == (VCR_RECT_MASKED | VCR_RECT_MASK64)) mhi[r] = rect_hi[id[r]];
+            cnt[r] = (rc[r].x & VCR_RECT_MASKED) ? (uint32_t)(__popc(rc[r].y) + __popc(mhi[r])) : (rc[r].y & 0xFFFFu) * (rc[r].y >> 16);
         }
     }
 #pragma unroll
@@ -106,9 +108,10 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
         const int xmin = (int)(rc[r].x & 0x3FFu), ymin = (int)((rc[r].x >> 10) & 0x3FFu);
         if (masked) {                                      // walk the set bits of the tile mask
             const int w = (int)((rc[r].x >> 20) & 31u) + 1;
-            uint32_t m = rc[r].y, at = start;
+            unsigned long long m = ((unsigned long long)mhi[r] << 32) | rc[r].y;
+            uint32_t at = start;
             while (m) {
-                const int k = __builtin_ctz(m);
+                const int k = __builtin_ctzll(m);
                 m &= m - 1;
                 inst_out[at] = make_uint2((uint32_t)((ymin + k / w) * gx + xmin + k % w), id[r]);      // (tile, Gaussian)
                 ++at;
@@ -181,14 +184,17 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
                            int num_tiles, uint32_t* totals, void* temp, size_t temp_bytes, hipStream_t st) {
     static const bool no_lpt = getenv("VCR_NO_LPT") != nullptr;          // experiment switches
     static const bool no_snake = getenv("VCR_NO_SNAKE") != nullptr;
+    const int gx_tiles = (a.W + VCR_TILE - 1) / VCR_TILE;
+    const bool ql = a.quad_lists != 0;
+    const int num_keys = ql ? 4 * num_tiles : num_tiles, gx_keys = ql ? 2 * gx_tiles : gx_tiles;
     if (R <= 0) {
-        VCR_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, st));
-        return vcr_launch_tile_order(num_tiles, ranges, tile_order, meta, 0, false, false, st);   // identity order
+        VCR_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_keys, st));
+        return vcr_launch_tile_order(num_tiles, ranges, tile_order, meta, 0, false, false, st, ql ? gx_keys : 0);   // identity order
     }
     const int blocks = (a.N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS);
     uint32_t* ticket = reinterpret_cast<uint32_t*>(status + blocks + 1);
-    hipLaunchKernelGGL(duplicate_kernel, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, ticket, g.rect, inst,
-                       ranges, num_tiles);
+    hipLaunchKernelGGL(duplicate_kernel, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, ticket, g.rect, g.rect_hi,
+                       inst, ranges, num_keys, gx_keys);
     VCR_HIP_CHECK(hipGetLastError());
     if (vcr_sort_pairs(R, nullptr, nullptr, inst, pair_a, pair_b, keys_b, point_list, 0, tile_bits, (uint32_t*)temp, totals, st,
                        nullptr)) {
@@ -197,5 +203,5 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
     const int64_t rb = (R + 255) / 256;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)rb), dim3(256), 0, st, R, keys_b, ranges);
     VCR_HIP_CHECK(hipGetLastError());
-    return vcr_launch_tile_order(num_tiles, ranges, tile_order, meta, R, !no_lpt, !no_snake, st);
+    return vcr_launch_tile_order(num_tiles, ranges, tile_order, meta, R, !no_lpt, !no_snake, st, ql ? gx_keys : 0);
 }

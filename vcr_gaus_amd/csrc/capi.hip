@@ -120,12 +120,16 @@ int validate(const VcrRasterArgs* a) {
     if (!a) { vcr_set_error("args is NULL"); return 1; }
     if (a->N < 0 || a->H <= 0 || a->W <= 0) { vcr_set_error("bad sizes N=%d H=%d W=%d", a->N, a->H, a->W); return 1; }
     if (a->H > VCR_MAX_IMAGE_DIM || a->W > VCR_MAX_IMAGE_DIM) { vcr_set_error("image %dx%d exceeds %d pixels per side", a->W, a->H, VCR_MAX_IMAGE_DIM); return 1; }
+    if (a->quad_lists && (a->H > VCR_MAX_IMAGE_DIM / 2 || a->W > VCR_MAX_IMAGE_DIM / 2)) {      // (cell coordinates have 10 bits)
+        vcr_set_error("image %dx%d exceeds %d pixels per side (quad-list mode)", a->W, a->H, VCR_MAX_IMAGE_DIM / 2); return 1;
+    }
     if (a->S < 0 || a->S > VCR_MAX_SEM) { vcr_set_error("semantic channels S=%d unsupported (0..%d)", a->S, VCR_MAX_SEM); return 1; }
     if (a->num_dist < 0 || a->num_dist > 2) {
         vcr_set_error("num_dist=%d unsupported: 0 (none), 1 (depth distortion) or 2 (depth moments sum w d, sum w d^2)",
                       a->num_dist);
         return 1;
     }
+    if (a->f_count < 0 || a->f_count > 4) { vcr_set_error("f_count=%d unsupported (0..4)", a->f_count); return 1; }
     if (a->num_dist != 0 && a->f_count != 0) { vcr_set_error("num_dist needs f_count=0"); return 1; }
     if (a->N == 0) {                            // empty model: data pointers may legitimately be NULL
         if (!a->bg) { vcr_set_error("bg is NULL"); return 1; }
@@ -187,7 +191,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
     const int gx = (a.W + VCR_TILE - 1) / VCR_TILE, gy = (a.H + VCR_TILE - 1) / VCR_TILE;
     const int T = gx * gy;
     const int C = 8 + a.S + a.num_dist;
-    if (a.f_count != 3 && !out->out) { vcr_set_error("out buffer is NULL"); return 1; }
+    if (a.f_count != 3 && a.f_count != 4 && !out->out) { vcr_set_error("out buffer is NULL"); return 1; }
     if (a.f_count != 0 && !out->count) { vcr_set_error("count buffer is NULL for f_count=%d", a.f_count); return 1; }
     if ((a.f_count == 1 || a.f_count == 2) && !out->score) { vcr_set_error("score buffer is NULL"); return 1; }
     out->num_rendered = 0; out->num_visible = 0; out->max_tile_len = -1; out->num_emitted = -1;
@@ -203,7 +207,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
     int64_t R = 0;
     if (N > 0) {
         if (!out->radii) { vcr_set_error("radii buffer is NULL"); return 1; }
-        const int tbits = tile_bits_for(T);
+        const int tbits = tile_bits_for(T) + (a.quad_lists ? 2 : 0);      // (quad lists: the key is the 8x8 cell)
         const size_t tmp1 = vcr_binning_temp_bytes(N, 0, tbits);
         const size_t nb = vcr_align(sizeof(uint32_t) * (size_t)N);
         const size_t ctr_bytes = vcr_align(sizeof(uint32_t) * VCR_CTR_WORDS);
@@ -268,7 +272,9 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         if (a.sh_update && !split_colour) { vcr_set_error("sh_update needs colour_stream and SH colours"); return join_streams(); }
         {
             StageTimer tm(ST_PREPROCESS, st);
-            if (vcr_launch_preprocess(a, g, out->radii, split_sort ? nullptr : depth_key, ids, vis_counter, !split_colour, st))
+            // (count-only modes 3 / 4 never read a colour: geometry-only projection, 36 against 105 us at 1 M Gaussians)
+            const bool colour_here = !split_colour && a.f_count != 3 && a.f_count != 4;
+            if (vcr_launch_preprocess(a, g, out->radii, split_sort ? nullptr : depth_key, ids, vis_counter, colour_here, st))
                 return join_streams();
         }
         if (split_colour) {
@@ -351,7 +357,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         out->num_rendered = R;
         if (a.debug) {                       // diagnostics only: longest per-tile list (one extra sync)
             VCR_HIP_CHECK_JOIN(hipMemsetAsync(vis_counter, 0, sizeof(uint32_t), st));
-            hipLaunchKernelGGL(max_tile_len_kernel, dim3(32), dim3(256), 0, st, T, b.ranges, vis_counter);
+            hipLaunchKernelGGL(max_tile_len_kernel, dim3(32), dim3(256), 0, st, a.quad_lists ? 4 * T : T, b.ranges, vis_counter);
             VCR_HIP_CHECK_JOIN(hipMemcpyAsync(&rb->R[0], vis_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             VCR_HIP_CHECK_JOIN(hipStreamSynchronize(st));
             out->max_tile_len = (int32_t)rb->R[0];
@@ -368,15 +374,195 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         BinState b = BinState::view(bin_p, T);
         out->binning = bin_p;
         out->num_emitted = 0;
-        VCR_HIP_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * (size_t)T, st));
-        if (vcr_launch_tile_order(T, b.ranges, b.tile_order, b.meta, 0, false, false, st)) return 1;   // identity order
+        VCR_HIP_CHECK(hipMemsetAsync(b.ranges, 0, sizeof(uint2) * 4 * (size_t)T, st));
+        if (vcr_launch_tile_order(T, b.ranges, b.tile_order, b.meta, 0, false, false, st,
+                                  a.quad_lists ? 2 * ((a.W + VCR_TILE - 1) / VCR_TILE) : 0)) return 1;   // identity order
         VCR_HIP_CHECK(hipMemsetAsync(img_p, 0, ImageState::bytes(P), st));
-        if (a.f_count != 3)
+        if (a.f_count != 3 && a.f_count != 4)
             hipLaunchKernelGGL(fill_background_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, a.f_count ? 3 : C, a.bg,
                                out->out);
         VCR_HIP_CHECK(hipGetLastError());
     }
     return 0;
+}
+
+// ---- batched visibility passes ---------------------------------------------------------------------------------------
+namespace {
+
+constexpr int VIS_STREAMS = 8, VIS_MAX_SETS = 16;
+
+struct VisPool {
+    hipStream_t st[VIS_STREAMS] = {};
+    hipEvent_t fork = nullptr, join[VIS_STREAMS] = {};
+    Published* pub = nullptr;                       // VIS_MAX_SETS pinned slots
+    bool ok = false;
+};
+
+VisPool* vis_pool() {
+    static thread_local VisPool p;
+    if (!p.ok) {
+        for (int k = 0; k < VIS_STREAMS; ++k) {
+            if (hipStreamCreateWithFlags(&p.st[k], hipStreamNonBlocking) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&p.join[k], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipHostMalloc((void**)&p.pub, sizeof(Published) * VIS_MAX_SETS, hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) return nullptr;
+        memset(p.pub, 0, sizeof(Published) * VIS_MAX_SETS);
+        p.ok = true;
+    }
+    return &p;
+}
+
+// host side of the publish / spin hand-over (see vcr_rasterize_forward); `st`: the stream the publishing kernel runs on
+int wait_published(volatile Published* pub, uint32_t seq, hipStream_t st) {
+    const auto t_spin = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (pub->seq != seq) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+        if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(20)) {
+            const hipError_t e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { vcr_set_error("visibility batch: %s", hipGetErrorString(e)); return 1; }
+            break;
+        }
+    }
+    if (pub->seq != seq) { vcr_set_error("device did not publish the instance count"); return 1; }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return 0;
+}
+
+struct VisSet {                   // buffers of one camera in flight; re-used by camera c + sets on the same stream
+    void* geom = nullptr;
+    char* s1 = nullptr;
+    int32_t* radii = nullptr;
+    void* bin = nullptr; char* s2 = nullptr; int64_t cap = -1;      // instance-count dependent: grown on demand
+    uint32_t seq = 0;
+};
+
+}  // namespace
+
+extern "C" int vcr_visibility_batch(const VcrVisibilityBatch* vb, vcr_alloc_fn alloc, void* user, void* stream) {
+    if (!vb || !alloc) { vcr_set_error("visibility batch: args/alloc is NULL"); return 1; }
+    const int N = vb->N, B = vb->B;
+    const int max_dim = vb->quad_lists ? VCR_MAX_IMAGE_DIM / 2 : VCR_MAX_IMAGE_DIM;
+    if (N < 0 || B < 0 || vb->H <= 0 || vb->W <= 0 || vb->H > max_dim || vb->W > max_dim) {
+        vcr_set_error("visibility batch: bad sizes N=%d B=%d H=%d W=%d", N, B, vb->H, vb->W); return 1;
+    }
+    if (N == 0 || B == 0) return 0;
+    const bool sr = vb->scales != nullptr && vb->rotations != nullptr;
+    if (sr == (vb->cov3D_precomp != nullptr)) { vcr_set_error("visibility batch: provide exactly one of (scales, rotations) / cov3D_precomp"); return 1; }
+    if (!vb->tanfovx || !vb->tanfovy || !vb->viewmatrix || !vb->projmatrix || !vb->campos || !vb->means3D || !vb->opacities || !vb->count) {
+        vcr_set_error("visibility batch: required pointer is NULL"); return 1;
+    }
+    VisPool* pool = vis_pool();
+    if (!pool) { vcr_set_error("visibility batch: stream / event / pinned-memory set-up failed"); return 1; }
+    hipStream_t st = (hipStream_t)stream;
+    const int gx = (vb->W + VCR_TILE - 1) / VCR_TILE, gy = (vb->H + VCR_TILE - 1) / VCR_TILE, T = gx * gy;
+    const int tbits = tile_bits_for(T) + (vb->quad_lists ? 2 : 0);
+    int sets = vb->inflight > 0 ? vb->inflight : 8;                  // cameras in flight = buffer sets
+    sets = sets > VIS_MAX_SETS ? VIS_MAX_SETS : sets;
+    if (sets > B) sets = B;
+    // camera c uses set (c mod sets) on stream (c mod sets) mod nstreams: camera c and c + sets share a buffer set AND a stream
+    const int nstreams = sets < VIS_STREAMS ? sets : VIS_STREAMS;
+
+    // per-set buffer layout: as in vcr_rasterize_forward (no image state: the count modes do not write one)
+    const size_t tmp1 = vcr_binning_temp_bytes(N, 0, tbits);
+    const size_t nb = vcr_align(sizeof(uint32_t) * (size_t)N);
+    const size_t ctr_bytes = vcr_align(sizeof(uint32_t) * VCR_CTR_WORDS);
+    const size_t status_bytes = vcr_duplicate_status_bytes(N);
+    const size_t tot_bytes = vcr_align(sizeof(uint32_t) * 2 * VCR_SORT_TOTALS_WORDS);
+    const size_t s1_bytes = 7 * nb + ctr_bytes + status_bytes + tot_bytes + tmp1;           // (+ nb: the radii of this camera)
+    VisSet vs[VIS_MAX_SETS];
+    for (int k = 0; k < sets; ++k) {
+        vs[k].geom = alloc(user, VCR_BUF_SCRATCH, GeomState::bytes(N, 0));
+        vs[k].s1 = (char*)alloc(user, VCR_BUF_SCRATCH, s1_bytes);
+        if (!vs[k].geom || !vs[k].s1) { vcr_set_error("allocator returned NULL"); return 1; }
+        vs[k].radii = (int32_t*)(vs[k].s1 + 6 * nb);
+    }
+    static thread_local uint32_t seq_counter = 0x40000000u;
+
+    VCR_HIP_CHECK(hipEventRecord(pool->fork, st));
+    for (int k = 0; k < nstreams; ++k) VCR_HIP_CHECK(hipStreamWaitEvent(pool->st[k], pool->fork, 0));
+    int rc = 0;
+    auto join_all = [&]() {
+        for (int k = 0; k < nstreams; ++k) {
+            if (hipEventRecord(pool->join[k], pool->st[k]) == hipSuccess) (void)hipStreamWaitEvent(st, pool->join[k], 0);
+            else (void)hipStreamSynchronize(pool->st[k]);
+        }
+    };
+    auto cam_args = [&](int c) {
+        VcrRasterArgs a;
+        memset(&a, 0, sizeof(a));
+        a.N = N; a.H = vb->H; a.W = vb->W; a.f_count = vb->flags_only ? 4 : 3; a.quad_lists = vb->quad_lists ? 1 : 0;
+        a.tanfovx = vb->tanfovx[c]; a.tanfovy = vb->tanfovy[c]; a.scale_modifier = vb->scale_modifier;
+        a.viewmatrix = vb->viewmatrix + 16 * (size_t)c; a.projmatrix = vb->projmatrix + 16 * (size_t)c;
+        a.campos = vb->campos + 3 * (size_t)c;
+        a.means3D = vb->means3D; a.opacities = vb->opacities; a.scales = vb->scales; a.rotations = vb->rotations;
+        a.cov3D_precomp = vb->cov3D_precomp;
+        return a;
+    };
+    for (int c0 = 0; c0 < B && !rc; c0 += sets) {
+        const int c1 = c0 + sets < B ? c0 + sets : B;
+        // front half of every camera of the group: projection (geometry only), counts to the host, depth order
+        for (int c = c0; c < c1 && !rc; ++c) {
+            VisSet& v = vs[c - c0];
+            hipStream_t cs = pool->st[(c - c0) % nstreams];
+            const VcrRasterArgs a = cam_args(c);
+            GeomState g = GeomState::view(v.geom, N, 0);
+            uint32_t* depth_key = (uint32_t*)v.s1;
+            uint32_t* ids_sorted = (uint32_t*)(v.s1 + nb);
+            uint32_t* ctr = (uint32_t*)(v.s1 + 7 * nb);
+            uint32_t* totals_depth = (uint32_t*)(v.s1 + 7 * nb + ctr_bytes + status_bytes);
+            void* temp1 = v.s1 + 7 * nb + ctr_bytes + status_bytes + tot_bytes;
+            if (hipMemsetAsync(ctr, 0, ctr_bytes + status_bytes, cs) != hipSuccess) { vcr_set_error("visibility batch: memset failed"); rc = 1; break; }
+            if (vcr_launch_preprocess(a, g, v.radii, depth_key, nullptr, ctr, false, cs)) { rc = 1; break; }
+            v.seq = ++seq_counter ? seq_counter : ++seq_counter;
+            hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(256), 0, cs, ctr, pool->pub + (c - c0), v.seq);
+            if (hipGetLastError() != hipSuccess) { vcr_set_error("visibility batch: publish launch failed"); rc = 1; break; }
+            if (vcr_depth_sort(N, depth_key, (uint2*)(v.s1 + 2 * nb), (uint2*)(v.s1 + 4 * nb), ids_sorted, totals_depth, temp1, cs)) { rc = 1; break; }
+        }
+        // back half: the host sizes the instance buffers of camera c while the later cameras' front halves run
+        for (int c = c0; c < c1 && !rc; ++c) {
+            VisSet& v = vs[c - c0];
+            hipStream_t cs = pool->st[(c - c0) % nstreams];
+            Published* pub = pool->pub + (c - c0);
+            if (wait_published(pub, v.seq, cs)) { rc = 1; break; }
+            const int64_t R = (int64_t)pub->R, E = (int64_t)pub->E;
+            if (vb->num_rendered) vb->num_rendered[c] = R;
+            if (vb->num_visible) vb->num_visible[c] = (int32_t)pub->V;
+            if (R >= (1ll << 32)) { vcr_set_error("more than 2^32 tile instances"); rc = 1; break; }
+            if (E <= 0) continue;
+            const bool third = vcr_sort_passes(tbits) > 2;
+            if (E > v.cap) {                       // grow with head-room: later cameras of the batch re-use the set
+                const int64_t cap = E + E / 4 + 1024;
+                const size_t rbts = vcr_align(sizeof(uint32_t) * (size_t)cap);
+                v.bin = alloc(user, VCR_BUF_SCRATCH, BinState::bytes(cap, T));
+                v.s2 = (char*)alloc(user, VCR_BUF_SCRATCH, (third ? 7 : 5) * rbts + vcr_binning_temp_bytes(N, cap, tbits));
+                if (!v.bin || !v.s2) { vcr_set_error("allocator returned NULL"); rc = 1; break; }
+                v.cap = cap;
+            }
+            const size_t rbts = vcr_align(sizeof(uint32_t) * (size_t)v.cap);
+            const size_t tmp2 = vcr_binning_temp_bytes(N, v.cap, tbits);
+            const VcrRasterArgs a = cam_args(c);
+            GeomState g = GeomState::view(v.geom, N, 0);
+            BinState b = BinState::view(v.bin, T);
+            uint32_t* ids_sorted = (uint32_t*)(v.s1 + nb);
+            unsigned long long* dup_status = (unsigned long long*)(v.s1 + 7 * nb + ctr_bytes);
+            uint32_t* totals_tile = (uint32_t*)(v.s1 + 7 * nb + ctr_bytes + status_bytes) + VCR_SORT_TOTALS_WORDS;
+            if (vcr_duplicate_and_sort(a, g, v.radii, ids_sorted, dup_status, E, tbits, (uint2*)v.s2, (uint2*)(v.s2 + 2 * rbts),
+                                       third ? (uint2*)(v.s2 + 5 * rbts) : nullptr, (uint32_t*)(v.s2 + 4 * rbts), b.point_list,
+                                       b.ranges, b.tile_order, b.meta, T, totals_tile, v.s2 + (third ? 7 : 5) * rbts, tmp2, cs)) { rc = 1; break; }
+            ImageState im;
+            im.final_T = nullptr; im.n_contrib = nullptr; im.moments = nullptr;      // (not written by the count modes)
+            VcrForwardOut fo;
+            memset(&fo, 0, sizeof(fo));
+            fo.count = vb->count;
+            if (vcr_launch_composite_forward(a, g, b, im, fo, cs)) { rc = 1; break; }
+        }
+    }
+    join_all();                    // also on errors: the caller's stream-ordered allocator gets the buffers back on return
+    return rc;
 }
 
 extern "C" int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* io, vcr_alloc_fn alloc, void* user,

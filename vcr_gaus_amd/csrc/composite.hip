@@ -69,6 +69,15 @@ __device__ __forceinline__ int work_item(const uint32_t* __restrict__ tile_order
     return i < num_tiles ? (int)tile_order[i] : -1;
 }
 
+// [begin, end) of the list a wave walks: the tile's (all four quad-waves share it), or -- quad-list mode, meta[3] = 8x8 cells
+// per row -- the list of the wave's own quad.
+__device__ __forceinline__ uint2 list_range(const uint2* __restrict__ ranges, const uint32_t* __restrict__ meta, int tile, int gx,
+                                            int quad) {
+    const int gxc = (int)meta[3];
+    if (!gxc) return ranges[tile];
+    return ranges[(2 * (tile / gx) + (quad >> 1)) * gxc + 2 * (tile % gx) + (quad & 1)];
+}
+
 // ================= one wave = one 8x8 quad, no LDS, no barriers ==========================================
 // Each lane first acts as a CULLER for one Gaussian of the tile list (exact minimum of the conic form over
 // the quad's pixel rectangle against the alpha >= 1/255 threshold), a 64-bit ballot compacts the survivors,
@@ -167,7 +176,7 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
     const int tile = work_item(tile_order, meta, num_tiles, sub);
     if (tile < 0) return;
     const PixelMap pm = pixel_of_thread(tile, gx, a.W, a.H, sub);
-    const uint2 range = ranges[tile];
+    const uint2 range = list_range(ranges, meta, tile, gx, threadIdx.x >> 6);
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // S <= 2 without count mode: the semantic features come with the record (GeomRec pad slots) and take the place of the id
@@ -197,15 +206,23 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
     bool done = !pm.inside;
 
     uint32_t pos = range.x;
-    uint32_t id, nid; float4 q0, q1, q2, q3, qs = {0.f, 0.f, 0.f, 0.f}; bool valid, nvalid;
+    // count-only modes (FC >= 3) shade no channel: they gather and stage the first 32 bytes of a record only
+#define VCR_GATHER_FWD(ID, Q0, Q1, Q2, Q3)                                          \
+    do {                                                                            \
+        const float4* _src = reinterpret_cast<const float4*>(rec + (ID));           \
+        Q0 = _src[0]; Q1 = _src[1];                                                 \
+        if (FC < 3) { Q2 = _src[2]; Q3 = _src[3]; }                                 \
+    } while (0)
+    const float4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    uint32_t id, nid; float4 q0, q1, q2 = zero4, q3 = zero4, qs = zero4; bool valid, nvalid;
     VCR_LOAD_ID(pos + lane, range.y, id, valid);
-    VCR_GATHER_REC(id, q0, q1, q2, q3);
+    VCR_GATHER_FWD(id, q0, q1, q2, q3);
     if (!SEM_IN_REC) VCR_GATHER_SEM(id, qs);
     VCR_LOAD_ID(pos + 64 + lane, range.y, nid, nvalid);
     while (pos < range.y) {
-        uint32_t nnid; float4 nq0, nq1, nq2, nq3, nqs = {0.f, 0.f, 0.f, 0.f}; bool nnvalid;
+        uint32_t nnid; float4 nq0, nq1, nq2 = zero4, nq3 = zero4, nqs = zero4; bool nnvalid;
         const uint32_t npos = pos + 64;
-        VCR_GATHER_REC(nid, nq0, nq1, nq2, nq3);                     // records of the next chunk
+        VCR_GATHER_FWD(nid, nq0, nq1, nq2, nq3);                     // records of the next chunk
         if (!SEM_IN_REC) VCR_GATHER_SEM(nid, nqs);
         VCR_LOAD_ID(npos + 64 + lane, range.y, nnid, nnvalid);       // ids of the chunk after that
 #ifdef VCR_TIMING
@@ -215,6 +232,8 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
         live_box(__builtin_amdgcn_ballot_w64(!done), X0, Y0, bx0, by0, bw, bh);
         const bool keep = valid && quad_touch(q0, q1, bx0, by0, bw, bh);
         unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        int chunk_cnt = 0; unsigned long long chunk_seen = 0;       // FC 3 / 4 (see below)
+        (void)chunk_cnt; (void)chunk_seen;
 #ifdef VCR_TIMING
         n_chunks++; n_surv += __popcll(m);
         { const long long t2 = wall_clock64(); t_cull += t2 - t_mark; t_mark = t2; }
@@ -226,8 +245,10 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
         if (keep) {
             srec[0 * 64 + lane] = make_float4(q0.x, q0.y, -VCR_L2E * q1.x, -VCR_L2E * q1.z);
             srec[1 * 64 + lane] = make_float4(-VCR_L2E * q1.y, __builtin_amdgcn_logf(q0.w), q0.z, q1.w);   // v_log_f32 = log2
-            srec[2 * 64 + lane] = make_float4(q2.x, q2.y, q2.z, q3.x);
-            srec[3 * 64 + lane] = SEM_IN_REC ? make_float4(q3.y, q3.z, q2.w, q3.w) : make_float4(q3.y, q3.z, __uint_as_float(id), 0.f);
+            if (FC < 3) {
+                srec[2 * 64 + lane] = make_float4(q2.x, q2.y, q2.z, q3.x);
+                srec[3 * 64 + lane] = SEM_IN_REC ? make_float4(q3.y, q3.z, q2.w, q3.w) : make_float4(q3.y, q3.z, __uint_as_float(id), 0.f);
+            }
             if (S > 0 && !SEM_IN_REC) srec[4 * 64 + lane] = qs;
         }
         __builtin_amdgcn_wave_barrier();          // same wave, DS ops execute in order: no s_barrier needed
@@ -247,21 +268,26 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
             if (hit && test_T < VCR_T_EPS) { done = true; hit = false; }                                                 \
             const float w = hit ? alpha * T : 0.f;                                                                       \
             { const unsigned long long hm_ = __builtin_amdgcn_ballot_w64(hit); VCR_COUNT_HITS(0, hm_); (void)hm_; }      \
-            if (FC != 0) {                                                                                               \
+            if (FC == 1) {                                                                                               \
                 const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);                                          \
                 if (hm != 0) {                                                                                           \
                     const float ws = wave_sum(w);                                                                        \
                     if (lane == 0) {                                                                                     \
                         const uint32_t gid = __float_as_uint(r3.z);                                                      \
                         atomicAdd(count + gid, (int)__popcll(hm));                                                       \
-                        if (FC != 3) atomicAdd(score + gid, ws);                                                         \
+                        atomicAdd(score + gid, ws);                                                                      \
                     }                                                                                                    \
                 }                                                                                                        \
             }                                                                                                            \
+            if (FC == 3) {      /* count only: the survivor's pixel count goes to ITS slot of the chunk (lane sb_), one atomic    */ \
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);   /* instruction per chunk deposits them all  */ \
+                chunk_cnt = lane == sb_ ? (int)__popcll(hm) : chunk_cnt;                                                 \
+            }                                                                                                            \
+            if (FC == 4) chunk_seen |= (unsigned long long)(__builtin_amdgcn_ballot_w64(hit) != 0) << sb_;               \
             const f2 c01 = {r2.x, r2.y}, c2n = {r2.z, r2.w}, n12 = {r3.x, r3.y};                                         \
             float dep = r1.z;                                                                                            \
             if (ISECT) {                                                                                                 \
-                const float den = c2n.y * rx + n12.x * ry + n12.y * rz;                                                  \
+                const float den = fmaf(c2n.y, rx, fmaf(n12.x, ry, n12.y * rz));   /* (explicit: both copies of the macro must round alike) */                                                  \
                 if (den > VCR_PLANE_EPS) dep = r1.w * fast_rcp(den) * rz;                                                \
             }                                                                                                            \
             const f2 ww = splat(w);                                                                                      \
@@ -269,16 +295,16 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
             acc_c2n = pk_fma(ww, c2n, acc_c2n);                                                                          \
             acc_n12 = pk_fma(ww, n12, acc_n12);                                                                          \
             acc_da = pk_fma(ww, f2{dep, 1.f}, acc_da);                                                                   \
-            if (ND == 2) M2 += w * dep * dep;                                                                            \
+            if (ND == 2) M2 = fmaf(w * dep, dep, M2);                                                                    \
             if (ND == 1) {                                                                                               \
                 const float md = -zc_map * VCR_ZNEAR * fast_rcp(dep);                                                    \
-                M1 += w * md; M2 += w * md * md;                                                                         \
+                M1 = fmaf(w, md, M1); M2 = fmaf(w * md, md, M2);                                                         \
             }                                                                                                            \
             if (S > 0) {                                                                                                 \
                 const float4 r4_ = SEM_IN_REC ? make_float4(r3.z, r3.w, 0.f, 0.f) : R##4;                                \
                 const float sv_[4] = {r4_.x, r4_.y, r4_.z, r4_.w};                                                       \
 _Pragma("unroll")                                                                                                        \
-                for (int k = 0; k < S; ++k) SM[k] += w * sv_[k];                                                         \
+                for (int k = 0; k < S; ++k) SM[k] = fmaf(w, sv_[k], SM[k]);                                              \
             }                                                                                                            \
             T = hit ? test_T : T;                                                                                        \
             last = hit ? pos - range.x + (uint32_t)sb_ + 1u : last;                                                        \
@@ -287,12 +313,13 @@ _Pragma("unroll")                                                               
         // shading of the current one; it does not wait for the data
 #define VCR_LDS_FETCH(R, B)                                                                                   \
         do {                                                                                                  \
-            R##0 = srec[(B)]; R##1 = srec[64 + (B)]; R##2 = srec[128 + (B)]; R##3 = srec[192 + (B)];          \
+            R##0 = srec[(B)]; R##1 = srec[64 + (B)];                                                          \
+            if (FC < 3) { R##2 = srec[128 + (B)]; R##3 = srec[192 + (B)]; }                                   \
             if (S > 0 && !SEM_IN_REC) R##4 = srec[256 + (B)];                                                 \
             asm volatile("" ::: "memory");                                                                    \
         } while (0)
         if (m && !(VCR_KO & 1)) {
-            float4 A0, A1, A2, A3, A4 = {0.f, 0.f, 0.f, 0.f}, B0, B1, B2, B3, B4 = {0.f, 0.f, 0.f, 0.f};
+            float4 A0, A1, A2 = zero4, A3 = zero4, A4 = zero4, B0, B1, B2 = zero4, B3 = zero4, B4 = zero4;
             int b = __builtin_ctzll(m);
             m &= m - 1;
             VCR_LDS_FETCH(A, b);
@@ -316,6 +343,10 @@ _Pragma("unroll")                                                               
 #ifdef VCR_TIMING
         t_surv += wall_clock64() - t_mark;
 #endif
+        // count modes 3 / 4: lane j holds what entry j of this chunk collected -- ONE atomic / store instruction per chunk
+        // instead of one per survivor (`id` is this lane's entry of the current chunk)
+        if (FC == 3 && chunk_cnt != 0) atomicAdd(count + id, chunk_cnt);
+        if (FC == 4 && ((chunk_seen >> lane) & 1ull)) count[id] = 1;
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;        // every pixel of the quad has T < 1e-4
         pos = npos; id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; qs = nqs; valid = nvalid; nid = nnid; nvalid = nnvalid;
     }
@@ -330,9 +361,11 @@ _Pragma("unroll")                                                               
     const float C0 = acc_c01.x, C1 = acc_c01.y, C2 = acc_c2n.x, N0 = acc_c2n.y, N1 = acc_n12.x, N2 = acc_n12.y;
     const float D = acc_da.x, A = acc_da.y;
     if (pm.inside) {
-        final_T[pm.pix] = T;
-        n_contrib[pm.pix] = last;
-        if (FC != 3) {
+        if (FC == 0) {                      // (the image state is the backward's; the count modes have none)
+            final_T[pm.pix] = T;
+            n_contrib[pm.pix] = last;
+        }
+        if (FC != 3 && FC != 4) {
             out[0 * (size_t)P + pm.pix] = C0 + T * a.bg[0];
             out[1 * (size_t)P + pm.pix] = C1 + T * a.bg[1];
             out[2 * (size_t)P + pm.pix] = C2 + T * a.bg[2];
@@ -373,10 +406,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 
     const int tile = work_item(tile_order, meta, num_tiles, sub);
     if (tile < 0) return;
     const PixelMap pm = pixel_of_thread(tile, gx, a.W, a.H, sub);
-    const uint2 range = ranges[tile];
+    const uint2 range = list_range(ranges, meta, tile, gx, threadIdx.x >> 6);
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr bool SEM_IN_REC = false;                    // (the backward needs the id for its atomics: semantics keep their plane)
+    constexpr int FC = 0;                                 // (VCR_LDS_FETCH: full records)
     constexpr int WREC = S > 0 ? 320 : 256;               // per wave: 4 (+1 with semantics) planes x 64 slots x 16 B
     __shared__ float4 s_rec_all[4 * WREC];
     float4* const srec = s_rec_all + wv * WREC;
@@ -450,7 +484,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 
                 float dep = zc, iden = 0.f;                                                                              \
                 bool isect = false;                                                                                      \
                 if (ISECT) {                                                                                             \
-                    const float den = c2n.y * rx + n12.x * ry + n12.y * rz;                                              \
+                    const float den = fmaf(c2n.y, rx, fmaf(n12.x, ry, n12.y * rz));   /* (explicit: both copies of the macro must round alike) */                                              \
                     isect = den > VCR_PLANE_EPS;                                                                         \
                     iden = isect ? fast_rcp(den) : 0.f;                                                                  \
                     dep = isect ? pl * iden * rz : zc;                                                                   \
@@ -640,10 +674,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_RO
     const int tile = work_item(tile_order, meta, num_tiles, sub);
     if (tile < 0) return;
     const PixelMap pm = pixel_of_thread_rows(tile, gx, a.W, a.H, sub);
-    const uint2 range = ranges[tile];
+    const uint2 range = list_range(ranges, meta, tile, gx, threadIdx.x >> 6);
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = lane >> 4;
     constexpr bool SEM_IN_REC = false;
+    constexpr int FC = 0;
     constexpr int WREC = S > 0 ? 320 : 256;
     __shared__ float4 s_rec_all[4 * WREC];
     float4* const srec = s_rec_all + wv * WREC;
@@ -802,6 +837,7 @@ int launch_fwd_fc(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im
     switch (a.f_count) {
         case 0: VCR_FWD(0, ND); break;
         case 1: case 2: VCR_FWD(1, 0); break;
+        case 4: VCR_FWD(4, 0); break;
         default: VCR_FWD(3, 0); break;
     }
 #undef VCR_FWD

@@ -233,7 +233,7 @@ __device__ __forceinline__ void stage_sh_in(const VcrRasterArgs& a, int base, in
 template <bool STAGE, bool COLOUR>
 __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const GeomState& g, int32_t* __restrict__ radii,
                                                    uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
-                                                   const float* s_sh, int i, uint32_t& emit) {
+                                                   const float* s_sh, int i, uint32_t& emit, int ql) {
     emit = 0;
     if (i >= a.N) return 0;
     radii[i] = 0;
@@ -320,7 +320,29 @@ __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const
     if (COLOUR) g.clamped[i] = clampbits;
     g.tiles[i] = (uint32_t)ntiles;
     const int rw = xmax - xmin, rh = ymax - ymin;
-    if (ntiles <= VCR_RECT_MASK_TILES) {
+    if (ql) {
+        // quad lists: the same record in units of 8x8 cells (2 gx cells per row); the exact test runs per cell
+        // The cells are those of the TILE rectangle (the reference renders a Gaussian at every pixel of its tile rectangle where
+        // alpha >= 1/255, also beyond the 3-sigma square), the mask drops the cells it cannot reach.
+        const int cx0 = 2 * xmin, cx1 = 2 * xmax, cy0 = 2 * ymin, cy1 = 2 * ymax;
+        const int cw = cx1 - cx0, ch = cy1 - cy0;
+        if (cw * ch <= 2 * VCR_RECT_MASK_TILES && cw <= 32 && ch <= 32) {       // up to 64 cells = 16 tiles: exact cell mask
+            const float4 q0 = make_float4(rec.px, rec.py, rec.z, rec.opacity), q1 = make_float4(rec.ca, rec.cb, rec.cc, rec.plane);
+            unsigned long long mask = 0;
+            for (int k = 0, cy = cy0; cy < cy1; ++cy)
+                for (int cx = cx0; cx < cx1; ++cx, ++k)
+                    if (quad_touch(q0, q1, (float)(cx * 8), (float)(cy * 8), 7.f, 7.f)) mask |= 1ull << k;
+            emit = (uint32_t)__popcll(mask);
+            const uint32_t wide = cw * ch > VCR_RECT_MASK_TILES ? VCR_RECT_MASK64 : 0u;
+            g.rect[i] = (cw > 0 && ch > 0) ? make_uint2(VCR_RECT_MASKED | wide | (uint32_t)cx0 | ((uint32_t)cy0 << 10) |
+                                                         ((uint32_t)(cw - 1) << 20) | ((uint32_t)(ch - 1) << 25), (uint32_t)mask)
+                                           : make_uint2(0u, 0u);
+            if (wide) g.rect_hi[i] = (uint32_t)(mask >> 32);
+        } else {
+            emit = (uint32_t)(cw * ch);
+            g.rect[i] = make_uint2((uint32_t)cx0 | ((uint32_t)cy0 << 10), (uint32_t)cw | ((uint32_t)ch << 16));
+        }
+    } else if (ntiles <= VCR_RECT_MASK_TILES) {
         const float4 q0 = make_float4(rec.px, rec.py, rec.z, rec.opacity), q1 = make_float4(rec.ca, rec.cb, rec.cc, rec.plane);
         uint32_t mask = 0;
         for (int k = 0, ty = ymin; ty < ymax; ++ty)
@@ -343,7 +365,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const
 template <bool STAGE, bool COLOUR>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, GeomState g, int32_t* __restrict__ radii,
                                                              uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
-                                                             uint32_t* __restrict__ vis_slots) {
+                                                             uint32_t* __restrict__ vis_slots, int ql) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];
     if (STAGE) {
         const int base = blockIdx.x * 256;
@@ -351,7 +373,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
         __syncthreads();
     }
     uint32_t em;
-    const uint32_t nt = preprocess_one<STAGE, COLOUR>(a, g, radii, depth_key, ids, s_sh, blockIdx.x * 256 + threadIdx.x, em);
+    const uint32_t nt = preprocess_one<STAGE, COLOUR>(a, g, radii, depth_key, ids, s_sh, blockIdx.x * 256 + threadIdx.x, em, ql);
     if (vis_slots) {
         __shared__ uint32_t s_cnt[3][4];
         uint32_t c = nt != 0 ? 1u : 0u, r = nt;
@@ -908,17 +930,18 @@ int vcr_launch_depth_keys(const VcrRasterArgs& a, uint32_t* depth_key, hipStream
 
 int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key, uint32_t* ids,
                           uint32_t* vis_slots, bool colour, hipStream_t st) {
+    const int ql = a.quad_lists ? 1 : 0;
     if (a.N == 0) return 0;
     const int blocks = (a.N + 255) / 256;
     if (!colour)
         hipLaunchKernelGGL((preprocess_fwd_kernel<false, false>), dim3(blocks), dim3(256), 0, st, a, g, radii, depth_key, ids,
-                           vis_slots);
+                           vis_slots, ql);
     else if (a.shs && a.K == SH_K)
         hipLaunchKernelGGL((preprocess_fwd_kernel<true, true>), dim3(blocks), dim3(256), 256 * SH_ROW * sizeof(float), st, a, g,
-                           radii, depth_key, ids, vis_slots);
+                           radii, depth_key, ids, vis_slots, ql);
     else
         hipLaunchKernelGGL((preprocess_fwd_kernel<false, true>), dim3(blocks), dim3(256), 0, st, a, g, radii, depth_key, ids,
-                           vis_slots);
+                           vis_slots, ql);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -265,14 +265,25 @@ __global__ void __launch_bounds__(RsShape<BITS>::THREADS) rs_downsweep_kernel(in
 // the SIMDs are not full (1 M Gaussians / 1080p: none).  meta[0] = S, meta[1] = non-empty tiles, meta[2] = longest list.
 __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ order,
                                                         uint32_t* __restrict__ meta, unsigned long long instances, int split_slots,
-                                                        int lpt, int snake) {
+                                                        int lpt, int snake, int gxc) {
     constexpr int BINS = 2048, SH = 2;                 // classes of 4 list entries; lists >= 8188 share the first class
+    // quad-list mode (gxc = 8x8 cells per row, 0 = off): `ranges` is per cell; a tile's length is the sum of its four quads'
+    // lists (what its workgroup shades), the longest serial chain is the longest CELL list
+    auto tile_len = [&](int i, uint32_t& longest) -> uint32_t {
+        if (!gxc) { const uint32_t l = ranges[i].y - ranges[i].x; longest = l; return l; }
+        const int gxt = gxc >> 1, tx = i % gxt, ty = i / gxt;
+        const uint2 a0 = ranges[(2 * ty) * gxc + 2 * tx], a1 = ranges[(2 * ty) * gxc + 2 * tx + 1];
+        const uint2 a2 = ranges[(2 * ty + 1) * gxc + 2 * tx], a3 = ranges[(2 * ty + 1) * gxc + 2 * tx + 1];
+        const uint32_t l0 = a0.y - a0.x, l1 = a1.y - a1.x, l2 = a2.y - a2.x, l3 = a3.y - a3.x;
+        longest = max(max(l0, l1), max(l2, l3));
+        return l0 + l1 + l2 + l3;
+    };
     __shared__ uint32_t hist[BINS];
     __shared__ uint32_t wsum[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (!lpt) {
         for (int i = t; i < T; i += 1024) order[i] = (uint32_t)i;
-        if (t < VCR_BIN_META_WORDS) meta[t] = 0u;
+        if (t < VCR_BIN_META_WORDS) meta[t] = t == 3 ? (uint32_t)gxc : 0u;
         return;
     }
     __shared__ uint32_t s_ne, s_max, s_empty;
@@ -284,8 +295,9 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2* __
     // with one atomic per wave instead.
     uint32_t ne = 0, mx = 0;
     for (int i = t; i < T; i += 1024) {
-        const uint32_t len = ranges[i].y - ranges[i].x;
-        ne += len > 0; mx = max(mx, len);
+        uint32_t longest;
+        const uint32_t len = tile_len(i, longest);
+        ne += len > 0; mx = max(mx, longest);
         if (len > 0) atomicAdd(&hist[BINS - 1 - min(len >> SH, (uint32_t)(BINS - 1))], 1u);   // bin 0 = longest
     }
     for (int o = 32; o > 0; o >>= 1) { ne += (uint32_t)__shfl_xor((int)ne, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
@@ -298,8 +310,8 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2* __
         // ... and only when the launch is bound by its longest serial chain rather than by total work: longest list > 4x the
         // list entries per workgroup slot (c2: 6400 against 590 -> split; 1 M / 1080p: 4500 against 1200 -> not: there the
         // SIMDs stay full to the end and the 1.9x work of the split items costs more than their shorter chains return)
-        if ((unsigned long long)s_max * (unsigned)split_slots <= 4ull * instances) S = 0;
-        meta[0] = (uint32_t)S; meta[1] = s_ne; meta[2] = s_max;
+        if ((unsigned long long)s_max * (unsigned)split_slots <= (gxc ? 1ull : 4ull) * instances) S = 0;
+        meta[0] = (uint32_t)S; meta[1] = s_ne; meta[2] = s_max; meta[3] = (uint32_t)gxc;
         s_empty = s_ne;                                  // the empty tiles follow the non-empty ones in launch order
     }
     // exclusive scan of the 2048 classes: 2 per lane, wave scan, 16 wave totals
@@ -318,7 +330,8 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2* __
     __syncthreads();
     for (int i0 = 0; i0 < T; i0 += 1024) {
         const int i = i0 + t;
-        const uint32_t len = i < T ? ranges[i].y - ranges[i].x : 1u;
+        uint32_t longest_;
+        const uint32_t len = i < T ? tile_len(i, longest_) : 1u;
         const unsigned long long em = __builtin_amdgcn_ballot_w64(i < T && len == 0);
         uint32_t ebase = 0;
         if (em) {
@@ -415,7 +428,7 @@ int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, 
 }
 
 int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, uint32_t* meta, int64_t instances, bool lpt, bool snake,
-                          hipStream_t st) {
+                          hipStream_t st, int gxc) {
     // workgroup slots of the compositing kernels on the chip: 5 resident 256-thread workgroups per CU (VCR_SPLIT_SLOTS overrides;
     // 0 disables the split work items)
     static const int slots = [] {
@@ -428,7 +441,7 @@ int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, uint32_t*
         return 5 * cus;
     }();
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, T, ranges, order, meta, (unsigned long long)instances, slots,
-                       lpt ? 1 : 0, snake ? 1 : 0);
+                       lpt ? 1 : 0, snake ? 1 : 0, gxc);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -60,13 +60,14 @@ struct GeomState {
                          //     VCR_RECT_MASK_TILES tiles: {MASKED | xmin | ymin << 10 | (w-1) << 20 | (h-1) << 25, bit k set when
                          //     tile (xmin + k % w, ymin + k / w) can be reached (exact rejection, tile_touch)}; larger ones:
                          //     {xmin | ymin << 10, w | h << 16}, every tile emitted; {0, 0} = culled
+    uint32_t* rect_hi;   // [N] quad-list mode: bits 32..63 of the cell mask of rectangles of 33..64 cells (VCR_RECT_MASK64 set)
     float4* cjac;        // [N][3] d(colour channel c) / d(mean), through the normalised view direction (written with the colour by
                          //     whichever kernel evaluates SH -> RGB): the projection backward forms the colour -> mean adjoint
                          //     from these 48 B instead of re-reading the 192 B of SH coefficients
     static size_t bytes(int N, int S) {
         return vcr_align(sizeof(GeomRec) * (size_t)N) + vcr_align(sizeof(float) * (size_t)N * (S > 0 ? S : 1)) +
                vcr_align(sizeof(uint32_t) * (size_t)N) + vcr_align((size_t)N) + vcr_align(sizeof(uint2) * (size_t)N) +
-               vcr_align(sizeof(float4) * 3 * (size_t)N);
+               vcr_align(sizeof(uint32_t) * (size_t)N) + vcr_align(sizeof(float4) * 3 * (size_t)N);
     }
     static GeomState view(void* p, int N, int S) {
         GeomState g;
@@ -76,6 +77,7 @@ struct GeomState {
         g.tiles = (uint32_t*)c;   c += vcr_align(sizeof(uint32_t) * (size_t)N);
         g.clamped = (uint8_t*)c;  c += vcr_align((size_t)N);
         g.rect = (uint2*)c;       c += vcr_align(sizeof(uint2) * (size_t)N);
+        g.rect_hi = (uint32_t*)c; c += vcr_align(sizeof(uint32_t) * (size_t)N);
         g.cjac = (float4*)c;
         return g;
     }
@@ -83,24 +85,29 @@ struct GeomState {
 
 #define VCR_RECT_MASK_TILES 32
 #define VCR_RECT_MASKED 0x80000000u
+#define VCR_RECT_MASK64 0x40000000u      // (with MASKED) the mask has 64 bits, the upper word in GeomState::rect_hi
 #define VCR_MAX_IMAGE_DIM 16384          // tile coordinates have 10 bits in the rectangle record
 
 #define VCR_BIN_META_WORDS 16
+// VcrRasterArgs.quad_lists: tile instances are binned per 8x8 QUAD instead of per 16x16 tile -- the projection kernel's exact
+// test runs on 8x8 cells, the sort key is the cell index (2 more bits), `ranges` holds one [begin, end) per cell and every
+// wave of the compositing kernels walks the list of ITS quad only.  BinState::meta[3] = cells per row when on, 0 when off: the
+// compositing kernels (forward and backward) read the mode from there.
 #define VCR_SPLIT_MAX 256          // at most this many tiles are split (one band of the launch order)
 struct BinState {
-    uint2* ranges;         // [T] per-tile [begin,end)
+    uint2* ranges;         // [4T] per-tile [begin,end) in [0, T); quad-list mode: per 8x8 cell, 4T entries
     uint32_t* tile_order;  // [T] tile ids, longest list first (block scheduling order)
     uint32_t* meta;        // [VCR_BIN_META_WORDS] written by tile_order: [0] number S of heaviest tiles launched as split work
                            //     items (composite.hip), [1] non-empty tiles, [2] longest tile list
     uint32_t* point_list;  // [R'] Gaussian ids, (tile, depth, id)-ordered; LAST, so that the views above do not depend on R'
     static size_t bytes(int64_t R, int T) {
-        return vcr_align(sizeof(uint2) * (size_t)T) + vcr_align(sizeof(uint32_t) * (size_t)T) +
+        return vcr_align(sizeof(uint2) * 4 * (size_t)T) + vcr_align(sizeof(uint32_t) * (size_t)T) +
                vcr_align(sizeof(uint32_t) * VCR_BIN_META_WORDS) + vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1));
     }
     static BinState view(void* p, int T) {
         BinState b;
         char* c = (char*)p;
-        b.ranges = (uint2*)c;         c += vcr_align(sizeof(uint2) * (size_t)T);
+        b.ranges = (uint2*)c;         c += vcr_align(sizeof(uint2) * 4 * (size_t)T);
         b.tile_order = (uint32_t*)c;  c += vcr_align(sizeof(uint32_t) * (size_t)T);
         b.meta = (uint32_t*)c;        c += vcr_align(sizeof(uint32_t) * VCR_BIN_META_WORDS);
         b.point_list = (uint32_t*)c;
@@ -178,8 +185,9 @@ int vcr_sort_passes(int bits);
 int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, const uint2* pairs_in, uint2* pair_a, uint2* pair_b,
                    uint32_t* keys_out, uint32_t* vals_out, int begin_bit, int end_bit, uint32_t* hist, uint32_t* totals,
                    hipStream_t st, const uint32_t* n_dev = nullptr);
+// gxc: 8x8 cells per row when `ranges` is per cell (quad-list mode), 0 when it is per tile
 int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, uint32_t* meta, int64_t instances, bool lpt, bool snake,
-                          hipStream_t st);
+                          hipStream_t st, int gxc = 0);
 int vcr_launch_composite_forward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o,
                                  hipStream_t st);
 int vcr_launch_composite_backward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,

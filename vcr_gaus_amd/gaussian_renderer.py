@@ -178,6 +178,35 @@ def visi_acc_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, 
     return {"viewspace_points": sp, "visibility_filter": radii > 0, "radii": radii, "countlist": count}
 
 
+@torch.no_grad()
+def visibility_counts(cameras, pc, pipe, scaling_modifier=1.0, flags_only=False, count=None, inflight=0):
+    """`get_visi_list` (`tools/prune.py:51-69`: one `visi_acc_render` per camera, `countlist`s summed) for a whole list of
+    cameras in one batched library call per image size.  -> int32 [N]: the summed `countlist` (or, with `flags_only`, 1
+    where it is > 0 -- the only thing `get_visi_list` derives from it)."""
+    from .rasterizer import visibility_batch
+    dev = pc.get_xyz.device
+    n = pc.get_xyz.shape[0]
+    if count is None:
+        count = torch.zeros(n, dtype=torch.int32, device=dev)
+    if not cameras or n == 0:
+        return count
+    # activations do not depend on the camera when no normals are asked for
+    scales, rotations, opacity = fused_activate(pc, cameras[0].camera_center, _cam_rotation(cameras[0], dev), False)
+    cov = None
+    if pipe.compute_cov3D_python:
+        cov, scales, rotations = pc.get_covariance(scaling_modifier), None, None
+    groups = {}
+    for cam in cameras:
+        groups.setdefault((int(cam.image_height), int(cam.image_width)), []).append(cam)
+    for (h, w), cams in groups.items():
+        vm = torch.stack([c.world_view_transform.to(dev) for c in cams])
+        pm = torch.stack([c.full_proj_transform.to(dev) for c in cams])
+        cc = torch.stack([c.camera_center.to(dev) for c in cams])
+        visibility_batch(vm, pm, cc, [math.tan(c.FoVx * 0.5) for c in cams], [math.tan(c.FoVy * 0.5) for c in cams], h, w,
+                         pc.get_xyz, opacity, scales, rotations, cov, scaling_modifier, flags_only, count, inflight)
+    return count
+
+
 def visi_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
     """f_count=2 (`gaussian_renderer/__init__.py:358-464`): per-Gaussian visibility count + importance + image."""
     (count, score, image, radii), sp = _forward_only(viewpoint_camera, pc, pipe, bg_color, scaling_modifier,

@@ -79,14 +79,17 @@ class RasterOptions:
       colour_stream    torch.cuda.Stream: SH -> RGB is evaluated there (VcrRasterArgs.colour_stream), joined before compositing.
       colour_hook      callable(): enqueue caller work on `colour_stream` ahead of the colour evaluation.
       colour_sh_update callable() -> (_lib.VcrShUpdate, keep-alive) or None: SH Adam step fused into the colour evaluation.
-      sort_stream      torch.cuda.Stream: depth keys + depth sort run there, beside the projection."""
-    __slots__ = ("sh_grad", "colour_stream", "colour_hook", "colour_sh_update", "sort_stream")
+      sort_stream      torch.cuda.Stream: depth keys + depth sort run there, beside the projection.
+      quad_lists       bin the tile instances per 8x8 quad instead of per 16x16 tile (`VcrRasterArgs.quad_lists`): identical
+                       results, fewer gathers in the compositing kernels, more sort entries -- pays for small footprints."""
+    __slots__ = ("sh_grad", "colour_stream", "colour_hook", "colour_sh_update", "sort_stream", "quad_lists")
 
-    def __init__(self, sh_grad="full", colour_stream=None, colour_hook=None, colour_sh_update=None, sort_stream=None):
+    def __init__(self, sh_grad="full", colour_stream=None, colour_hook=None, colour_sh_update=None, sort_stream=None,
+                 quad_lists=False):
         if sh_grad not in ("full", "rgb"):
             raise ValueError("sh_grad must be 'full' or 'rgb'")
         self.sh_grad, self.colour_stream, self.colour_hook = sh_grad, colour_stream, colour_hook
-        self.colour_sh_update, self.sort_stream = colour_sh_update, sort_stream
+        self.colour_sh_update, self.sort_stream, self.quad_lists = colour_sh_update, sort_stream, bool(quad_lists)
 
 
 DEFAULT_OPTIONS = RasterOptions()
@@ -175,6 +178,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         fc = int(rs.f_count)
         opts = DEFAULT_OPTIONS if opts is None else opts
         rec = RasterRecord() if rec is None else rec
+        a.quad_lists = 1 if (opts.quad_lists and max(H, W) <= 8192) else 0
         hook = upd = None
         if opts.sort_stream is not None and fc == 0 and N > 0:
             a.sort_stream = opts.sort_stream.cuda_stream
@@ -189,7 +193,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 hook = _lib.HOOK_FN(lambda _user: fn())            # kept alive until the forward call returns
                 a.colour_stream_hook = _ct.cast(hook, _ct.c_void_p)
         C = 8 + S + int(num_dist)
-        out = torch.empty((C if fc == 0 else 3, H, W), dtype=torch.float32, device=dev) if fc != 3 else None
+        out = torch.empty((C if fc == 0 else 3, H, W), dtype=torch.float32, device=dev) if fc not in (3, 4) else None
         radii = torch.empty(N, dtype=torch.int32, device=dev)      # fully written by the preprocess kernel
         count = torch.zeros(N, dtype=torch.int32, device=dev) if fc != 0 else None
         if fc == 0 and _os.environ.get("VCR_TIMING"):       # experiment builds only (-DVCR_TIMING)
@@ -270,6 +274,44 @@ class _RasterizeGaussians(torch.autograd.Function):
             ctx.rec.drgb, ctx.rec.view_dirs = d_rgb, v_dirs
         return (d_means3D, d_means2D, d_dens, d_shs, d_col, d_nrm, d_sem, d_opac, d_sc, d_rot, d_cov, None, None, d_shr, None,
                 None, None)
+
+
+@torch.no_grad()
+def visibility_batch(viewmatrices, projmatrices, campos, tanfovx, tanfovy, image_height, image_width, means3D, opacities,
+                     scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0, flags_only=False, count=None,
+                     inflight=0):
+    """The visibility passes of one densification step as ONE library call (`vcr_visibility_batch`): B cameras of the same
+    resolution, per-Gaussian counters accumulated on the device.  Equivalent to B `GaussianRasterizer` calls with
+    `f_count=3` whose `countlist`s are summed (`tools/prune.py:51-69`), without SH -> RGB, without an image and without a
+    host round trip per camera.
+      viewmatrices / projmatrices [B,4,4], campos [B,3]: `world_view_transform`, `full_proj_transform`, `camera_center` stacked;
+      tanfovx / tanfovy: sequences of B floats;  count: int32 [N] to accumulate into (default: a new zero tensor);
+      flags_only: count[i] = 1 where the summed count would be > 0 (all that `get_visi_list` reads) instead of the sum.
+    -> (count [N] int32, num_rendered [B] (3-sigma tile instances per camera), num_visible [B])"""
+    lib = _lib.load()
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("vcr_raster: tensors must live on a HIP device (no CPU path exists)")
+    N, B = int(means3D.shape[0]), int(viewmatrices.shape[0])
+    if count is None:
+        count = torch.zeros(N, dtype=torch.int32, device=dev)
+    if count.dtype != torch.int32 or count.shape != (N,) or not count.is_contiguous():
+        raise ValueError("count must be a contiguous int32 tensor of shape [N]")
+    if len(tanfovx) != B or len(tanfovy) != B or projmatrices.shape[0] != B or campos.shape[0] != B:
+        raise ValueError("one view / projection matrix, camera centre and tan(fov) pair per camera")
+    t = [_f32(x) for x in (viewmatrices, projmatrices, campos, means3D, opacities, scales, rotations, cov3D_precomp)]
+    t = [None if x is None else x.to(dev) for x in t]
+    tx, ty = (_ct.c_float * max(B, 1))(*map(float, tanfovx)), (_ct.c_float * max(B, 1))(*map(float, tanfovy))
+    nr, nv = (_ct.c_int64 * max(B, 1))(), (_ct.c_int32 * max(B, 1))()
+    a = _lib.VcrVisibilityBatch(N=N, H=int(image_height), W=int(image_width), B=B, flags_only=int(bool(flags_only)),
+                                inflight=int(inflight), scale_modifier=float(scale_modifier), tanfovx=tx, tanfovy=ty,
+                                viewmatrix=_ptr(t[0]), projmatrix=_ptr(t[1]), campos=_ptr(t[2]), means3D=_ptr(t[3]),
+                                opacities=_ptr(t[4]), scales=_ptr(t[5]), rotations=_ptr(t[6]), cov3D_precomp=_ptr(t[7]),
+                                count=count.data_ptr(), num_rendered=nr, num_visible=nv)
+    al = _Allocator(dev)
+    with torch.cuda.device(dev):
+        _check(lib.vcr_visibility_batch(a, al.cb, None, torch.cuda.current_stream(dev).cuda_stream))
+    return count, list(nr)[:B], list(nv)[:B]
 
 
 class GaussianRasterizer(nn.Module):

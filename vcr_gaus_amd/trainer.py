@@ -19,7 +19,7 @@ import torch
 import torch.distributed as dist
 
 from .gaussian_model import GaussianModel
-from .gaussian_renderer import count_render, render, visi_acc_render
+from .gaussian_renderer import count_render, render, visi_acc_render, visibility_counts
 from .loss_utils import (curv_loss, edge_aware_mean, entropy_regulariser, l1_ssim, normal_loss, scale_regulariser,
                          semantic_loss)
 
@@ -37,9 +37,16 @@ def load_capture(path):
 
 class Trainer:
     def __init__(self, cfg, model, cameras, extent, device, world=1, rank=0, dirs=None, seed=0, force_factorised=False,
-                 overlap_sh=None, overlap_min_gaussians=400_000):
+                 overlap_sh=None, overlap_min_gaussians=400_000, exchange="allreduce"):
         self.cfg, self.model, self.cameras = cfg, model, cameras
         self.device, self.world, self.rank = device, world, rank
+        # Collective for the geometry bucket (44 B / Gaussian): "allreduce" = ONE all-reduce, the algorithm is RCCL's choice
+        # (a ring is bound by one xGMI link: 2 (n-1)/n S / B); "rs_ag" = reduce-scatter + all-gather of the same bucket,
+        # which a fully connected xGMI node can run over all seven links at once (2 S / (n B)).  Same sums,
+        # same replicas; which one is faster on hardware is what the first SCALE run decides.
+        if exchange not in ("allreduce", "rs_ag"):
+            raise ValueError("exchange must be 'allreduce' or 'rs_ag'")
+        self.exchange_algo = exchange
         self.extent = extent
         self.model.extent = extent
         self.dirs = dirs
@@ -83,11 +90,40 @@ class Trainer:
         # third stream: depth keys + depth sort beside the projection (two-stream form only).  Measured: neutral at 1-2 M
         # Gaussians (1.61 vs 1.61, 2.50-2.58 vs 2.49-2.58 ms/step), -4 % at 5 M (4.53 vs 4.74), where the 8 sort launches
         # over 5 M keys are long enough to matter: used from 3 M Gaussians on.
+        # Binning granularity of the training render (`RasterOptions.quad_lists`), chosen per step from the previous render's
+        # footprint statistic R / V (3-sigma tiles per visible Gaussian; a property of the scene that changes slowly): per
+        # 8x8 quad below `quad_lists_below` tiles, per 16x16 tile above.  Measured (profiles/r4_quad_ab.txt): R / V = 1.9
+        # (5 M Gaussians, 1600 x 1200) step 4.42 -> 4.19 ms, 2.6 (300 k, 800 x 600) 0.815 -> 0.795, 2.8 (metric) 1.366 -> 1.359,
+        # 9.8 (full-frame variant) 1.84 -> 2.39: the sort grows with the quads a footprint covers, the compositing gain does not.
+        self.quad_lists_below, self._tiles_per_visible = 4.0, None
         self.sort_stream, self.sort_stream_min_gaussians = None, 3_000_000
         if self.overlap_sh:
             self.side = torch.cuda.Stream(device=device)
             if not os.environ.get("VCR_NO_SORT_STREAM"):
                 self.sort_stream = torch.cuda.Stream(device=device)
+
+    def reserve_arena(self, factor=8.0, min_gb=4.0, max_fraction=0.25):
+        """Take ONE large block from the device through torch's caching allocator and hand it straight back to the cache:
+        later requests of sizes the cache has not seen (every densification changes N and with it the size of every
+        per-Gaussian array and N-sized scratch buffer) are split off it instead of going to `hipMalloc`.  `factor` x the
+        model's state (parameters + both Adam moments), at least `min_gb`, at most `max_fraction` of the free memory.
+        (Measured, profiles/r4_diag_alloc.json: this removes the large `hipMalloc`s of a densification, 14 -> 0, but NOT the
+        ~0.3-0.5 s the FIRST densification of a process takes -- that is the lazy loading of the code objects of the dozen
+        torch kernels the selection logic uses for the first time; the second event takes 4 ms either way.)
+        Returns the bytes reserved (0 on host tensors)."""
+        m = self.model
+        if not m._xyz.is_cuda:
+            return 0
+        n = m._xyz.shape[0]
+        row = sum(g["params"][0].numel() // max(n, 1) for g in m.optimizer.param_groups if not g.get("aux")) * 4
+        want = max(int(min_gb * 2 ** 30), int(factor * 3 * row * n))
+        free, _total = torch.cuda.mem_get_info(self.device)
+        want = min(want, int(max_fraction * free))
+        if want <= 0:
+            return 0
+        block = torch.empty(want, dtype=torch.uint8, device=self.device)
+        del block
+        return want
 
     def _launch_pending_sh(self):
         """Enqueue the deferred SH Adam update on the side stream.  Called from the rasterizer's colour-stream hook, i.e.
@@ -275,7 +311,20 @@ class Trainer:
                 if p.grad is not None:
                     flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
                 off += n
-        works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+        if self.exchange_algo == "rs_ag" and self.world > 1:
+            # reduce-scatter + all-gather on the bucket padded to a multiple of the ranks: rank r sums slice r of every
+            # rank's bucket, then the summed slices are gathered back in place (both queued on the collective stream in order)
+            pad = (-flat.numel()) % self.world
+            if pad:
+                flat = torch.cat([flat, flat.new_zeros(pad)])
+            shard = torch.empty(flat.numel() // self.world, dtype=flat.dtype, device=flat.device)
+            # (wait(): RCCL -- this stream waits, the host does not block; gloo's asynchronous operations are NOT ordered among
+            #  themselves, so the gather must not start before the scatter has finished)
+            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, async_op=True).wait()
+            works.append(dist.all_gather_into_tensor(flat, shard, async_op=True))
+            self._rs_ag_keep = shard                                          # (alive until the waits below)
+        else:
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
         off = 0
         for p, n in zip(params, sizes):
             p.grad = flat[off:off + p.numel()].view_as(p)                       # views of the bucket: no copy back
@@ -309,6 +358,8 @@ class Trainer:
             if self.world > 1 or getattr(self, "force_collectives", False):
                 self._allreduce_grads(defer_sh=True, rec=rec)
                 self.last_exchange = "factorised-deferred"      # bucket all-reduce now, all-view SH update on the side stream
+                if self.exchange_algo == "rs_ag" and self.world > 1:
+                    self.last_exchange += "+rs_ag"
             else:
                 self.last_exchange = "none"
                 m.optimizer.grad_scale = 1.0
@@ -318,6 +369,8 @@ class Trainer:
             self._allreduce_grads(early_feature_step=not surgery, rec=rec)
             collectives = self.world > 1 or getattr(self, "force_collectives", False)
             self.last_exchange = ("factorised" if self.factorised_sh else "dense") if collectives else "none"
+            if collectives and self.exchange_algo == "rs_ag" and self.world > 1:
+                self.last_exchange += "+rs_ag"
 
     def _sh_grads_from_rgb(self, drgb_all, campos_all):
         """sum over the step's views of basis_k(dir_view) x dL/drgb_view (HIP kernel vcr_sh_grad_from_rgb)."""
@@ -410,13 +463,21 @@ class Trainer:
 
     # ---- visibility / importance passes (`tools/prune.py:6-69`, `trainer.py:688-702`), camera-sharded ------------
     @torch.no_grad()
-    def visibility_mask(self, cams):
-        count = None
-        for cam in cams[self.rank::self.world]:
-            c = visi_acc_render(cam, self.model, self.cfg.pipline, self.background)["countlist"]
-            count = c if count is None else count + c
-        if count is None:
-            count = torch.zeros(self.model._xyz.shape[0], dtype=torch.int32, device=self.device)
+    def visibility_mask(self, cams, batched=True):
+        """`Trainer.get_visi_mask_acc` (`trainer.py:688-702`): Gaussians that contribute to a pixel of any of `cams` and lie
+        inside the normalised bounding box.  The reference renders the cameras one by one (`get_visi_list`) and tests the
+        summed `countlist` for `> 0`; here a rank's share of the cameras goes through ONE batched library call that only
+        raises a flag per Gaussian (`batched=False`: the reference's per-camera form, kept for the equality test)."""
+        mine = cams[self.rank::self.world]
+        if batched and self.model._xyz.is_cuda:
+            count = visibility_counts(mine, self.model, self.cfg.pipline, flags_only=True)
+        else:
+            count = None
+            for cam in mine:
+                c = visi_acc_render(cam, self.model, self.cfg.pipline, self.background)["countlist"]
+                count = c if count is None else count + c
+            if count is None:
+                count = torch.zeros(self.model._xyz.shape[0], dtype=torch.int32, device=self.device)
         if self.world > 1:
             dist.all_reduce(count, op=dist.ReduceOp.SUM)
         return (count > 0) & self.model.get_inside_gaus_normalized()[0]
@@ -468,7 +529,8 @@ class Trainer:
         opts = RasterOptions("rgb" if self.factorised_sh else "full", self.side if overlap else None,
                              self._launch_pending_sh if (overlap and not fuse) else None,
                              self._pending_sh_update if fuse else None,
-                             self.sort_stream if (overlap and m._xyz.shape[0] >= self.sort_stream_min_gaussians) else None)
+                             self.sort_stream if (overlap and m._xyz.shape[0] >= self.sort_stream_min_gaussians) else None,
+                             quad_lists=self._tiles_per_visible is not None and self._tiles_per_visible < self.quad_lists_below)
         surgery = (it < cfg.optim.densify_until_iter and it > cfg.optim.densify_from_iter
                    and it % cfg.optim.densification_interval == 0) \
             or it % cfg.optim.opacity_reset_interval == 0 or it in cfg.optim.prune.iterations \
@@ -486,6 +548,8 @@ class Trainer:
                           dist_channels="distortion" in extra or "depth_var" in extra)
             if self._pending_sh is not None:     # the render did not go through the two-stream path (e.g. no Gaussians)
                 self.join_side()
+            rr = data["raster"]
+            self._tiles_per_visible = rr.R / rr.V if rr.V > 0 else None
             fused_losses.DEFER_SCALE_GRAD = True    # l1_scale's gradient joins the activation backward's kernel (same graph)
             left, ok = None, False
             try:
@@ -554,7 +618,8 @@ class Trainer:
 
 
 def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_jitter=0.02, seed=0,
-                           force_factorised=False, overlap_sh=None, overlap_min_gaussians=400_000, **overrides):
+                           force_factorised=False, overlap_sh=None, overlap_min_gaussians=400_000, exchange="allreduce",
+                           **overrides):
     """Model + GT (renders of a perturbed copy of the scene, so every loss is non-trivial) + Trainer."""
     from . import synthetic
     from .config import make_config
@@ -575,7 +640,8 @@ def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_
     dirs = get_all_px_dir(cams[0].intr, cams[0].image_height, cams[0].image_width) \
         if cfg.model.depth_type == "intersection" else None
     tr = Trainer(cfg, model, cams, extent, device, world=world, rank=rank, dirs=dirs, seed=seed,
-                 force_factorised=force_factorised, overlap_sh=overlap_sh, overlap_min_gaussians=overlap_min_gaussians)
+                 force_factorised=force_factorised, overlap_sh=overlap_sh, overlap_min_gaussians=overlap_min_gaussians,
+                 exchange=exchange)
     # ground truth from a jittered copy
     g = torch.Generator().manual_seed(seed + 1)
     raw2 = {k: v.clone() for k, v in raw.items()}
@@ -600,11 +666,12 @@ def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_
 class BenchTrainer:
     """bench.py's step: exactly `Trainer.train_step` on a synthetic workload."""
 
-    def __init__(self, raw, cams, device, world=1, rank=0, preset="tnt"):
-        self.tr = make_synthetic_trainer(raw, cams, device, world=world, rank=rank, preset=preset,
+    def __init__(self, raw, cams, device, world=1, rank=0, preset="tnt", exchange="allreduce"):
+        self.tr = make_synthetic_trainer(raw, cams, device, world=world, rank=rank, preset=preset, exchange=exchange,
                                          optim={"densify_from_iter": 10 ** 9, "prune": {"iterations": []}})
         self.last_R = self.last_V = self.last_E = 0
         self._primed = False
+        self.arena_bytes = self.tr.reserve_arena()
 
     def prime(self, min_seconds=1.0):
         """Untimed set-up.  Runs ordinary training steps -- every camera at least once, so that every instance-count-
