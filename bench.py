@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--preset", default="tnt", help="loss / schedule configuration of the step: tnt (the headline line), dtu (the "
                     "reference's DTU configuration: distortion loss configured, active after iteration 15 000), dtu_c3, 360")
     ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--side-cus", type=int, default=0, help="experiment: confine the side stream (SH update + SH -> RGB) to this "
+                    "many compute units (0 = the whole chip)")
     ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "rs_ag"], help="collective for the 44 B / Gaussian "
                     "geometry bucket on N > 1 GPUs: one all-reduce (RCCL's algorithm choice) or reduce-scatter + all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -348,7 +350,7 @@ def main():
     if smult != 1.0:
         raw["scaling"] = raw["scaling"] + math.log(smult)
     cams = synthetic.make_cameras(max(args.views, world), W, H, focal, radius=synthetic.camera_radius(args.workload), device=dev)
-    trainer = BenchTrainer(raw, cams, dev, world=world, rank=rank, preset=args.preset, exchange=args.exchange)
+    trainer = BenchTrainer(raw, cams, dev, world=world, rank=rank, preset=args.preset, exchange=args.exchange, side_cus=args.side_cus)
 
     def sync():
         if world > 1:
@@ -407,7 +409,7 @@ def main():
                        "views_per_step": world, "tile_instances_R": R, "emitted_instances": trainer.last_E, "visible_V": trainer.last_V,
                        "max_tile_len": shape["max_tile_len"], "covered_pixels": shape["covered_pixels"],
                        "exchange": trainer.exchange(), "exchange_collective": args.exchange if world > 1 else None,
-                       "step": trainer.describe(), "ranks": world,
+                       "step": trainer.describe(), "ranks": world, "side_stream_cus": args.side_cus or None,
                        "dist_backend": (dist.get_backend() if world > 1 else None), "env_switches": switches()},
             "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": per_step[0], "max": per_step[-1],
                         "note": "per-step GPU-timeline spread (events after every step); `value` uses the wall clock of all K steps"},

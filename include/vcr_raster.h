@@ -371,6 +371,12 @@ int vcr_l1_ssim_forward(int H, int W, const float* img1, const float* img2, doub
 int vcr_l1_ssim_backward(int H, int W, const float* img1, const float* img2, const float* partials9, const float* g_l1,
                          const float* g_ssim, float* dimg1, void* stream);
 
+/* A HIP stream confined to the compute units whose bits are set in `mask` (hipExtStreamCreateWithCUMask; consecutive bits
+ * are dealt round-robin over the XCDs, so the lowest M bits are M CUs spread over the chip) -- for VcrRasterArgs.colour_stream:
+ * the streaming SH kernel then leaves the remaining CUs to the sort chain.  Returns NULL on error. */
+void* vcr_stream_create_cu_masked(const uint32_t* mask, int nwords);
+int vcr_stream_destroy(void* stream);
+
 /* Optional per-stage timing with HIP events recorded on the launch stream (used by bench.py for the
  * live roofline figure; no reference counterpart).  Stage order: preprocess, depth sort+scan,
  * duplicate+tile sort+ranges, composite forward, composite backward, preprocess backward. */

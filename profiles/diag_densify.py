@@ -47,6 +47,14 @@ def main():
     out = []
     o = tr.cfg.optim
     dl = o.densify_large
+    from vcr_gaus_amd import _lib as _L
+    _L.profile_enable(True); _L.profile_read()
+    for k in range(16):
+        bt.step(0)
+    tr.join_side(); torch.cuda.synchronize()
+    pr0 = _L.profile_read(); _L.profile_enable(False)
+    setup["stage_ms_before"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in pr0.items()}
+    setup["R_V_E_before"] = [bt.last_R, bt.last_V, bt.last_E]
     for ev in range(a.events):
         rec = {"N_before": tr.model._xyz.shape[0]}
         _, rec["steady_step_ms"] = wall(lambda: [bt.step(0) for _ in range(10)])
@@ -78,6 +86,15 @@ def main():
             _, t = wall(lambda: bt.step(0))
             steps.append((round(t, 3), torch.cuda.memory_stats(dev)["num_device_alloc"] - s0))
         rec["steps_after_ms_and_hipmallocs"] = steps
+        from vcr_gaus_amd import _lib
+        _lib.profile_enable(True); _lib.profile_read()
+        for k in range(16):
+            bt.step(0)
+        tr.join_side(); torch.cuda.synchronize()
+        pr = _lib.profile_read(); _lib.profile_enable(False)
+        rec["stage_ms_after"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in pr.items()}
+        rec["R_V_E_after"] = [bt.last_R, bt.last_V, bt.last_E]
+        rec["quad_lists_after"] = bool(tr._tiles_per_visible is not None and tr._tiles_per_visible < tr.quad_lists_below)
         rec["reserved_GB"] = torch.cuda.memory_reserved(dev) / 2 ** 30
         out.append(rec)
     print(json.dumps({"setup": setup, "events": out}))

@@ -120,16 +120,18 @@ def grad_stats(a, b):
 #   "full"   the full-size sampled-tile cases (every pixel sees ~10x more pairs: the yardstick itself is ~6x wider there),
 #   "step"   whole training iterations (the image losses add their own fp32 reductions).
 # i.e. the HIP path may be at most FACTOR times as noisy as a plain fp32 evaluation of the same algorithm.  FACTOR = 3,
-# with these measured exceptions (HIP / yardstick over the GPU suite, profiles/r3_grad_ratio_table.txt):
-#   small: 5 for means3D / scales / rots -- their gradients pass through the Sigma2D -> Sigma3D -> (s, q) and projection
-#          adjoints, which amplify the rounding of the conic / position sums the compositing backward accumulates with
-#          fp32 atomics in arbitrary order (measured up to 4.3x; the oracle sums pairwise in index order);
-#   step:  8 on the quantiles: on top of that the whole-step scenes use 6x enlarged Gaussians (long per-pixel lists), where
-#          the back-to-front transmittance recovery T_i = T_{i+1} / (1 - alpha_i) of the backward -- the reference's algorithm,
-#          which the autograd oracle does not share -- accumulates one rounding per list entry (measured 3 - 6.7x).  The
-#          max-norm figure is the error of the single largest entry: there the step yardstick (5e-6 for the scales) is a
-#          lucky draw, and the bound is the small-regime max-norm tolerance of the same tensor; 12 for the densification
-#          statistic (sum over pixels of |dL/dxy|: measured 8.8 - 10.8x);
+# with these measured exceptions (HIP / yardstick per case: profiles/r4_grad_ratio_table_default.txt, and -- the same figures
+# with every fp32 atomic of the backward issued in ONE fixed order -- profiles/r4_grad_ratio_table_det.txt):
+#   small: 5 for means3D / scales / rots (measured element-wise p99 / p99.9 up to 3.6 / 5.9x).  Round 4 built the
+#          deterministic-order backward to find out what this is made of, and the answer is NOT the order of the atomics:
+#          the deterministic build shows the same quantiles to within a few per cent (tests/test_deterministic_bwd_gpu.py).
+#          It is the backward ALGORITHM of the reference's rasterizer family -- transmittance recovered back to front by
+#          T_i = T_{i+1} / (1 - alpha_i), one division's rounding per list entry, amplified by the Sigma2D -> Sigma3D ->
+#          (s, q) and projection adjoints -- which the autograd oracle (it keeps every T_i from the forward) does not share;
+#   step:  8 on the quantiles: the whole-step scenes use 6x enlarged Gaussians (long per-pixel lists), where that recovery
+#          accumulates most (measured 3 - 6.7x).  The max-norm figure is the error of the single largest entry: there the step
+#          yardstick (5e-6 for the scales) is a lucky draw, and the bound is the small-regime max-norm tolerance of the same
+#          tensor; 12 for the densification statistic (sum over pixels of |dL/dxy|: measured 8.8 - 10.8x);
 #   full:  3 throughout (measured 0.7 - 1.6x).
 # Floors: 2e-5 / 2e-5 / 2e-4 (below that the figure is a handful of fp32 ulps of a sum of ~100 terms).
 # (A pixel whose alpha >= 1/255 or T < 1e-4 decision flips between fp32 and fp64 moves the gradients of the few

@@ -144,6 +144,8 @@ SYMBOLS = {
     "vcr_entropy_backward": (C.c_int, [C.c_int] + [C.c_void_p] * 8),
     "vcr_l1_ssim_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
     "vcr_l1_ssim_backward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 7),
+    "vcr_stream_create_cu_masked": (C.c_void_p, [C.POINTER(C.c_uint32), C.c_int]),
+    "vcr_stream_destroy": (C.c_int, [C.c_void_p]),
     "vcr_profile_enable": (None, [C.c_int]),
     "vcr_profile_select": (None, [C.c_uint]),
     "vcr_profile_num_stages": (C.c_int, []),
@@ -188,6 +190,22 @@ def stream_of(t):
 
 def last_error():
     return load().vcr_last_error().decode()
+
+
+def cu_masked_stream(num_cus, device, total_cus=256):
+    """torch.cuda.ExternalStream confined to `num_cus` compute units spread evenly over the XCDs (the lowest `num_cus` bits of
+    the driver's logical CU mask).  The HIP stream lives as long as the process."""
+    import torch
+    lib = load()
+    words = (total_cus + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for i in range(min(num_cus, total_cus)):
+        mask[i // 32] |= 1 << (i % 32)
+    with torch.cuda.device(device):
+        ptr = lib.vcr_stream_create_cu_masked(mask, words)
+    if not ptr:
+        raise RuntimeError("vcr_raster: " + last_error())
+    return torch.cuda.ExternalStream(ptr, device=device)
 
 
 def profile_enable(on=True, stages=None):

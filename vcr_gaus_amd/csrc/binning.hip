@@ -182,8 +182,13 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
                            unsigned long long* status, int64_t R, int tile_bits, uint2* inst, uint2* pair_a, uint2* pair_b,
                            uint32_t* keys_b, uint32_t* point_list, uint2* ranges, uint32_t* tile_order, uint32_t* meta,
                            int num_tiles, uint32_t* totals, void* temp, size_t temp_bytes, hipStream_t st) {
+#ifdef VCR_DETERMINISTIC_BWD
+    const bool no_lpt = true, no_snake = true;       // test-only build: identity launch order (the counting sort of tile_order
+                                                     // places tiles of equal length in the order its LDS atomics resolve)
+#else
     static const bool no_lpt = getenv("VCR_NO_LPT") != nullptr;          // experiment switches
     static const bool no_snake = getenv("VCR_NO_SNAKE") != nullptr;
+#endif
     const int gx_tiles = (a.W + VCR_TILE - 1) / VCR_TILE;
     const bool ql = a.quad_lists != 0;
     const int num_keys = ql ? 4 * num_tiles : num_tiles, gx_keys = ql ? 2 * gx_tiles : gx_tiles;

@@ -604,6 +604,22 @@ extern "C" int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* 
     return vcr_launch_preprocess_backward(a, g, io->radii, sgrad, sgrad_sem, io2, st);
 }
 
+// A HIP stream whose kernels may only run on the compute units whose bits are set in `mask` (`nwords` 32-bit words, bit i of the
+// logical CU numbering of the driver, which deals consecutive bits round-robin over the XCDs and their shader engines, so the
+// lowest M bits are M CUs spread evenly over the chip).  For the side stream of the two-stream step: a streaming kernel
+// confined to part of the chip leaves the rest to the latency-bound sort chain of the main stream.
+extern "C" void* vcr_stream_create_cu_masked(const uint32_t* mask, int nwords) {
+    hipStream_t s = nullptr;
+    if (!mask || nwords <= 0) { vcr_set_error("vcr_stream_create_cu_masked: empty mask"); return nullptr; }
+    const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask);
+    if (e != hipSuccess) { vcr_set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e)); return nullptr; }
+    return (void*)s;
+}
+extern "C" int vcr_stream_destroy(void* stream) {
+    if (stream) VCR_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+
 extern "C" void vcr_profile_enable(int on) { g_prof = on != 0; }
 extern "C" void vcr_profile_select(unsigned stage_mask) { g_prof_mask = stage_mask; }
 

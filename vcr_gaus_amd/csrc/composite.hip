@@ -354,7 +354,12 @@ _Pragma("unroll")                                                               
     if (lane == 0 && count) {       // experiment builds only: (start, end) wall-clock ticks per wave
         reinterpret_cast<long long*>(count)[4 * (blockIdx.x * 4 + wv)] = t_start;
         reinterpret_cast<long long*>(count)[4 * (blockIdx.x * 4 + wv) + 1] = wall_clock64();
-        reinterpret_cast<long long*>(count)[4 * (blockIdx.x * 4 + wv) + 2] = ((long long)n_chunks << 32) | (unsigned)n_surv;
+        // bits 48..: where the wave ran -- HW_ID (wave / SIMD / CU / SH / SE ids) and the XCC id
+        unsigned hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        const unsigned long long place = ((unsigned long long)(xcc_id & 0xF) << 12) | ((hw_id >> 4) & 0xFFF);   // simd[1:0] pipe[3:2] cu[7:4] sh[8] se[11:9]
+        reinterpret_cast<long long*>(count)[4 * (blockIdx.x * 4 + wv) + 2] = (long long)((place << 48) | ((unsigned long long)(n_chunks & 0xFFFF) << 32) | (unsigned)n_surv);
         reinterpret_cast<long long*>(count)[4 * (blockIdx.x * 4 + wv) + 3] = (t_cull << 32) | (t_surv & 0xFFFFFFFF);
     }
 #endif
@@ -400,7 +405,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 
                                                                const uint32_t* __restrict__ n_contrib,
                                                                const float* __restrict__ moments,
                                                                const float* __restrict__ dL_dout, GradRec* __restrict__ sgrad,
-                                                               float* __restrict__ sgrad_sem) {
+                                                               float* __restrict__ sgrad_sem, int det_sel) {
+#ifdef VCR_DETERMINISTIC_BWD
+    // test-only build: the launcher issues one launch per (workgroup, wave) and every other wave leaves at once, so the fp32
+    // atomics of the whole backward happen in ONE fixed order (tile order, quad 0..3, list back to front)
+    if ((int)(blockIdx.x * 4 + (threadIdx.x >> 6)) != det_sel) return;
+#else
+    (void)det_sel;
+#endif
     const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
     int sub;
     const int tile = work_item(tile_order, meta, num_tiles, sub);
@@ -668,7 +680,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_RO
                                                                const uint32_t* __restrict__ n_contrib,
                                                                const float* __restrict__ moments,
                                                                const float* __restrict__ dL_dout, GradRec* __restrict__ sgrad,
-                                                               float* __restrict__ sgrad_sem, int rows_bias, int rows_pair_cost) {
+                                                               float* __restrict__ sgrad_sem, int rows_bias, int rows_pair_cost, int det_sel) {
+#ifdef VCR_DETERMINISTIC_BWD
+    // test-only build: the launcher issues one launch per (workgroup, wave) and every other wave leaves at once, so the fp32
+    // atomics of the whole backward happen in ONE fixed order (tile order, quad 0..3, list back to front)
+    if ((int)(blockIdx.x * 4 + (threadIdx.x >> 6)) != det_sel) return;
+#else
+    (void)det_sel;
+#endif
     const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
     int sub;
     const int tile = work_item(tile_order, meta, num_tiles, sub);
@@ -866,15 +885,20 @@ int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
     // (64, 0) = always; (20, 2) from the sweep in profiles/r3_bwd_rows_ab.txt
     static const int rows_bias = []() { const char* e = getenv("VCR_BWD_ROWS_BIAS"); return e ? atoi(e) : 20; }();
     static const int rows_pair_cost = []() { const char* e = getenv("VCR_BWD_ROWS_PAIR"); return e ? atoi(e) : 2; }();
+#ifdef VCR_DETERMINISTIC_BWD
+    const int det_first = 0, det_last = 4 * (tiles + 3 * VCR_SPLIT_MAX);      // one launch per (workgroup, wave), in order
+#else
+    const int det_first = -1, det_last = 0;
+#endif
 #define VCR_BWD(SS)                                                                                              \
-    do {                                                                                                         \
+    for (int det = det_first; det < det_last; ++det) {                                                           \
         if (rows)                                                                                                \
             hipLaunchKernelGGL((composite_bwd_rows_kernel<SS, ISECT, ND>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
-                               b.point_list, b.ranges, b.tile_order, b.meta, tiles, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem, rows_bias, rows_pair_cost); \
+                               b.point_list, b.ranges, b.tile_order, b.meta, tiles, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem, rows_bias, rows_pair_cost, det); \
         else                                                                                                     \
             hipLaunchKernelGGL((composite_bwd_v2_kernel<SS, ISECT, ND>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
-                               b.point_list, b.ranges, b.tile_order, b.meta, tiles, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem); \
-    } while (0)
+                               b.point_list, b.ranges, b.tile_order, b.meta, tiles, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem, det); \
+    }
     switch (a.S) {
         case 0: VCR_BWD(0); break;
         case 1: VCR_BWD(1); break;

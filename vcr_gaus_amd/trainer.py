@@ -37,7 +37,7 @@ def load_capture(path):
 
 class Trainer:
     def __init__(self, cfg, model, cameras, extent, device, world=1, rank=0, dirs=None, seed=0, force_factorised=False,
-                 overlap_sh=None, overlap_min_gaussians=400_000, exchange="allreduce"):
+                 overlap_sh=None, overlap_min_gaussians=400_000, exchange="allreduce", side_cus=0):
         self.cfg, self.model, self.cameras = cfg, model, cameras
         self.device, self.world, self.rank = device, world, rank
         # Collective for the geometry bucket (44 B / Gaussian): "allreduce" = ONE all-reduce, the algorithm is RCCL's choice
@@ -98,7 +98,13 @@ class Trainer:
         self.quad_lists_below, self._tiles_per_visible = 4.0, None
         self.sort_stream, self.sort_stream_min_gaussians = None, 3_000_000
         if self.overlap_sh:
-            self.side = torch.cuda.Stream(device=device)
+            # `side_cus` > 0: the side stream is confined to that many compute units (spread over the XCDs), so that the streaming
+            # SH update cannot occupy the CUs the sort chain of the main stream needs (experiment)
+            if side_cus:
+                from . import _lib
+                self.side = _lib.cu_masked_stream(int(side_cus), device)
+            else:
+                self.side = torch.cuda.Stream(device=device)
             if not os.environ.get("VCR_NO_SORT_STREAM"):
                 self.sort_stream = torch.cuda.Stream(device=device)
 
@@ -619,7 +625,7 @@ class Trainer:
 
 def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_jitter=0.02, seed=0,
                            force_factorised=False, overlap_sh=None, overlap_min_gaussians=400_000, exchange="allreduce",
-                           **overrides):
+                           side_cus=0, **overrides):
     """Model + GT (renders of a perturbed copy of the scene, so every loss is non-trivial) + Trainer."""
     from . import synthetic
     from .config import make_config
@@ -641,7 +647,7 @@ def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_
         if cfg.model.depth_type == "intersection" else None
     tr = Trainer(cfg, model, cams, extent, device, world=world, rank=rank, dirs=dirs, seed=seed,
                  force_factorised=force_factorised, overlap_sh=overlap_sh, overlap_min_gaussians=overlap_min_gaussians,
-                 exchange=exchange)
+                 exchange=exchange, side_cus=side_cus)
     # ground truth from a jittered copy
     g = torch.Generator().manual_seed(seed + 1)
     raw2 = {k: v.clone() for k, v in raw.items()}
@@ -666,8 +672,9 @@ def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_
 class BenchTrainer:
     """bench.py's step: exactly `Trainer.train_step` on a synthetic workload."""
 
-    def __init__(self, raw, cams, device, world=1, rank=0, preset="tnt", exchange="allreduce"):
+    def __init__(self, raw, cams, device, world=1, rank=0, preset="tnt", exchange="allreduce", side_cus=0):
         self.tr = make_synthetic_trainer(raw, cams, device, world=world, rank=rank, preset=preset, exchange=exchange,
+                                         side_cus=side_cus,
                                          optim={"densify_from_iter": 10 ** 9, "prune": {"iterations": []}})
         self.last_R = self.last_V = self.last_E = 0
         self._primed = False
