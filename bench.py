@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--preset", default="tnt", help="loss / schedule configuration of the step: tnt (the headline line), dtu (the "
                     "reference's DTU configuration: distortion loss configured, active after iteration 15 000), dtu_c3, 360")
     ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--quad-below", type=float, default=None, help="experiment: R / V threshold below which the training render bins "
+                    "per 8x8 quad (default: the trainer's 2.7; 0 = never)")
+    ap.add_argument("--arena", action="store_true", help="experiment: reserve the memory arena (Trainer.reserve_arena) at set-up")
     ap.add_argument("--side-cus", type=int, default=0, help="experiment: confine the side stream (SH update + SH -> RGB) to this "
                     "many compute units (0 = the whole chip)")
     ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "rs_ag"], help="collective for the 44 B / Gaussian "
@@ -350,7 +353,10 @@ def main():
     if smult != 1.0:
         raw["scaling"] = raw["scaling"] + math.log(smult)
     cams = synthetic.make_cameras(max(args.views, world), W, H, focal, radius=synthetic.camera_radius(args.workload), device=dev)
-    trainer = BenchTrainer(raw, cams, dev, world=world, rank=rank, preset=args.preset, exchange=args.exchange, side_cus=args.side_cus)
+    trainer = BenchTrainer(raw, cams, dev, world=world, rank=rank, preset=args.preset, exchange=args.exchange, side_cus=args.side_cus,
+                           arena=args.arena)
+    if args.quad_below is not None:
+        trainer.tr.quad_lists_below = args.quad_below
 
     def sync():
         if world > 1:
@@ -366,6 +372,9 @@ def main():
     _lib.profile_enable(True, stages=["composite_fwd"])
     _lib.profile_read()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step spread (GPU timeline)
+    # (NOT done here: keeping the interpreter's cyclic garbage collector out of the timed steps.  Measured with the driver's
+    #  20 steps, round 4: with `gc.disable()` every step is ~50 us slower and the first one 0.6 ms -- the autograd graph of a step
+    #  is cyclic garbage, and until it is collected its tensors keep their blocks, so the next step works in cold memory.)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -373,7 +382,8 @@ def main():
         marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    in_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    per_step = sorted(in_order)
     pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
     prof = _lib.profile_read()
     _lib.profile_enable(True)                      # untimed: the same steps again with every stage timed (stage_ms)
@@ -410,8 +420,9 @@ def main():
                        "max_tile_len": shape["max_tile_len"], "covered_pixels": shape["covered_pixels"],
                        "exchange": trainer.exchange(), "exchange_collective": args.exchange if world > 1 else None,
                        "step": trainer.describe(), "ranks": world, "side_stream_cus": args.side_cus or None,
+                       "quad_lists_below": trainer.tr.quad_lists_below, "quad_lists": bool(trainer.tr._quad_on), "arena_bytes": trainer.arena_bytes,
                        "dist_backend": (dist.get_backend() if world > 1 else None), "env_switches": switches()},
-            "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": per_step[0], "max": per_step[-1],
+            "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": per_step[0], "max": per_step[-1], "slowest_step_index": in_order.index(per_step[-1]),
                         "note": "per-step GPU-timeline spread (events after every step); `value` uses the wall clock of all K steps"},
             "raster_mpix_per_s": world * P / (raster_fwd_ms * 1e-3) / 1e6 if raster_fwd_ms > 0 else None,
             "raster_covered_mpix_per_s": world * shape["covered_pixels"] / (raster_fwd_ms * 1e-3) / 1e6 if raster_fwd_ms > 0 else None,

@@ -95,7 +95,8 @@ typedef struct VcrRasterArgs {
                                    no entry is gathered or culled four times (-33 % HBM fetch of both compositing kernels at
                                    1 M Gaussians / 1080p) at the price of 1.3-1.6x sort entries when footprints are small and
                                    up to 4x when they cover whole tiles.  Same image, same gradients (positions in a list are
-                                   internal to a forward / backward pair; the backward follows the forward's choice).  Pays for
+                                   internal to a forward / backward pair).  vcr_rasterize_backward MUST be called with the value its forward was
+                                   called with: the state buffers hold the lists in that form.  Pays for
                                    small footprints (R / V below ~4 tiles per visible Gaussian); images up to 8192 pixels. */
     int32_t pad_;
 } VcrRasterArgs;

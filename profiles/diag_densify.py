@@ -94,7 +94,7 @@ def main():
         pr = _lib.profile_read(); _lib.profile_enable(False)
         rec["stage_ms_after"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in pr.items()}
         rec["R_V_E_after"] = [bt.last_R, bt.last_V, bt.last_E]
-        rec["quad_lists_after"] = bool(tr._tiles_per_visible is not None and tr._tiles_per_visible < tr.quad_lists_below)
+        rec["quad_lists_after"] = bool(tr._quad_on)
         rec["reserved_GB"] = torch.cuda.memory_reserved(dev) / 2 ** 30
         out.append(rec)
     print(json.dumps({"setup": setup, "events": out}))

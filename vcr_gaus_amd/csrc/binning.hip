@@ -28,6 +28,7 @@ constexpr int DUP_ROUNDS = 4;                       // Gaussians per thread: 102
 //   * unmasked giants: wave-cooperatively and load-balanced -- the wave's giant counts are prefix-summed in LDS and every
 //     lane binary-searches the Gaussian its slot belongs to, so a screen-filling Gaussian does not serialise a lane.
 // `status`: one zeroed 64-bit word per block; `ticket`: one zeroed word.
+template <bool QL>      // QL: 64-bit cell masks (upper word in rect_hi); the per-tile form compiles to its 32-bit walk
 __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, const uint32_t* __restrict__ ids_sorted,
                                                         unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket,
                                                         const uint2* __restrict__ rect, const uint32_t* __restrict__ rect_hi,
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
         if (gi < N) {
             id[r] = ids_sorted[gi];
             rc[r] = rect[id[r]];                          // {0, 0} for culled Gaussians
-            if ((rc[r].x & (VCR_RECT_MASKED | VCR_RECT_MASK64)) == (VCR_RECT_MASKED | VCR_RECT_MASK64)) mhi[r] = rect_hi[id[r]];
+            if (QL && (rc[r].x & (VCR_RECT_MASKED | VCR_RECT_MASK64)) == (VCR_RECT_MASKED | VCR_RECT_MASK64)) mhi[r] = rect_hi[id[r]];
             cnt[r] = (rc[r].x & VCR_RECT_MASKED) ? (uint32_t)(__popc(rc[r].y) + __popc(mhi[r])) : (rc[r].y & 0xFFFFu) * (rc[r].y >> 16);
         }
     }
@@ -108,13 +109,23 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
         const int xmin = (int)(rc[r].x & 0x3FFu), ymin = (int)((rc[r].x >> 10) & 0x3FFu);
         if (masked) {                                      // walk the set bits of the tile mask
             const int w = (int)((rc[r].x >> 20) & 31u) + 1;
-            unsigned long long m = ((unsigned long long)mhi[r] << 32) | rc[r].y;
             uint32_t at = start;
-            while (m) {
-                const int k = __builtin_ctzll(m);
-                m &= m - 1;
-                inst_out[at] = make_uint2((uint32_t)((ymin + k / w) * gx + xmin + k % w), id[r]);      // (tile, Gaussian)
-                ++at;
+            if (QL) {
+                unsigned long long m = ((unsigned long long)mhi[r] << 32) | rc[r].y;
+                while (m) {
+                    const int k = __builtin_ctzll(m);
+                    m &= m - 1;
+                    inst_out[at] = make_uint2((uint32_t)((ymin + k / w) * gx + xmin + k % w), id[r]);      // (cell, Gaussian)
+                    ++at;
+                }
+            } else {
+                uint32_t m = rc[r].y;
+                while (m) {
+                    const int k = __builtin_ctz(m);
+                    m &= m - 1;
+                    inst_out[at] = make_uint2((uint32_t)((ymin + k / w) * gx + xmin + k % w), id[r]);      // (tile, Gaussian)
+                    ++at;
+                }
             }
         }
         const bool giant = !masked && cnt[r] != 0;
@@ -198,8 +209,12 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
     }
     const int blocks = (a.N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS);
     uint32_t* ticket = reinterpret_cast<uint32_t*>(status + blocks + 1);
-    hipLaunchKernelGGL(duplicate_kernel, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, ticket, g.rect, g.rect_hi,
-                       inst, ranges, num_keys, gx_keys);
+    if (ql)
+        hipLaunchKernelGGL(duplicate_kernel<true>, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, ticket, g.rect,
+                           g.rect_hi, inst, ranges, num_keys, gx_keys);
+    else
+        hipLaunchKernelGGL(duplicate_kernel<false>, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, ticket, g.rect,
+                           g.rect_hi, inst, ranges, num_keys, gx_keys);
     VCR_HIP_CHECK(hipGetLastError());
     if (vcr_sort_pairs(R, nullptr, nullptr, inst, pair_a, pair_b, keys_b, point_list, 0, tile_bits, (uint32_t*)temp, totals, st,
                        nullptr)) {

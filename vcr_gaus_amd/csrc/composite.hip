@@ -69,12 +69,12 @@ __device__ __forceinline__ int work_item(const uint32_t* __restrict__ tile_order
     return i < num_tiles ? (int)tile_order[i] : -1;
 }
 
-// [begin, end) of the list a wave walks: the tile's (all four quad-waves share it), or -- quad-list mode, meta[3] = 8x8 cells
-// per row -- the list of the wave's own quad.
-__device__ __forceinline__ uint2 list_range(const uint2* __restrict__ ranges, const uint32_t* __restrict__ meta, int tile, int gx,
-                                            int quad) {
-    const int gxc = (int)meta[3];
-    if (!gxc) return ranges[tile];
+// [begin, end) of the list a wave walks: the tile's (all four quad-waves share it), or -- quad-list mode, gxc = 8x8 cells per
+// row (a kernel argument: the host knows the mode of the call; reading it from BinState::meta would put a second dependent
+// load in front of every wave, 7 us per launch with 32 k mostly empty waves) -- the list of the wave's own quad.
+template <bool QL>       // (compile-time: the per-tile kernels keep their one `ranges[tile]` load and nothing else -- a run-time
+__device__ __forceinline__ uint2 list_range(const uint2* __restrict__ ranges, int gxc, int tile, int gx, int quad) {   // branch here
+    if (!QL) return ranges[tile];                                                          // measured +7 us per forward launch)
     return ranges[(2 * (tile / gx) + (quad >> 1)) * gxc + 2 * (tile % gx) + (quad & 1)];
 }
 
@@ -162,13 +162,13 @@ __device__ unsigned int g_hithist[130];
 #else
 #define VCR_FWD_ATTR
 #endif
-template <int S, bool ISECT, int FC, int ND>
+template <int S, bool ISECT, int FC, int ND, bool QL>
 __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
                                                                const float* __restrict__ semv,
                                                                const uint32_t* __restrict__ point_list,
                                                                const uint2* __restrict__ ranges,
                                                                const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ meta,
-                                                               int num_tiles, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                               int num_tiles, int gxc, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                                float* __restrict__ moments, float* __restrict__ out,
                                                                int32_t* __restrict__ count, float* __restrict__ score) {
     const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
     const int tile = work_item(tile_order, meta, num_tiles, sub);
     if (tile < 0) return;
     const PixelMap pm = pixel_of_thread(tile, gx, a.W, a.H, sub);
-    const uint2 range = list_range(ranges, meta, tile, gx, threadIdx.x >> 6);
+    const uint2 range = list_range<QL>(ranges, gxc, tile, gx, threadIdx.x >> 6);
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // S <= 2 without count mode: the semantic features come with the record (GeomRec pad slots) and take the place of the id
@@ -395,13 +395,13 @@ _Pragma("unroll")                                                               
     }
 }
 
-template <int S, bool ISECT, int ND>
+template <int S, bool ISECT, int ND, bool QL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 0 && ND == 0) ? VCR_BWD_WAVES : 4))) composite_bwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
                                                                const float* __restrict__ semv,
                                                                const uint32_t* __restrict__ point_list,
                                                                const uint2* __restrict__ ranges,
                                                                const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ meta,
-                                                               int num_tiles, const float* __restrict__ final_T,
+                                                               int num_tiles, int gxc, const float* __restrict__ final_T,
                                                                const uint32_t* __restrict__ n_contrib,
                                                                const float* __restrict__ moments,
                                                                const float* __restrict__ dL_dout, GradRec* __restrict__ sgrad,
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 
     const int tile = work_item(tile_order, meta, num_tiles, sub);
     if (tile < 0) return;
     const PixelMap pm = pixel_of_thread(tile, gx, a.W, a.H, sub);
-    const uint2 range = list_range(ranges, meta, tile, gx, threadIdx.x >> 6);
+    const uint2 range = list_range<QL>(ranges, gxc, tile, gx, threadIdx.x >> 6);
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr bool SEM_IN_REC = false;                    // (the backward needs the id for its atomics: semantics keep their plane)
@@ -670,13 +670,13 @@ __device__ __forceinline__ float row_reduce16(const f2 v[8], int lane) {
     return (h4 ? c1 : c0) + dpp_get<0xB1>(h4 ? c0 : c1);                // quad_perm [1,0,3,2]
 }
 
-template <int S, bool ISECT, int ND>
+template <int S, bool ISECT, int ND, bool QL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_ROWS_WAVES))) composite_bwd_rows_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
                                                                const float* __restrict__ semv,
                                                                const uint32_t* __restrict__ point_list,
                                                                const uint2* __restrict__ ranges,
                                                                const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ meta,
-                                                               int num_tiles, const float* __restrict__ final_T,
+                                                               int num_tiles, int gxc, const float* __restrict__ final_T,
                                                                const uint32_t* __restrict__ n_contrib,
                                                                const float* __restrict__ moments,
                                                                const float* __restrict__ dL_dout, GradRec* __restrict__ sgrad,
@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_RO
     const int tile = work_item(tile_order, meta, num_tiles, sub);
     if (tile < 0) return;
     const PixelMap pm = pixel_of_thread_rows(tile, gx, a.W, a.H, sub);
-    const uint2 range = list_range(ranges, meta, tile, gx, threadIdx.x >> 6);
+    const uint2 range = list_range<QL>(ranges, gxc, tile, gx, threadIdx.x >> 6);
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = lane >> 4;
     constexpr bool SEM_IN_REC = false;
@@ -850,9 +850,11 @@ _Pragma("unroll")                                                               
 template <int S, bool ISECT, int ND>
 int launch_fwd_fc(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o, int tiles,
                   hipStream_t st) {
-#define VCR_FWD(FC, NDD)                                                                                          \
-    hipLaunchKernelGGL((composite_fwd_v2_kernel<S, ISECT, FC, NDD>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
-                       b.point_list, b.ranges, b.tile_order, b.meta, tiles, im.final_T, im.n_contrib, im.moments, o.out, o.count, o.score)
+    const int gxc = a.quad_lists ? 2 * ((a.W + VCR_TILE - 1) / VCR_TILE) : 0;
+#define VCR_FWD_Q(FC, NDD, Q)                                                                                     \
+    hipLaunchKernelGGL((composite_fwd_v2_kernel<S, ISECT, FC, NDD, Q>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
+                       b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, o.out, o.count, o.score)
+#define VCR_FWD(FC, NDD) do { if (gxc) { VCR_FWD_Q(FC, NDD, true); } else { VCR_FWD_Q(FC, NDD, false); } } while (0)
     switch (a.f_count) {
         case 0: VCR_FWD(0, ND); break;
         case 1: case 2: VCR_FWD(1, 0); break;
@@ -860,6 +862,7 @@ int launch_fwd_fc(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im
         default: VCR_FWD(3, 0); break;
     }
 #undef VCR_FWD
+#undef VCR_FWD_Q
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -879,6 +882,7 @@ int launch_fwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
 template <bool ISECT, int ND>
 int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, const float* dL_dout, GradRec* sgrad,
                  float* sgrad_sem, int tiles, hipStream_t st) {
+    const int gxc = a.quad_lists ? 2 * ((a.W + VCR_TILE - 1) / VCR_TILE) : 0;
     static const bool rows = []() { const char* e = getenv("VCR_BWD_ROWS"); return e ? atoi(e) != 0 : true; }();
     // per chunk: row-packed loop iff 16 * max_r |list_r| + pair * sum_r |list_r| <= bias * |union_r list_r| (the second term
     // prices the atomics: an iteration with all four rows live issues 64 atomic lanes instead of 16).  bias 0 = never,
@@ -890,15 +894,16 @@ int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
 #else
     const int det_first = -1, det_last = 0;
 #endif
-#define VCR_BWD(SS)                                                                                              \
+#define VCR_BWD_Q(SS, Q)                                                                                         \
     for (int det = det_first; det < det_last; ++det) {                                                           \
         if (rows)                                                                                                \
-            hipLaunchKernelGGL((composite_bwd_rows_kernel<SS, ISECT, ND>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
-                               b.point_list, b.ranges, b.tile_order, b.meta, tiles, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem, rows_bias, rows_pair_cost, det); \
+            hipLaunchKernelGGL((composite_bwd_rows_kernel<SS, ISECT, ND, Q>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
+                               b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem, rows_bias, rows_pair_cost, det); \
         else                                                                                                     \
-            hipLaunchKernelGGL((composite_bwd_v2_kernel<SS, ISECT, ND>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
-                               b.point_list, b.ranges, b.tile_order, b.meta, tiles, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem, det); \
+            hipLaunchKernelGGL((composite_bwd_v2_kernel<SS, ISECT, ND, Q>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
+                               b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem, det); \
     }
+#define VCR_BWD(SS) do { if (gxc) { VCR_BWD_Q(SS, true) } else { VCR_BWD_Q(SS, false) } } while (0)
     switch (a.S) {
         case 0: VCR_BWD(0); break;
         case 1: VCR_BWD(1); break;
@@ -907,6 +912,7 @@ int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
         default: VCR_BWD(4); break;
     }
 #undef VCR_BWD
+#undef VCR_BWD_Q
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -230,10 +230,10 @@ __device__ __forceinline__ void stage_sh_in(const VcrRasterArgs& a, int base, in
 // Returns the number of tiles of the Gaussian's 3-sigma rectangle (0 = culled); `emit` receives the number of tile instances
 // it will emit: rectangles of up to VCR_RECT_MASK_TILES tiles are tested tile by tile (see vcr_common.h, `tile_touch`) and
 // carry the result as a bit mask in their 8-byte rectangle record, larger ones emit every tile.
-template <bool STAGE, bool COLOUR>
+template <bool STAGE, bool COLOUR, bool QL>
 __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const GeomState& g, int32_t* __restrict__ radii,
                                                    uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
-                                                   const float* s_sh, int i, uint32_t& emit, int ql) {
+                                                   const float* s_sh, int i, uint32_t& emit) {
     emit = 0;
     if (i >= a.N) return 0;
     radii[i] = 0;
@@ -320,7 +320,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const
     if (COLOUR) g.clamped[i] = clampbits;
     g.tiles[i] = (uint32_t)ntiles;
     const int rw = xmax - xmin, rh = ymax - ymin;
-    if (ql) {
+    if (QL) {      // (compile-time: the per-tile form keeps its registers and its 32-bit masks)
         // quad lists: the same record in units of 8x8 cells (2 gx cells per row); the exact test runs per cell
         // The cells are those of the TILE rectangle (the reference renders a Gaussian at every pixel of its tile rectangle where
         // alpha >= 1/255, also beyond the 3-sigma square), the mask drops the cells it cannot reach.
@@ -362,10 +362,10 @@ __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const
 
 // vis_slots (optional): 3 x VCR_VIS_SLOTS counters, [visible Gaussians | tile instances of the 3-sigma rectangles | tile
 // instances emitted], three atomics per block spread over many addresses (same-address L2 atomics serialise at ~200 ns each)
-template <bool STAGE, bool COLOUR>
+template <bool STAGE, bool COLOUR, bool QL>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, GeomState g, int32_t* __restrict__ radii,
                                                              uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
-                                                             uint32_t* __restrict__ vis_slots, int ql) {
+                                                             uint32_t* __restrict__ vis_slots) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];
     if (STAGE) {
         const int base = blockIdx.x * 256;
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
         __syncthreads();
     }
     uint32_t em;
-    const uint32_t nt = preprocess_one<STAGE, COLOUR>(a, g, radii, depth_key, ids, s_sh, blockIdx.x * 256 + threadIdx.x, em, ql);
+    const uint32_t nt = preprocess_one<STAGE, COLOUR, QL>(a, g, radii, depth_key, ids, s_sh, blockIdx.x * 256 + threadIdx.x, em);
     if (vis_slots) {
         __shared__ uint32_t s_cnt[3][4];
         uint32_t c = nt != 0 ? 1u : 0u, r = nt;
@@ -930,18 +930,21 @@ int vcr_launch_depth_keys(const VcrRasterArgs& a, uint32_t* depth_key, hipStream
 
 int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key, uint32_t* ids,
                           uint32_t* vis_slots, bool colour, hipStream_t st) {
-    const int ql = a.quad_lists ? 1 : 0;
     if (a.N == 0) return 0;
     const int blocks = (a.N + 255) / 256;
-    if (!colour)
-        hipLaunchKernelGGL((preprocess_fwd_kernel<false, false>), dim3(blocks), dim3(256), 0, st, a, g, radii, depth_key, ids,
-                           vis_slots, ql);
-    else if (a.shs && a.K == SH_K)
-        hipLaunchKernelGGL((preprocess_fwd_kernel<true, true>), dim3(blocks), dim3(256), 256 * SH_ROW * sizeof(float), st, a, g,
-                           radii, depth_key, ids, vis_slots, ql);
-    else
-        hipLaunchKernelGGL((preprocess_fwd_kernel<false, true>), dim3(blocks), dim3(256), 0, st, a, g, radii, depth_key, ids,
-                           vis_slots, ql);
+#define VCR_PRE(STAGE, COLOUR, SMEM)                                                                                          \
+    do {                                                                                                                       \
+        if (a.quad_lists)                                                                                                      \
+            hipLaunchKernelGGL((preprocess_fwd_kernel<STAGE, COLOUR, true>), dim3(blocks), dim3(256), SMEM, st, a, g, radii,   \
+                               depth_key, ids, vis_slots);                                                                     \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((preprocess_fwd_kernel<STAGE, COLOUR, false>), dim3(blocks), dim3(256), SMEM, st, a, g, radii,  \
+                               depth_key, ids, vis_slots);                                                                     \
+    } while (0)
+    if (!colour) VCR_PRE(false, false, 0);
+    else if (a.shs && a.K == SH_K) VCR_PRE(true, true, 256 * SH_ROW * sizeof(float));
+    else VCR_PRE(false, true, 0);
+#undef VCR_PRE
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }

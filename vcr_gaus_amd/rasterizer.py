@@ -55,6 +55,15 @@ class _Allocator:
 
         self.cb = _lib.ALLOC_FN(_cb)
 
+    def close(self):
+        """Call when the library call has returned.  The callback closes over this object and this object holds the callback:
+        a reference cycle, which would keep every scratch tensor of the call (hundreds of MB per step) out of the caching
+        allocator until the interpreter's cyclic collector happens to run -- the next steps then find their block sizes taken
+        and fall through to `hipMalloc` (single steps of 5-10 ms in a run of 1.3 ms steps, round 4).  Scratch is only needed
+        until the call returns (later work on the same stream is ordered behind it), so it goes back right away."""
+        self.scratch.clear()
+        self.cb = None
+
 
 def _f32(t):
     return None if t is None else t.detach().contiguous().float()
@@ -203,8 +212,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         fo = _lib.VcrForwardOut(out=_ptr(out), radii=_ptr(radii), count=_ptr(count), score=_ptr(score))
         al = _Allocator(dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
-            _check(lib.vcr_rasterize_forward(a, fo, al.cb, None, stream))
+        try:
+            with torch.cuda.device(dev):
+                _check(lib.vcr_rasterize_forward(a, fo, al.cb, None, stream))
+        finally:
+            al.close()
         rec.R, rec.V, rec.N, rec.max_tile_len = int(fo.num_rendered), int(fo.num_visible), N, int(fo.max_tile_len)
         rec.emitted = int(fo.num_emitted)
         if fc == 0:
@@ -212,6 +224,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             ctx.num_rendered = int(fo.num_rendered)
             ctx.has = (means2D_densify is not None)
             ctx.num_dist = int(num_dist)
+            ctx.quad_lists = int(a.quad_lists)
             ctx.rgb_mode = opts.sh_grad == "rgb" and t["shs"] is not None
             ctx.save_for_backward(radii)
             ctx.mark_non_differentiable(radii)
@@ -241,6 +254,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                shs=_ptr(t["shs"]), shs_rest=_ptr(t["shs_rest"]), colors_precomp=_ptr(t["colors"]), normals_precomp=_ptr(t["normals"]),
                                semantics_precomp=_ptr(t["sem"]), opacities=_ptr(t["opac"]), scales=_ptr(t["scales"]),
                                rotations=_ptr(t["rots"]), cov3D_precomp=_ptr(t["cov"]), dirs=_ptr(t["dirs"]))
+        a.quad_lists = ctx.quad_lists                 # (the state buffers hold the lists in the form the forward chose)
         g = grad_out.contiguous().float()
 
         def new(*shape):
@@ -268,8 +282,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                                 dL_dcov3D=_ptr(d_cov))
         al = _Allocator(dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
-            _check(lib.vcr_rasterize_backward(a, io, al.cb, None, stream))
+        try:
+            with torch.cuda.device(dev):
+                _check(lib.vcr_rasterize_backward(a, io, al.cb, None, stream))
+        finally:
+            al.close()
         if rgb_mode:
             ctx.rec.drgb, ctx.rec.view_dirs = d_rgb, v_dirs
         return (d_means3D, d_means2D, d_dens, d_shs, d_col, d_nrm, d_sem, d_opac, d_sc, d_rot, d_cov, None, None, d_shr, None,
@@ -309,8 +326,11 @@ def visibility_batch(viewmatrices, projmatrices, campos, tanfovx, tanfovy, image
                                 opacities=_ptr(t[4]), scales=_ptr(t[5]), rotations=_ptr(t[6]), cov3D_precomp=_ptr(t[7]),
                                 count=count.data_ptr(), num_rendered=nr, num_visible=nv)
     al = _Allocator(dev)
-    with torch.cuda.device(dev):
-        _check(lib.vcr_visibility_batch(a, al.cb, None, torch.cuda.current_stream(dev).cuda_stream))
+    try:
+        with torch.cuda.device(dev):
+            _check(lib.vcr_visibility_batch(a, al.cb, None, torch.cuda.current_stream(dev).cuda_stream))
+    finally:
+        al.close()
     return count, list(nr)[:B], list(nv)[:B]
 
 

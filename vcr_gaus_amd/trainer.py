@@ -92,10 +92,14 @@ class Trainer:
         # over 5 M keys are long enough to matter: used from 3 M Gaussians on.
         # Binning granularity of the training render (`RasterOptions.quad_lists`), chosen per step from the previous render's
         # footprint statistic R / V (3-sigma tiles per visible Gaussian; a property of the scene that changes slowly): per
-        # 8x8 quad below `quad_lists_below` tiles, per 16x16 tile above.  Measured (profiles/r4_quad_ab.txt): R / V = 1.9
-        # (5 M Gaussians, 1600 x 1200) step 4.42 -> 4.19 ms, 2.6 (300 k, 800 x 600) 0.815 -> 0.795, 2.8 (metric) 1.366 -> 1.359,
-        # 9.8 (full-frame variant) 1.84 -> 2.39: the sort grows with the quads a footprint covers, the compositing gain does not.
-        self.quad_lists_below, self._tiles_per_visible = 4.0, None
+        # 8x8 quad below `quad_lists_below`, per 16x16 tile above.  Measured (profiles/r4_quad_threshold.txt, step in ms, per tile
+        # -> per quad): R / V = 1.92 (5 M Gaussians, 1600 x 1200) 4.32 -> 4.04, 2.24 (2 M, 1080p, semantics) 2.635 -> 2.571, 2.64
+        # (300 k, 800 x 600) 0.812 -> 0.788, 2.76 (metric scene) 1.354 -> 1.364, 10.5 (dense variant) 1.655 -> 2.10: the sort grows
+        # with the quads a footprint covers (1.37x ... 4x the entries), the compositing gain does not.
+        # The statistic is smoothed over ~10 renders and the switch has a hysteresis band (on below `quad_lists_below`, off above
+        # it + 0.2): the cameras of one scene differ by +-0.2, and a form that flips from view to view costs more (two sets of
+        # buffer sizes in the allocator, 0.7 % at the metric scene) than either form.
+        self.quad_lists_below, self._tiles_per_visible, self._quad_on = 2.7, None, False
         self.sort_stream, self.sort_stream_min_gaussians = None, 3_000_000
         if self.overlap_sh:
             # `side_cus` > 0: the side stream is confined to that many compute units (spread over the XCDs), so that the streaming
@@ -115,7 +119,8 @@ class Trainer:
         model's state (parameters + both Adam moments), at least `min_gb`, at most `max_fraction` of the free memory.
         (Measured, profiles/r4_diag_alloc.json: this removes the large `hipMalloc`s of a densification, 14 -> 0, but NOT the
         ~0.3-0.5 s the FIRST densification of a process takes -- that is the lazy loading of the code objects of the dozen
-        torch kernels the selection logic uses for the first time; the second event takes 4 ms either way.)
+        torch kernels the selection logic uses for the first time; the second event takes 4 ms either way -- and the steady
+        step is ~7 us slower out of the arena's addresses (1.354 against 1.347 ms).  Hence opt-in, not a default.)
         Returns the bytes reserved (0 on host tensors)."""
         m = self.model
         if not m._xyz.is_cuda:
@@ -536,7 +541,7 @@ class Trainer:
                              self._launch_pending_sh if (overlap and not fuse) else None,
                              self._pending_sh_update if fuse else None,
                              self.sort_stream if (overlap and m._xyz.shape[0] >= self.sort_stream_min_gaussians) else None,
-                             quad_lists=self._tiles_per_visible is not None and self._tiles_per_visible < self.quad_lists_below)
+                             quad_lists=self._quad_on)
         surgery = (it < cfg.optim.densify_until_iter and it > cfg.optim.densify_from_iter
                    and it % cfg.optim.densification_interval == 0) \
             or it % cfg.optim.opacity_reset_interval == 0 or it in cfg.optim.prune.iterations \
@@ -555,7 +560,13 @@ class Trainer:
             if self._pending_sh is not None:     # the render did not go through the two-stream path (e.g. no Gaussians)
                 self.join_side()
             rr = data["raster"]
-            self._tiles_per_visible = rr.R / rr.V if rr.V > 0 else None
+            if rr.V > 0:
+                t = rr.R / rr.V
+                self._tiles_per_visible = t if self._tiles_per_visible is None else 0.9 * self._tiles_per_visible + 0.1 * t
+                if self._tiles_per_visible < self.quad_lists_below:
+                    self._quad_on = True
+                elif self._tiles_per_visible > self.quad_lists_below + 0.2:
+                    self._quad_on = False
             fused_losses.DEFER_SCALE_GRAD = True    # l1_scale's gradient joins the activation backward's kernel (same graph)
             left, ok = None, False
             try:
@@ -672,13 +683,13 @@ def make_synthetic_trainer(raw, cams, device, world=1, rank=0, preset="tnt", gt_
 class BenchTrainer:
     """bench.py's step: exactly `Trainer.train_step` on a synthetic workload."""
 
-    def __init__(self, raw, cams, device, world=1, rank=0, preset="tnt", exchange="allreduce", side_cus=0):
+    def __init__(self, raw, cams, device, world=1, rank=0, preset="tnt", exchange="allreduce", side_cus=0, arena=False):
         self.tr = make_synthetic_trainer(raw, cams, device, world=world, rank=rank, preset=preset, exchange=exchange,
                                          side_cus=side_cus,
                                          optim={"densify_from_iter": 10 ** 9, "prune": {"iterations": []}})
         self.last_R = self.last_V = self.last_E = 0
         self._primed = False
-        self.arena_bytes = self.tr.reserve_arena()
+        self.arena_bytes = self.tr.reserve_arena() if arena else 0
 
     def prime(self, min_seconds=1.0):
         """Untimed set-up.  Runs ordinary training steps -- every camera at least once, so that every instance-count-
