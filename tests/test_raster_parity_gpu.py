@@ -37,6 +37,25 @@ def test_forward_matches_oracle(device, case):
     assert bad <= util.pixel_budget(ref), f"{bad} mismatching pixels"
 
 
+@pytest.mark.parametrize("view", [0, 1, 2, 3])
+def test_c1_all_four_cameras_forward_and_backward(device, view):
+    """BASELINE config c1 as it is written: 10 k Gaussians, FOUR synthetic 256 x 256 cameras (the parametrised cases above use
+    the first camera of a three-camera ring) -- forward and every gradient against the fp64 oracle for each of the four."""
+    n, W, H, f, sm, sem = CASES[2]
+    cam, inp, dirs = util.make_case(n, W, H, f, seed=0, scale_mult=sm, view=view, n_views=4)
+    bg = torch.tensor([0.1, 0.3, 0.7])
+    (ref, rradii, st), rl = util.oracle_forward(cam, inp, dirs, bg, dtype=torch.float64, requires_grad=True)
+    wgt = torch.randn(ref.shape, generator=torch.Generator().manual_seed(40 + view), dtype=torch.float64)
+    (ref * wgt).sum().backward()
+    (out, radii), hl = util.hip_forward(cam, inp, dirs, bg, device, requires_grad=True)
+    assert torch.equal(radii.cpu(), rradii) and (hl["record"].R, hl["record"].V) == (st["R"], st["V"])
+    assert util.bad_pixels(out, ref) <= util.pixel_budget(ref)
+    (out * wgt.float().to(device)).sum().backward()
+    clean, flipped = util.flip_clean_mask(cam, inp, out, ref, bg)
+    for k in ["means3D", "shs", "normals", "opac", "scales", "rots", "m2", "m2d"]:
+        util.assert_grads_close(hl[k].grad.cpu()[clean], rl[k].grad[clean], f"c1 view {view}:{k}")
+
+
 def test_forward_traditional_depth_no_normals(device):
     cam, inp, dirs = util.make_case(2000, 80, 48, 70.0, seed=5, scale_mult=8.0)
     bg = torch.zeros(3)

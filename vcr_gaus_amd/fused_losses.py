@@ -10,10 +10,6 @@ from . import _lib
 
 NAMES = ["l1", "ssim", "l1_scale", "mono_normal", "depth_normal", "consistent_normal"]
 _ONES = {}
-_SUMS = {}               # device -> [reduction buffer, in use]: kept alive across steps (vcr_finalize_losses re-zeroes its slots)
-# True (set by the trainer around loss + backward): the l1_scale gradient does not travel through autograd to `_scaling` but is
-# handed to the activation backward of the same graph (gaussian_model.PENDING_SCALE_GRAD), which adds it in its kernel.
-DEFER_SCALE_GRAD = False
 
 
 def unit_seed(device):
@@ -41,12 +37,15 @@ class _FusedLosses(torch.autograd.Function):
         # ONE buffer for all reductions.  It is reused
         # from step to step: the finalize kernel leaves the slots zeroed again (a fresh zero-filled one only if the previous
         # forward's backward has not run yet).
-        ent = _SUMS.get(dev)
+        cache = sink.sums if (sink is not None and sink.sums is not None) else None      # the caller's cache, or none
+        ent = cache.get(dev) if cache is not None else None
         if ent is not None and not ent[1] and ent[0].numel() == n2 + n3 + n9:
             sums = ent[0]
         else:
             sums = torch.zeros(n2 + n3 + n9, dtype=torch.float64, device=dev)
-            ent = _SUMS[dev] = [sums, False]
+            ent = [sums, False]
+            if cache is not None:
+                cache[dev] = ent
         ent[1] = torch.is_grad_enabled() and ent[0] is sums
         ctx.sums_entry = ent if ent[0] is sums else None
         res8 = torch.empty(8, dtype=torch.float32, device=dev)      # (fresh per call: the returned loss values must not alias the reused buffer)
@@ -75,12 +74,11 @@ class _FusedLosses(torch.autograd.Function):
         except Exception:
             # a kernel failed between the first accumulation and the finalize that re-zeroes the slots: the reused buffer may
             # hold partial sums -- drop it, the next forward starts from a fresh zero-filled one
-            if _SUMS.get(dev) is ent:
-                del _SUMS[dev]
+            if cache is not None and cache.get(dev) is ent:
+                del cache[dev]
             raise
         ctx.save_for_backward(o, gi, part, sums, sr, xz, gn, m, wvec, trans, scale)
         ctx.meta = (H, W, C, tuple(intr), tuple(active), float(exp_t), float(depth_max), n2, n3, nbits)
-        ctx.scale_key = id(scaling_raw) if DEFER_SCALE_GRAD else None
         ctx.sink = sink
         ctx.mark_non_differentiable(res)
         return total, res
@@ -124,9 +122,8 @@ class _FusedLosses(torch.autograd.Function):
             d_sc = torch.empty_like(sr)
             _lib.check(lib.vcr_scale_reg_backward(sr.shape[0], sr.data_ptr(), xz.data_ptr(), trans.data_ptr(), scale.data_ptr(),
                                                   s_scale, gp(2), d_sc.data_ptr(), st))
-        if d_sc is not None and ctx.scale_key is not None:
-            from .gaussian_model import PENDING_SCALE_GRAD
-            PENDING_SCALE_GRAD[ctx.scale_key] = d_sc        # added by the activation backward of the same graph
+        if d_sc is not None and ctx.sink is not None and ctx.sink.defer_scale_grad:
+            ctx.sink.scale_grad = d_sc                      # added by the activation backward of the same graph (runs later)
             d_sc = None
         return (dout, d_sc) + (None,) * 12
 

@@ -24,22 +24,22 @@ from .general_utils import build_rotation, get_expon_lr_func, inverse_sigmoid
 GROUPS = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "obj_dc"]
 
 
-# Gradients that reach `_scaling` on a second path (the l1_scale regulariser of the fused loss node) can be handed to the
-# activation backward here instead of through autograd: the kernel adds them to its own result, which spares the engine's
-# add kernel for two incoming gradients of one leaf.  {id(raw scaling parameter): tensor [N,3]}; see fused_losses.py.
-PENDING_SCALE_GRAD = {}
-
-
 class GeometrySink:
-    """Hand-over between one iteration's backward and `FusedAdam.geometry_step` (the fused static tail of the step): when a
-    model carries an ARMED sink, the backward of its fused activation does not launch its kernel but leaves the upstream
-    gradients (w.r.t. activated scales / rotations / opacities / camera normals) and what it saved here, and the fused loss
-    node leaves the factors of the l1_scale gradient instead of forming it.  One object per iteration, owned by the
-    trainer (`model._geom_sink`); nothing process-global."""
-    __slots__ = ("armed", "grads", "saved", "scale_reg")
+    """Everything ONE training iteration hands from node to node outside autograd's tensors -- one object per iteration,
+    owned by the trainer (`model._geom_sink` while the step runs); nothing process-global.
+      * `defer_scale_grad` / `scale_grad`: the l1_scale regulariser of the fused loss node reaches `_scaling` on a second path;
+        instead of a second incoming gradient on that leaf (an add kernel of the engine) the loss node leaves it here and the
+        backward of the fused activation -- same graph, runs later -- adds it inside its own kernel;
+      * `armed` + `grads` / `saved` / `scale_reg`: the fused static tail.  With an ARMED sink the activation backward does not
+        launch its kernel but leaves the upstream gradients (w.r.t. activated scales / rotations / opacities / camera normals)
+        and what it saved, and the loss node leaves the FACTORS of the l1_scale gradient; `FusedAdam.geometry_step` consumes both;
+      * `sums`: the trainer's cache of the loss node's fp64 reduction buffer, {device: [buffer, in use]} (re-zeroed by the
+        finalize kernel, so it can be re-used from step to step instead of being allocated and cleared)."""
+    __slots__ = ("armed", "grads", "saved", "scale_reg", "defer_scale_grad", "scale_grad", "sums")
 
-    def __init__(self):
-        self.armed, self.grads, self.saved, self.scale_reg = True, None, None, None
+    def __init__(self, armed=True, defer_scale_grad=False, sums=None):
+        self.armed, self.grads, self.saved, self.scale_reg = armed, None, None, None
+        self.defer_scale_grad, self.scale_grad, self.sums = defer_scale_grad, None, sums
 
 
 class _FusedActivate(torch.autograd.Function):
@@ -62,7 +62,6 @@ class _FusedActivate(torch.autograd.Function):
         ctx.save_for_backward(sr, rr, orr, Rw, aux)
         ctx.want_normal = want_normal
         ctx.sink = sink
-        ctx.scale_key = id(scaling)
         if want_normal:
             return scales, rots, opac, nrm
         return scales, rots, opac
@@ -82,9 +81,11 @@ class _FusedActivate(torch.autograd.Function):
             ctx.sink.grads, ctx.sink.saved = keep, (sr, rr, orr, Rw, aux)
             return (None,) * 8
         ds, dr, do = torch.empty_like(sr), torch.empty_like(rr), torch.empty_like(orr)
-        extra = PENDING_SCALE_GRAD.pop(ctx.scale_key, None)
-        if extra is not None and tuple(extra.shape) != tuple(sr.shape):      # (a stale entry under a recycled id())
-            raise RuntimeError(f"pending l1_scale gradient has shape {tuple(extra.shape)}, the scaling parameter {tuple(sr.shape)}")
+        extra = None
+        if ctx.sink is not None and ctx.sink.scale_grad is not None:          # l1_scale gradient of this iteration's loss node
+            extra, ctx.sink.scale_grad = ctx.sink.scale_grad, None
+            if tuple(extra.shape) != tuple(sr.shape):
+                raise RuntimeError(f"pending l1_scale gradient has shape {tuple(extra.shape)}, the scaling parameter {tuple(sr.shape)}")
         _lib.check(lib.vcr_activate_backward(N, sr.data_ptr(), rr.data_ptr(), orr.data_ptr(), Rw.data_ptr(), aux.data_ptr(),
                                              *[None if t is None else t.data_ptr() for t in keep],
                                              None if extra is None else extra.data_ptr(),

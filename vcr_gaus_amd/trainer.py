@@ -52,6 +52,7 @@ class Trainer:
         self.dirs = dirs
         self.weights = {k: v for k, v in cfg.optim.loss_weight.items() if v}
         self.losses = {}
+        self._loss_sums = {}                  # reduction-buffer cache of the fused loss node (GeometrySink.sums)
         self.current_iteration = 0
         self.background = torch.tensor([1.0, 1.0, 1.0] if cfg.model.white_background else [0.0, 0.0, 0.0], device=device)
         self.rng = random.Random(seed)            # identical on every rank
@@ -549,11 +550,14 @@ class Trainer:
         from . import fused_losses, gaussian_model
         # the fused static tail needs every gradient path into scaling / rotation / opacity to pass through the fused
         # activation node (the fused loss node guarantees that), un-reduced gradients (one process) and unchanged rows
-        sink = None
-        if self.fuse_geometry and fused and not surgery and self.world == 1 and not getattr(self, "force_collectives", False) \
-                and m._xyz.is_cuda and m._xyz.shape[0] > 0 and not cfg.pipline.compute_cov3D_python:
-            sink = gaussian_model.GeometrySink()
+        armed = bool(self.fuse_geometry and fused and not surgery and self.world == 1
+                     and not getattr(self, "force_collectives", False) and m._xyz.is_cuda and m._xyz.shape[0] > 0
+                     and not cfg.pipline.compute_cov3D_python)
+        # the iteration's side channel (see GeometrySink): armed = the one-kernel static tail; the l1_scale gradient joins the
+        # activation backward's kernel; the loss node's reduction buffer is this trainer's
+        sink = gaussian_model.GeometrySink(armed=armed, defer_scale_grad=True, sums=self._loss_sums)
         m._geom_sink = sink
+        ok, left = False, None
         try:
             data = render(cam, m, cfg, bg, dirs=self.dirs, lazy_mask=True, geometry=not fused, raster_options=opts,
                           dist_channels="distortion" in extra or "depth_var" in extra)
@@ -567,24 +571,18 @@ class Trainer:
                     self._quad_on = True
                 elif self._tiles_per_visible > self.quad_lists_below + 0.2:
                     self._quad_on = False
-            fused_losses.DEFER_SCALE_GRAD = True    # l1_scale's gradient joins the activation backward's kernel (same graph)
-            left, ok = None, False
-            try:
-                loss = self._compute_loss(data, cam)
-                loss.backward(fused_losses.unit_seed(loss.device))
-                ok = True
-            finally:
-                fused_losses.DEFER_SCALE_GRAD = False
-                left = gaussian_model.PENDING_SCALE_GRAD.pop(id(m._scaling), None)     # never survives the step, also on errors
+            loss = self._compute_loss(data, cam)
+            loss.backward(fused_losses.unit_seed(loss.device))
+            ok = True
         finally:
             m._geom_sink = None
-            if sink is not None:
-                sink.armed = False
-        if sink is not None and sink.grads is None and sink.scale_reg is not None:
+            sink.armed = False
+            left, sink.scale_grad = sink.scale_grad, None        # (never survives the step, also on errors)
+        if sink.grads is None and sink.scale_reg is not None:
             left = fused_losses.scale_grad_from_factors(sink.scale_reg)        # (no activation backward ran: ordinary path)
         if ok and left is not None:                 # (no activation backward consumed it: add it the ordinary way)
             m._scaling.grad = left if m._scaling.grad is None else m._scaling.grad + left
-        geom = sink is not None and sink.grads is not None
+        geom = armed and sink.grads is not None
         with torch.no_grad():
             self._exchange_grads(overlap, surgery, data["raster"])
             if geom:
