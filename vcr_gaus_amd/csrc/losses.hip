@@ -300,15 +300,15 @@ __global__ void __launch_bounds__(256) normal_losses_fwd_kernel(int H, int W, In
     block_accumulate<9>(sums9 + 9, v);
 }
 
-// totals + the three losses (0 when a loss has no selected pixel / is inactive)
-__global__ void finalize_normal_losses_kernel(double* __restrict__ sums9, float* __restrict__ res3) {
+// totals + the three losses (0 when a loss has no selected pixel / is inactive).  9 waves, one per sum, lane l folds slots
+// l, l + 64, ... in the fixed order of finalize_losses_kernel (bit-identical results); the one-wave form took 22 us.
+__global__ void __launch_bounds__(576) finalize_normal_losses_kernel(double* __restrict__ sums9, float* __restrict__ res3) {
     __shared__ double s_t[9];
-    for (int k = 0; k < 9; ++k) {
-        double t = 0.0;
-        for (int s = threadIdx.x; s < VCR_NSLOT; s += 64) t += sums9[9 + (size_t)s * 9 + k];
-        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-        if (threadIdx.x == 0) { s_t[k] = t; sums9[k] = t; }
-    }
+    const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+    double t = 0.0;
+    for (int s = lane; s < VCR_NSLOT; s += 64) t += sums9[9 + (size_t)s * 9 + k];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) { s_t[k] = t; sums9[k] = t; }
     __syncthreads();
     if (threadIdx.x < 3) {
         const int l = threadIdx.x;
@@ -630,7 +630,7 @@ extern "C" int vcr_normal_losses_forward(int H, int W, float fx, float fy, float
     hipLaunchKernelGGL(normal_losses_fwd_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, (hipStream_t)stream, H, W,
                        make_intr(k4), depth, normal_planes, gt, mask, depth_max, exp_t, active, sums9);
     if (!(sums_prezeroed & 2))
-        hipLaunchKernelGGL(finalize_normal_losses_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums9, res3);
+        hipLaunchKernelGGL(finalize_normal_losses_kernel, dim3(1), dim3(576), 0, (hipStream_t)stream, sums9, res3);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }
