@@ -434,7 +434,8 @@ def test_fused_loss_node_matches_modular_losses(device):
 
 
 @pytest.mark.parametrize("n,bits,iota", [(1, 32, True), (777, 32, True), (8193, 9, False), (300001, 32, True),
-                                         (1000000, 13, False), (70000, 17, False)])
+                                         (1000000, 13, False), (70000, 17, False), (1000000, 27, True), (300001, 18, False),
+                                         (5000000, 27, True)])
 def test_radix_sort_pairs_is_stable_and_matches_torch(device, n, bits, iota):
     """vcr_sort_pairs_u32 (the rasterizer's depth / tile sort): stable, exact, ragged sizes, partial last pass."""
     import ctypes as C

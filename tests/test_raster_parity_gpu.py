@@ -444,3 +444,38 @@ def test_quad_granular_binning_gives_the_same_render_and_gradients(device, case)
     (c0, _), _ = util.hip_forward(cam, inp, dirs, bg, device, f_count=3, use_normals=False)
     (c1, _), _ = util.hip_forward(cam, inp, dirs, bg, device, f_count=3, use_normals=False, options=RasterOptions(quad_lists=True))
     assert torch.equal(c0, c1)
+
+
+def test_depth_order_beyond_the_27_bit_key_range(device):
+    """The depth sort runs on 27-bit keys, bits(z) - bits(0.2): exact below z = 13 107.2.  Gaussians beyond that raise the
+    projection's `far` flag and the host appends one more pass over the upper key bits -- the order must stay the exact depth
+    order.  Scene: overlapping translucent Gaussians along the optical axis at depths from 3 to 60 000 (footprints scaled with
+    depth so that they all cover the same pixels); a wrong order among the far ones changes the blended colour."""
+    import math
+    from vcr_gaus_amd import synthetic
+    from vcr_gaus_amd.graphics_utils import get_all_px_dir
+    from vcr_gaus_amd.sh_utils import RGB2SH
+    W, H, focal = 64, 48, 60.0
+    cam = synthetic.make_cameras(1, W, H, focal)[0]
+    g = torch.Generator().manual_seed(3)
+    depths = torch.tensor([3.0, 9000.0, 20000.0, 13000.0, 13200.0, 60000.0, 14000.0, 5.0, 30000.0, 13107.0, 13108.0, 40000.0])
+    n = depths.shape[0]
+    fwd = torch.tensor(cam.R[:, 2], dtype=torch.float32)                    # camera z axis in world coordinates
+    centre = cam.camera_center.float()
+    lateral = 0.02 * torch.randn(n, 3, generator=g) * depths[:, None] * 0.2
+    means = centre[None] + depths[:, None] * fwd[None] + lateral
+    scales = (0.15 * depths)[:, None].repeat(1, 3) * (0.8 + 0.4 * torch.rand(n, 3, generator=g))
+    rots = torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=1)
+    shs = torch.cat([RGB2SH(torch.rand(n, 1, 3, generator=g)), torch.zeros(n, 15, 3)], 1)
+    inp = dict(means3D=means, shs=shs, normals=None, opac=torch.full((n, 1), 0.35), scales=scales, rots=rots, sem=None)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    (ref, rradii, st), _ = util.oracle_forward(cam, inp, None, bg, dtype=torch.float64, use_normals=False)
+    (out, radii), hl = util.hip_forward(cam, inp, None, bg, device, use_normals=False)
+    assert int((rradii > 0).sum()) == n and torch.equal(radii.cpu(), rradii)
+    assert float(ref[7].max()) > 0.9                                          # they really are stacked
+    assert util.bad_pixels(out, ref) <= util.pixel_budget(ref)
+    # and the nearer-than-13 107 scene takes the three-pass path with the same result as before
+    inp2 = dict(inp, means3D=centre[None] + (depths[:, None] / 10.0) * fwd[None] + lateral / 10.0, scales=scales / 10.0)
+    (ref2, _, _), _ = util.oracle_forward(cam, inp2, None, bg, dtype=torch.float64, use_normals=False)
+    (out2, _), _ = util.hip_forward(cam, inp2, None, bg, device, use_normals=False)
+    assert util.bad_pixels(out2, ref2) <= util.pixel_budget(ref2)

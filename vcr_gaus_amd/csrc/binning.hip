@@ -179,11 +179,23 @@ size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits) {
 // look-back status words of the emission kernel (+ its ticket word at the end), zeroed by the caller
 size_t vcr_duplicate_status_bytes(int N) { return vcr_align(sizeof(unsigned long long) * (size_t)((N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS) + 2)); }
 
-// depth order of the N Gaussians (ties by index).  (pair_a, pair_b): N 8-byte records each; `totals`: VCR_SORT_TOTALS_WORDS words.
+// depth order of the N Gaussians (ties by index): three stable passes over the 27 low bits of the depth keys (see vcr_common.h).
+// (pair_a, pair_b): N 8-byte records each -- pair_a holds the (key, id) records in that order afterwards; `totals`:
+// VCR_SORT_TOTALS_WORDS words.
 int vcr_depth_sort(int N, const uint32_t* depth_key, uint2* pair_a, uint2* pair_b, uint32_t* ids_sorted, uint32_t* totals,
                    void* temp, hipStream_t st) {
-    return vcr_sort_pairs(N, depth_key, nullptr, nullptr, pair_a, pair_b, nullptr, ids_sorted, 0, 32, (uint32_t*)temp, totals, st,
-                          nullptr);
+    if (vcr_sort_passes(VCR_DEPTH_KEY_BITS) != 3)                 // (VCR_SORT_DIGIT_BITS=8: four passes, the third writes pair_a)
+        return vcr_sort_pairs(N, depth_key, nullptr, nullptr, pair_a, pair_b, nullptr, ids_sorted, 0, 32, (uint32_t*)temp, totals, st,
+                              nullptr);
+    return vcr_sort_pairs(N, depth_key, nullptr, nullptr, pair_a, pair_b, nullptr, ids_sorted, 0, VCR_DEPTH_KEY_BITS, (uint32_t*)temp,
+                          totals, st, nullptr, pair_a);
+}
+
+// the pass over the upper key bits, when the projection reported a visible Gaussian beyond z = 13 107
+int vcr_depth_sort_far(int N, uint2* pair_a, uint32_t* ids_sorted, uint32_t* totals, void* temp, hipStream_t st) {
+    if (vcr_sort_passes(VCR_DEPTH_KEY_BITS) != 3) return 0;       // (the four-pass plan already covered all 32 bits)
+    return vcr_sort_pairs(N, nullptr, nullptr, pair_a, nullptr, nullptr, nullptr, ids_sorted, VCR_DEPTH_KEY_BITS, 32, (uint32_t*)temp,
+                          totals, st, nullptr);
 }
 
 // inst: the emitted (tile, Gaussian) records; (pair_a, pair_b): buffers of the sort's intermediate passes (pair_b may be

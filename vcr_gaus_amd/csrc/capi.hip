@@ -46,18 +46,18 @@ struct StageTimer {
 
 // device counters of one forward call, zeroed by ONE memset together with the emission kernel's look-back words:
 // visible-count slots and tile-instance-count slots
-#define VCR_CTR_WORDS (3 * VCR_VIS_SLOTS)
+#define VCR_CTR_WORDS (3 * VCR_VIS_SLOTS + 64)          // + the `far` flag word (vcr_common.h)
 struct Readback { uint32_t V[VCR_VIS_SLOTS]; uint32_t R[VCR_VIS_SLOTS]; };
 // what the host polls: totals + a sequence number published by the device AFTER the totals (system-scope fence).
 // R: tile instances of the 3-sigma rectangles (what the reference counts), E: instances really emitted (exact rejection)
-struct Published { unsigned long long R, E; uint32_t V; volatile uint32_t seq; };
+struct Published { unsigned long long R, E; uint32_t V; uint32_t far; volatile uint32_t seq; };
 
 Published* pinned_published() {
     static thread_local Published* p = nullptr;
     if (!p) {
         // coherent (uncached on the device side) so that the host sees the device's system-scope stores while the stream runs
         if (hipHostMalloc((void**)&p, sizeof(Published), hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) { p = nullptr; return nullptr; }
-        p->R = 0; p->E = 0; p->V = 0; p->seq = 0;
+        p->R = 0; p->E = 0; p->V = 0; p->far = 0; p->seq = 0;
     }
     return p;
 }
@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(256) publish_counts_kernel(const uint32_t* __r
         host->R = s_r[0] + s_r[1] + s_r[2] + s_r[3];
         host->E = s_e[0] + s_e[1] + s_e[2] + s_e[3];
         host->V = s_v[0] + s_v[1] + s_v[2] + s_v[3];
+        host->far = slots[VCR_FAR_FLAG_WORD];
         __threadfence_system();
         host->seq = seq;
     }
@@ -332,6 +333,12 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         }
         R = (int64_t)pub->R;
         const int64_t E = (int64_t)pub->E;                  // what the emission kernel will write: sizes everything below
+        if (pub->far) {          // a visible Gaussian beyond the 27-bit key range: one more pass over the upper key bits, behind the sort
+            hipStream_t ds = split_sort ? (hipStream_t)a.sort_stream : st;
+            StageTimer tm(ST_DEPTHSORT, ds);
+            if (vcr_depth_sort_far(N, pair_a, ids_sorted, totals_depth, temp1, ds)) return fail_joined();
+            if (split_sort) VCR_HIP_CHECK_JOIN(hipEventRecord(colour_event(3), ds));
+        }
         out->num_visible = (int32_t)pub->V;
         out->num_emitted = E;
         if (R >= (1ll << 32)) { vcr_set_error("more than 2^32 tile instances"); return fail_joined(); }
@@ -529,6 +536,9 @@ extern "C" int vcr_visibility_batch(const VcrVisibilityBatch* vb, vcr_alloc_fn a
             Published* pub = pool->pub + (c - c0);
             if (wait_published(pub, v.seq, cs)) { rc = 1; break; }
             const int64_t R = (int64_t)pub->R, E = (int64_t)pub->E;
+            if (pub->far && vcr_depth_sort_far(N, (uint2*)(v.s1 + 2 * nb), (uint32_t*)(v.s1 + nb),
+                                               (uint32_t*)(v.s1 + 7 * nb + ctr_bytes + status_bytes),
+                                               v.s1 + 7 * nb + ctr_bytes + status_bytes + tot_bytes, cs)) { rc = 1; break; }
             if (vb->num_rendered) vb->num_rendered[c] = R;
             if (vb->num_visible) vb->num_visible[c] = (int32_t)pub->V;
             if (R >= (1ll << 32)) { vcr_set_error("more than 2^32 tile instances"); rc = 1; break; }

@@ -233,8 +233,9 @@ __device__ __forceinline__ void stage_sh_in(const VcrRasterArgs& a, int base, in
 template <bool STAGE, bool COLOUR, bool QL>
 __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const GeomState& g, int32_t* __restrict__ radii,
                                                    uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
-                                                   const float* s_sh, int i, uint32_t& emit) {
+                                                   const float* s_sh, int i, uint32_t& emit, bool& far) {
     emit = 0;
+    far = false;
     if (i >= a.N) return 0;
     radii[i] = 0;
     g.tiles[i] = 0;
@@ -356,7 +357,8 @@ __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const
         g.rect[i] = make_uint2((uint32_t)xmin | ((uint32_t)ymin << 10), (uint32_t)rw | ((uint32_t)rh << 16));
     }
     radii[i] = (int32_t)rad;
-    if (depth_key) depth_key[i] = __float_as_uint(pr.t[2]);
+    if (depth_key) depth_key[i] = vcr_depth_key(pr.t[2]);
+    far = (vcr_depth_key(pr.t[2]) >> VCR_DEPTH_KEY_BITS) != 0;
     return (uint32_t)ntiles;
 }
 
@@ -373,7 +375,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
         __syncthreads();
     }
     uint32_t em;
-    const uint32_t nt = preprocess_one<STAGE, COLOUR, QL>(a, g, radii, depth_key, ids, s_sh, blockIdx.x * 256 + threadIdx.x, em);
+    bool far;
+    const uint32_t nt = preprocess_one<STAGE, COLOUR, QL>(a, g, radii, depth_key, ids, s_sh, blockIdx.x * 256 + threadIdx.x, em, far);
+    if (vis_slots && __builtin_amdgcn_ballot_w64(far) != 0 && (threadIdx.x & 63) == 0)      // (a visible depth beyond 27 key bits: rare)
+        atomicOr(vis_slots + VCR_FAR_FLAG_WORD, 1u);
     if (vis_slots) {
         __shared__ uint32_t s_cnt[3][4];
         uint32_t c = nt != 0 ? 1u : 0u, r = nt;
@@ -918,7 +923,7 @@ __global__ void __launch_bounds__(256) depth_key_kernel(VcrRasterArgs a, uint32_
     const float p[3] = {a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2]};
     Proj pr;
     project(a, cam, p, pr);
-    depth_key[i] = pr.t[2] > VCR_NEAR ? __float_as_uint(pr.t[2]) : 0xFFFFFFFFu;
+    depth_key[i] = pr.t[2] > VCR_NEAR ? vcr_depth_key(pr.t[2]) : 0xFFFFFFFFu;
 }
 
 int vcr_launch_depth_keys(const VcrRasterArgs& a, uint32_t* depth_key, hipStream_t st) {
@@ -949,13 +954,16 @@ int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, u
     return 0;
 }
 
-// Workgroups of a side-stream kernel (persistent grid).  One per CU up to 3 M Gaussians: there the sort chain on the main
-// stream is the critical path and must find room beside it; two per CU above, where the 1.15 kB per
-// Gaussian of the SH update make the side stream itself the critical path (5 M: 4.9 vs 4.7 ms/step).  VCR_SIDE_GRID overrides.
+// Workgroups of a side-stream kernel (persistent grid).  The side stream (1.15 kB per Gaussian of SH update) is the critical path of
+// the front end at every size (profiles/r4_step_timeline.txt: it ends 20 us after the sort chain beside it), so it gets 1.5
+// workgroups per CU up to 3 M Gaussians (round 4, profiles/r4_side_grid.txt: 256 / 320 / 384 / 512 / 768 workgroups -> step 1.355 /
+// 1.374 / 1.345 / 1.356 / 1.367 ms at 1 M, 2.54 / 2.50 / 2.45 / 2.53 / 2.54 at 2 M: more of them slow the chain down by more
+// than the update gains) and four per CU above (5 M, profiles/r4_side_grid_c5.txt: 512 / 640 / 768 / 1024 -> 3.79 / 3.92 / 3.78 / 3.735
+// ms/step).  VCR_SIDE_GRID overrides.
 int vcr_side_grid(int N) {
     static const int g = [] { const char* e = getenv("VCR_SIDE_GRID"); return e ? atoi(e) : 0; }();
     if (g > 0) return g;
-    return N > 3000000 ? 512 : 256;
+    return N > 3000000 ? 1024 : 384;
 }
 
 int vcr_launch_sh_update_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st) {

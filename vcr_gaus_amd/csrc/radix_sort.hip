@@ -129,8 +129,10 @@ __device__ __forceinline__ uint32_t block_exclusive(uint32_t sum, uint32_t* wsum
 }
 
 // IN: 0 = separate key / value arrays, 1 = key array + values 0..n-1, 2 = 8-byte (key, value) records in `keys_in`
-// OUT_AOS: 8-byte records into `keys_out`; else separate arrays (keys_out may be NULL: values only)
-template <int BITS, int IN, bool OUT_AOS>
+// OUT: 0 = separate arrays (keys_out may be NULL: values only), 1 = 8-byte records into `keys_out`, 2 = 8-byte records
+// into `keys_out` AND the values into `vals_out` (the depth sort's last pass: ids for the emission, records in case a pass
+// over the upper key bits has to follow)
+template <int BITS, int IN, int OUT>
 __global__ void __launch_bounds__(RsShape<BITS>::THREADS) rs_downsweep_kernel(int64_t n_host, const uint32_t* __restrict__ n_dev,
                                                                  const uint32_t* __restrict__ keys_in,
                                                                  const uint32_t* __restrict__ vals_in, int shift, int nbits,
@@ -245,8 +247,9 @@ __global__ void __launch_bounds__(RsShape<BITS>::THREADS) rs_downsweep_kernel(in
             if (j < nvalid) {
                 const uint2 kv = items[j - (int)lo];
                 const uint32_t dst = (uint32_t)j + gbase[(kv.x >> shift) & mask];
-                if (OUT_AOS) reinterpret_cast<uint2*>(keys_out)[dst] = kv;
-                else {
+                if (OUT >= 1) reinterpret_cast<uint2*>(keys_out)[dst] = kv;
+                if (OUT == 2) vals_out[dst] = kv.y;
+                if (OUT == 0) {
                     if (keys_out) keys_out[dst] = kv.x;
                     vals_out[dst] = kv.y;
                 }
@@ -351,7 +354,7 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2* __
     }
 }
 
-template <int BITS, int IN, bool OUT_AOS>
+template <int BITS, int IN, int OUT>
 void rs_pass(int64_t n, const uint32_t* n_dev, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int shift,
              int nbits, uint32_t* hist, uint32_t* totals, hipStream_t st) {
     constexpr int RADIX = 1 << BITS;
@@ -359,16 +362,17 @@ void rs_pass(int64_t n, const uint32_t* n_dev, const uint32_t* kin, const uint32
     constexpr int DT = RsShape<BITS>::THREADS;
     hipLaunchKernelGGL((rs_upsweep_kernel<BITS, IN == 2>), dim3(nblk), dim3(1024), 0, st, n, n_dev, kin, shift, (1u << nbits) - 1u, hist);
     hipLaunchKernelGGL((rs_scan_kernel<BITS>), dim3(RADIX / 16), dim3(1024), 0, st, n, n_dev, hist, totals);
-    hipLaunchKernelGGL((rs_downsweep_kernel<BITS, IN, OUT_AOS>), dim3(nblk), dim3(DT), 0, st, n, n_dev, kin, vin, shift, nbits, hist,
+    hipLaunchKernelGGL((rs_downsweep_kernel<BITS, IN, OUT>), dim3(nblk), dim3(DT), 0, st, n, n_dev, kin, vin, shift, nbits, hist,
                        totals, kout, vout);
 }
 
 template <int BITS>
-void rs_pass_any(int in, bool out_aos, int64_t n, const uint32_t* n_dev, const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
+void rs_pass_any(int in, int out, int64_t n, const uint32_t* n_dev, const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
                  uint32_t* vout, int shift, int nbits, uint32_t* hist, uint32_t* totals, hipStream_t st) {
 #define VCR_RS(IN, OUT) rs_pass<BITS, IN, OUT>(n, n_dev, kin, vin, kout, vout, shift, nbits, hist, totals, st)
-    if (out_aos) { if (in == 0) VCR_RS(0, true); else if (in == 1) VCR_RS(1, true); else VCR_RS(2, true); }
-    else { if (in == 0) VCR_RS(0, false); else if (in == 1) VCR_RS(1, false); else VCR_RS(2, false); }
+    if (out == 1) { if (in == 0) VCR_RS(0, 1); else if (in == 1) VCR_RS(1, 1); else VCR_RS(2, 1); }
+    else if (out == 2) { if (in == 0) VCR_RS(0, 2); else if (in == 1) VCR_RS(1, 2); else VCR_RS(2, 2); }
+    else { if (in == 0) VCR_RS(0, 0); else if (in == 1) VCR_RS(1, 0); else VCR_RS(2, 0); }
 #undef VCR_RS
 }
 
@@ -380,14 +384,15 @@ size_t vcr_sort_scratch_bytes(int64_t n) {
     return vcr_align(sizeof(uint32_t) * (size_t)(2048 * (nblk > 0 ? nblk : 1)));
 }
 
-// Pass plan for `bits` key bits -> number of passes, bits of every pass in `out`.  Digits of at most 8 bits by default
-// (VCR_SORT_DIGIT_BITS=11 selects 11-bit digits: 3 instead of 4 passes over the 32-bit depth keys).  Measured at 1 M keys
+// Pass plan for `bits` key bits -> number of passes, bits of every pass in `out`.  Digits of at most 9 bits by default (round 4:
+// the depth keys are 27 bits wide, vcr_depth_sort -> 3 x 9; 16-17 tile / cell bits -> 2 passes instead of 3; every plan of at
+// most 8 bits per pass is unchanged).  VCR_SORT_DIGIT_BITS = 8 ... 11 overrides (11: 3 passes over 32-bit keys).  Measured at 1 M keys
 // (profiles/r3_sort_ab.txt): 3 x 11 bits 88 us stand-alone / 146 us inside the step against 4 x 8 bits 79 / 137 us -- with
 // 2048 digits and 4096 items per workgroup a run of equal digits is 2 items long, so the scatter of the first passes
 // degenerates to single stores, and the scan kernel works on 8 KB rows; the wide digits lose more per pass than the
 // saved pass returns.
 static int rs_plan(int bits, int out[4]) {
-    static const int max_digit = [] { const char* e = getenv("VCR_SORT_DIGIT_BITS"); const int v = e ? atoi(e) : 8; return v < 8 ? 8 : (v > 11 ? 11 : v); }();
+    static const int max_digit = [] { const char* e = getenv("VCR_SORT_DIGIT_BITS"); const int v = e ? atoi(e) : 9; return v < 8 ? 8 : (v > 11 ? 11 : v); }();
     int passes = bits <= 8 ? 1 : (bits <= 16 ? 2 : (bits <= 2 * max_digit ? 2 : (bits <= 3 * max_digit ? 3 : 4)));
     for (int p = 0, left = bits; p < passes; ++p) {
         out[p] = (left + (passes - p) - 1) / (passes - p);
@@ -406,7 +411,7 @@ int vcr_sort_passes(int bits) { int b[4]; return rs_plan(bits, b); }
 // the) element count; `n_dev`, when not NULL, points to the actual count in device memory (<= n).
 int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, const uint2* pairs_in, uint2* pair_a, uint2* pair_b,
                    uint32_t* keys_out, uint32_t* vals_out, int begin_bit, int end_bit, uint32_t* hist, uint32_t* totals,
-                   hipStream_t st, const uint32_t* n_dev) {
+                   hipStream_t st, const uint32_t* n_dev, uint2* pairs_out) {
     if (n <= 0) return 0;
     int bits[4];
     const int passes = rs_plan(end_bit - begin_bit, bits);
@@ -416,10 +421,15 @@ int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, 
     int shift = begin_bit;
     for (int p = 0; p < passes; ++p) {
         const bool last = p == passes - 1;
-        uint32_t* kout = last ? keys_out : reinterpret_cast<uint32_t*>((p & 1) ? pair_b : pair_a);
+        // (pairs_out: the last pass leaves its (key, value) records there as well as the values in vals_out; it must not be the
+        //  buffer that pass reads)
+        uint32_t* kout = last ? (pairs_out ? reinterpret_cast<uint32_t*>(pairs_out) : keys_out)
+                              : reinterpret_cast<uint32_t*>((p & 1) ? pair_b : pair_a);
         uint32_t* vout = last ? vals_out : nullptr;
-        if (bits[p] <= 8) rs_pass_any<8>(in, !last, n, n_dev, kin, vin, kout, vout, shift, bits[p], hist, totals, st);
-        else rs_pass_any<11>(in, !last, n, n_dev, kin, vin, kout, vout, shift, bits[p], hist, totals, st);
+        const int out = last ? (pairs_out ? 2 : 0) : 1;
+        if (bits[p] <= 8) rs_pass_any<8>(in, out, n, n_dev, kin, vin, kout, vout, shift, bits[p], hist, totals, st);
+        else if (bits[p] <= 9) rs_pass_any<9>(in, out, n, n_dev, kin, vin, kout, vout, shift, bits[p], hist, totals, st);
+        else rs_pass_any<11>(in, out, n, n_dev, kin, vin, kout, vout, shift, bits[p], hist, totals, st);
         shift += bits[p];
         kin = kout; vin = nullptr; in = 2;
     }

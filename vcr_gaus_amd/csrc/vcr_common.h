@@ -161,6 +161,7 @@ void vcr_set_error(const char* fmt, ...);
 
 // ---- stage launchers (defined in the .hip files) ----------------------------------------------
 #define VCR_VIS_SLOTS 1024                    // counter slots for visible Gaussians / 3-sigma tile instances / emitted tile instances
+#define VCR_FAR_FLAG_WORD (3 * VCR_VIS_SLOTS)  // behind the three slot arrays: != 0 when a visible depth key needs more than 27 bits
 int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key,
                           uint32_t* ids, uint32_t* vis_slots, bool colour, hipStream_t st);
 int vcr_launch_depth_keys(const VcrRasterArgs& a, uint32_t* depth_key, hipStream_t st);
@@ -172,8 +173,16 @@ int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const in
                                    hipStream_t st);
 size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits);
 size_t vcr_duplicate_status_bytes(int N);
+// Depth keys (round 4): key = bits(z) - bits(VCR_NEAR) of the view-space depth z > VCR_NEAR -- monotone in z, and below
+// z = 13 107.2 it fits VCR_DEPTH_KEY_BITS = 27 bits, so the depth order takes THREE 9-bit passes instead of four 8-bit ones
+// (culled Gaussians carry 0xFFFFFFFF: last).  A visible Gaussian beyond that depth raises the `far` flag of the projection's
+// counters; the host sees it with R / E / V and appends vcr_depth_sort_far -- one more stable pass over the upper five bits of
+// the (key, id) records the third pass left in pair_a -- so the order is exact at every depth.
+#define VCR_DEPTH_KEY_BITS 27
+__host__ __device__ inline uint32_t vcr_depth_key(float z) { return __float_as_uint(z) - 0x3E4CCCCDu; }      // bits(0.2f)
 int vcr_depth_sort(int N, const uint32_t* depth_key, uint2* pair_a, uint2* pair_b, uint32_t* ids_sorted, uint32_t* totals,
                    void* temp, hipStream_t st);
+int vcr_depth_sort_far(int N, uint2* pair_a, uint32_t* ids_sorted, uint32_t* totals, void* temp, hipStream_t st);
 int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const uint32_t* ids_sorted,
                            unsigned long long* status, int64_t R /* emitted instances */, int tile_bits, uint2* inst, uint2* pair_a,
                            uint2* pair_b, uint32_t* keys_b, uint32_t* point_list, uint2* ranges, uint32_t* tile_order,
@@ -184,7 +193,7 @@ size_t vcr_sort_scratch_bytes(int64_t n);
 int vcr_sort_passes(int bits);
 int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, const uint2* pairs_in, uint2* pair_a, uint2* pair_b,
                    uint32_t* keys_out, uint32_t* vals_out, int begin_bit, int end_bit, uint32_t* hist, uint32_t* totals,
-                   hipStream_t st, const uint32_t* n_dev = nullptr);
+                   hipStream_t st, const uint32_t* n_dev = nullptr, uint2* pairs_out = nullptr);
 // gxc: 8x8 cells per row when `ranges` is per cell (quad-list mode), 0 when it is per tile
 int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, uint32_t* meta, int64_t instances, bool lpt, bool snake,
                           hipStream_t st, int gxc = 0);
