@@ -983,3 +983,14 @@ def test_batched_visibility_equals_the_per_camera_passes(device):
                                  mv(inp["scales"]), mv(inp["rots"]))
     assert float((cnt.cpu() != rc).double().mean()) < 1e-3
     assert int(c3.max()) == 1 and torch.equal(c3 > 0, visi_acc_render(cam, m, pipe, tr.background)["countlist"] > 0)
+    # the trainer's own cameras (`sample_cameras`: rows of one stacked tensor, handed to the library without re-stacking)
+    from vcr_gaus_amd.camera_utils import sample_cameras
+    vc = sample_cameras(12, m.trans, m.scale, device=device, generator=torch.Generator().manual_seed(5), size=96, fov=1.2)
+    assert vc[0]._stack[0].is_cuda and vc[3].world_view_transform.data_ptr() == vc[0]._stack[0][3].data_ptr()
+    want = torch.zeros_like(ref)
+    for c in vc:
+        want += visi_acc_render(c, m, pipe, tr.background)["countlist"]
+    assert int((want > 0).sum()) > 100
+    assert torch.equal(visibility_counts(vc, m, pipe), want)
+    assert torch.equal(visibility_counts(vc[::-1], m, pipe), want)            # (not the stack's order: re-stacked)
+    assert torch.equal(tr.visibility_mask(vc), (want > 0) & m.get_inside_gaus_normalized()[0])

@@ -248,6 +248,15 @@ def test_virtual_visibility_cameras_look_at_box_floor():
     cams = sample_cameras(3, trans, scale, device="cpu", generator=torch.Generator().manual_seed(1))
     assert cams[0].image_width == 1500 and abs(cams[0].FoVx - 2.5) < 1e-9
     assert torch.allclose(cams[0].camera_center, -(cams[0].world_view_transform[:3, :3] @ cams[0].world_view_transform[3, :3]), atol=1e-4)
+    # the stacked construction `sample_cameras` uses is the per-camera constructor (`scene/cameras.py:90-113`) to the bit
+    from vcr_gaus_amd.cameras import SampleCam
+    one = [SampleCam(T[i], 1500, 1500, 2.5, 2.5, device="cpu") for i in range(50)]
+    many = SampleCam.batch(T, 1500, 1500, 2.5, 2.5, device="cpu")
+    for a, b in zip(one, many):
+        for f in ("world_view_transform", "projection_matrix", "full_proj_transform", "camera_center", "R_w2c"):
+            assert torch.equal(getattr(a, f), getattr(b, f)) and getattr(b, f).is_contiguous(), f
+        assert (a.R == b.R).all() and (a.image_width, a.image_height, a.FoVx, a.znear, a.zfar) == (b.image_width, b.image_height, b.FoVx, b.znear, b.zfar)
+    assert SampleCam.batch(T[:0], 8, 8, 1.0, 1.0, device="cpu") == []
 
 
 def test_lazy_dictionaries_and_scoped_modes():

@@ -181,4 +181,4 @@ def sample_cameras(n, trans, scale, up=False, around=True, look_mode="target", s
     """`Trainer.sample_cameras` (`trainer.py:621-634`)."""
     w2cs = bb_camera(n, trans.detach().float().cpu(), scale.detach().float().cpu(), up=up, around=around,
                      look_mode=look_mode, sample_mode=sample_mode, bidirect=bidirect, generator=generator)
-    return [SampleCam(w2cs[i], size, size, fov, fov, device=device) for i in range(w2cs.shape[0])]
+    return SampleCam.batch(w2cs, size, size, fov, fov, device=device)

@@ -150,6 +150,42 @@ int validate(const VcrRasterArgs* a) {
     return 0;
 }
 
+// Diagnostics (VCR_HOST_TRACE=1): wall-clock of the HOST inside vcr_rasterize_forward, split at the points named below; the mean
+// of every 200 calls goes to stderr.  "spin" near zero means the host arrives late at the hand-over (host-bound), a large value
+// means it waits for the device there.
+struct HostTrace {
+    enum { ENTRY = 0, PROJECTION, SIDE, PUBLISH, DEPTH_SORT, SPIN, ALLOC, BINNING, COMPOSITE, NSEG };
+    bool on = getenv("VCR_HOST_TRACE") != nullptr;
+    double acc[NSEG] = {};
+    double between = 0;                                 // from the return of one call to the entry of the next
+    int calls = 0;
+    std::chrono::steady_clock::time_point t, t_exit;
+    bool have_exit = false;
+    void begin() {
+        if (!on) return;
+        t = std::chrono::steady_clock::now();
+        if (have_exit) between += std::chrono::duration<double, std::micro>(t - t_exit).count();
+    }
+    void mark(int k) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        acc[k] += std::chrono::duration<double, std::micro>(n - t).count();
+        t = n;
+    }
+    void end() {
+        if (!on) return;
+        t_exit = std::chrono::steady_clock::now(); have_exit = true;
+        if (++calls == 200) {
+            static const char* names[NSEG] = {"entry+alloc", "projection", "side-stream", "publish", "depth-sort", "spin", "alloc", "binning", "composite"};
+            fprintf(stderr, "[vcr host trace, us per forward]");
+            for (int k = 0; k < NSEG; ++k) { fprintf(stderr, " %s %.1f", names[k], acc[k] / calls); acc[k] = 0; }
+            fprintf(stderr, " | between-calls %.1f\n", between / calls);
+            between = 0; calls = 0;
+        }
+    }
+};
+thread_local HostTrace g_ht;
+
 int tile_bits_for(int T) {
     int b = 1;
     while ((1 << b) < T) ++b;
@@ -197,6 +233,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
     if ((a.f_count == 1 || a.f_count == 2) && !out->score) { vcr_set_error("score buffer is NULL"); return 1; }
     out->num_rendered = 0; out->num_visible = 0; out->max_tile_len = -1; out->num_emitted = -1;
     out->geom = out->binning = out->image = nullptr;
+    g_ht.begin();
 
     void* geom_p = alloc(user, VCR_BUF_GEOM, GeomState::bytes(N > 0 ? N : 1, a.S));
     void* img_p = alloc(user, VCR_BUF_IMAGE, ImageState::bytes(P));
@@ -246,6 +283,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
                 return join_streams();                                                                  \
             }                                                                                           \
         } while (0)
+        g_ht.mark(HostTrace::ENTRY);
         // optional sort stream: depth keys + depth sort of the N Gaussians start now, beside the projection
         const bool split_sort = a.sort_stream && a.sort_stream != stream;
         if (split_sort) {
@@ -278,6 +316,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             if (vcr_launch_preprocess(a, g, out->radii, split_sort ? nullptr : depth_key, ids, vis_counter, colour_here, st))
                 return join_streams();
         }
+        g_ht.mark(HostTrace::PROJECTION);
         if (split_colour) {
             hipEvent_t e_geo = colour_event(0), e_col = colour_event(1);
             if (!e_geo || !e_col) { vcr_set_error("hipEventCreate for the colour stream failed"); return join_streams(); }
@@ -295,6 +334,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             }
             if (rc) return join_streams();
         }
+        g_ht.mark(HostTrace::SIDE);
         // R and V go back to the host now; the depth sort and the offsets scan do not need them and keep the GPU busy
         // while the host wakes up, sizes the instance buffers and enqueues the rest
         Readback* rb = pinned_readback();
@@ -306,6 +346,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(256), 0, st, vis_counter, pub, seq);
         VCR_HIP_CHECK_JOIN(hipGetLastError());
         VCR_HIP_CHECK_JOIN(hipEventRecord(ev, st));
+        g_ht.mark(HostTrace::PUBLISH);
         if (!split_sort) {
             StageTimer tm(ST_DEPTHSORT, st);
             if (vcr_depth_sort(N, depth_key, pair_a, pair_b, ids_sorted, totals_depth, temp1, st)) return join_streams();
@@ -313,6 +354,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         // From here on the colour stream may already be running work that consumed the caller's pending SH update: every
         // error return below first joins it (the caller's retry / error handling must not see an un-joined stream).
         auto fail_joined = join_streams;
+        g_ht.mark(HostTrace::DEPTH_SORT);
         {   // spin on the published sequence number for at most ~2 ms of wall time, then sleep in the event (which also
             // surfaces a device fault or a failed launch as an error instead of a hang)
             const auto t_spin = std::chrono::steady_clock::now();
@@ -331,6 +373,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             if (pub->seq != seq) { vcr_set_error("device did not publish the instance count"); return fail_joined(); }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
         }
+        g_ht.mark(HostTrace::SPIN);
         R = (int64_t)pub->R;
         const int64_t E = (int64_t)pub->E;                  // what the emission kernel will write: sizes everything below
         if (pub->far) {          // a visible Gaussian beyond the 27-bit key range: one more pass over the upper key bits, behind the sort
@@ -354,6 +397,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         char* s2 = (char*)alloc(user, VCR_BUF_SCRATCH, (third ? 7 : 5) * rbts + tmp2);
         if (!s2) { vcr_set_error("allocator returned NULL"); return fail_joined(); }
         if (split_sort) VCR_HIP_CHECK_JOIN(hipStreamWaitEvent(st, colour_event(3), 0));  // the depth order is needed from here on
+        g_ht.mark(HostTrace::ALLOC);
         {
             StageTimer tm(ST_BINNING, st);
             if (vcr_duplicate_and_sort(a, g, out->radii, ids_sorted, dup_status, E, tbits, (uint2*)s2, (uint2*)(s2 + 2 * rbts),
@@ -361,6 +405,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
                                        b.point_list, b.ranges, b.tile_order, b.meta, T, totals_tile, s2 + (third ? 7 : 5) * rbts, tmp2, st))
                 return fail_joined();
         }
+        g_ht.mark(HostTrace::BINNING);
         out->num_rendered = R;
         if (a.debug) {                       // diagnostics only: longest per-tile list (one extra sync)
             VCR_HIP_CHECK_JOIN(hipMemsetAsync(vis_counter, 0, sizeof(uint32_t), st));
@@ -374,6 +419,8 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             StageTimer tm(ST_COMPOSITE_FWD, st);
             if (vcr_launch_composite_forward(a, g, b, im, *out, st)) return fail_joined();
         }
+        g_ht.mark(HostTrace::COMPOSITE);
+        g_ht.end();
 #undef VCR_HIP_CHECK_JOIN
     } else {
         void* bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(0, T));

@@ -199,9 +199,14 @@ def visibility_counts(cameras, pc, pipe, scaling_modifier=1.0, flags_only=False,
     for cam in cameras:
         groups.setdefault((int(cam.image_height), int(cam.image_width)), []).append(cam)
     for (h, w), cams in groups.items():
-        vm = torch.stack([c.world_view_transform.to(dev) for c in cams])
-        pm = torch.stack([c.full_proj_transform.to(dev) for c in cams])
-        cc = torch.stack([c.camera_center.to(dev) for c in cams])
+        st = getattr(cams[0], "_stack", None)
+        if st is not None and st[0].device == dev and st[0].shape[0] == len(cams) and \
+                all(getattr(c, "_stack", None) is st and c._stack_index == i for i, c in enumerate(cams)):
+            vm, pm, cc = st[0], st[1], st[2]                  # (`SampleCam.batch`: the cameras ARE the rows of one stack)
+        else:
+            vm = torch.stack([c.world_view_transform.to(dev) for c in cams])
+            pm = torch.stack([c.full_proj_transform.to(dev) for c in cams])
+            cc = torch.stack([c.camera_center.to(dev) for c in cams])
         visibility_batch(vm, pm, cc, [math.tan(c.FoVx * 0.5) for c in cams], [math.tan(c.FoVy * 0.5) for c in cams], h, w,
                          pc.get_xyz, opacity, scales, rotations, cov, scaling_modifier, flags_only, count, inflight)
     return count
