@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 16
+#define VCR_ABI_VERSION 17
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -261,6 +261,18 @@ typedef struct VcrGeometryStep {
     float *next_scales, *next_rots, *next_opac, *next_normals; uint8_t* next_aux;
 } VcrGeometryStep;
 int vcr_geometry_step(const VcrGeometryStep* args, void* stream);
+/* vcr_rasterize_backward with the static tail of the iteration INSIDE its last kernel: the projection backward hands its
+ * per-Gaussian gradients (w.r.t. means3D, the densification screen gradient, activated scales / rotations / opacities,
+ * camera-space normals) to vcr_geometry_step's arithmetic in registers -- they are never written, and io->dL_dmeans3D /
+ * dL_dmeans2D / dL_dmeans2D_densify / dL_dopacities / dL_dscales / dL_drotations / dL_dnormals are not dereferenced
+ * (dL_dmeans2D_densify non-NULL only selects the densify-variant of the screen gradient for the statistics, like the
+ * `means2D_densify.grad` of trainer.py:345).  What still has a consumer is written as before: dL_drgb + view_dirs (the SH
+ * update), dL_dcolors, dL_dsemantics.  `tail`: as for vcr_geometry_step with d_means3D / d_scales / d_rots / d_opac /
+ * d_normals / grad2d / radii all NULL (statistics run when accum is non-NULL; radii are the render's own).  Requires the
+ * scale / rotation form of the covariance and no materialised SH gradient (dL_dshs NULL).  Same per-Gaussian functions as the
+ * two separate kernels (preprocess.hip / model_math.h). */
+int vcr_rasterize_backward_tail(const VcrRasterArgs* args, VcrBackwardIO* io, const VcrGeometryStep* tail,
+                                vcr_alloc_fn alloc, void* user, void* stream);
 
 /* add_densification_stats + max_radii2D update (scene/gaussian_model.py:669-671, trainer.py:345) */
 int vcr_densify_stats(int N, const float* grad2d /*[N,3]*/, const int32_t* radii, float* accum, float* denom,

@@ -331,6 +331,8 @@ def test_two_stream_sh_path_trains_like_the_serial_loop(device):
             from vcr_gaus_amd.rasterizer import RasterOptions
             if tr.current_iteration in (3, 4):
                 keep = {g["name"]: g["params"][0].grad for g in tr.model.optimizer.param_groups}
+                for g in tr.model.optimizer.param_groups:
+                    g["params"][0].grad = None           # (autograd accumulates IN PLACE into a gradient that is already there)
                 tr.join_side()
                 with torch.enable_grad():
                     pkg = render(cams[2], tr.model, tr.cfg, tr.background, dirs=tr.dirs, raster_options=RasterOptions("rgb"))

@@ -16,7 +16,7 @@ c_int_p = C.POINTER(C.c_int32)
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 BUF_GEOM, BUF_BINNING, BUF_IMAGE, BUF_SCRATCH = 0, 1, 2, 3
-ABI_VERSION = 16         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
+ABI_VERSION = 17         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
 
 
 class VcrShUpdate(C.Structure):
@@ -116,6 +116,8 @@ SYMBOLS = {
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_int64), c_float_p, C.c_float, C.c_float,
                                 C.c_float, C.c_int, C.c_float, C.c_void_p]),
     "vcr_geometry_step": (C.c_int, [C.POINTER(VcrGeometryStep), C.c_void_p]),
+    "vcr_rasterize_backward_tail": (C.c_int, [C.POINTER(VcrRasterArgs), C.POINTER(VcrBackwardIO), C.POINTER(VcrGeometryStep), ALLOC_FN,
+                                              C.c_void_p, C.c_void_p]),
     "vcr_densify_stats": (C.c_int, [C.c_int] + [C.c_void_p] * 6),
     "vcr_depth_to_normal_forward": (C.c_int, [C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 3),
     "vcr_depth_to_normal_backward": (C.c_int, [C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p] * 5),

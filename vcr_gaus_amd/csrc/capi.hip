@@ -622,8 +622,10 @@ extern "C" int vcr_visibility_batch(const VcrVisibilityBatch* vb, vcr_alloc_fn a
     return rc;
 }
 
-extern "C" int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* io, vcr_alloc_fn alloc, void* user,
-                                      void* stream) {
+namespace {
+// vcr_rasterize_backward (tail == nullptr) and vcr_rasterize_backward_tail
+int backward_impl(const VcrRasterArgs* args, VcrBackwardIO* io, const VcrGeometryStep* tail, vcr_alloc_fn alloc, void* user,
+                  void* stream) {
     if (validate(args)) return 1;
     if (!io || !alloc) { vcr_set_error("io/alloc is NULL"); return 1; }
     const VcrRasterArgs& a = *args;
@@ -631,12 +633,33 @@ extern "C" int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* 
     hipStream_t st = (hipStream_t)stream;
     const int N = a.N, P = a.H * a.W;
     if (N == 0) return 0;
-    if (!io->dL_dout || !io->geom || !io->binning || !io->image || !io->radii || !io->dL_dmeans3D || !io->dL_dmeans2D ||
-        !io->dL_dopacities) { vcr_set_error("backward: required pointer is NULL"); return 1; }
+    if (!io->dL_dout || !io->geom || !io->binning || !io->image || !io->radii) { vcr_set_error("backward: required pointer is NULL"); return 1; }
+    if (!tail && (!io->dL_dmeans3D || !io->dL_dmeans2D || !io->dL_dopacities)) { vcr_set_error("backward: required pointer is NULL"); return 1; }
     if (a.shs && !io->dL_dshs && !io->dL_drgb) { vcr_set_error("backward: dL_dshs and dL_drgb are both NULL"); return 1; }
     if (a.shs_rest && io->dL_dshs && !io->dL_dshs_rest) { vcr_set_error("backward: dL_dshs_rest is NULL"); return 1; }
-    if (a.scales && (!io->dL_dscales || !io->dL_drotations)) { vcr_set_error("backward: dL_dscales/rotations NULL"); return 1; }
+    if (!tail && a.scales && (!io->dL_dscales || !io->dL_drotations)) { vcr_set_error("backward: dL_dscales/rotations NULL"); return 1; }
     if (a.cov3D_precomp && !io->dL_dcov3D) { vcr_set_error("backward: dL_dcov3D is NULL"); return 1; }
+    if (tail) {
+        const VcrGeometryStep& t = *tail;
+        if (t.N != N) { vcr_set_error("backward tail: N = %d, the render had %d Gaussians", t.N, N); return 1; }
+        if (!a.scales || a.cov3D_precomp) { vcr_set_error("backward tail: needs the scale / rotation form of the covariance"); return 1; }
+        if (a.shs && io->dL_dshs) { vcr_set_error("backward tail: SH gradients only as dL_drgb"); return 1; }
+        if (a.S > 0 && !io->dL_dsemantics) { vcr_set_error("backward tail: dL_dsemantics is NULL"); return 1; }
+        if (t.d_means3D || t.d_scales || t.d_rots || t.d_opac || t.d_normals || t.grad2d || t.radii) {
+            vcr_set_error("backward tail: the upstream gradient pointers of VcrGeometryStep must be NULL (they stay in registers)"); return 1;
+        }
+        if (!t.xyz || !t.scaling || !t.rotation || !t.opacity || !t.m_xyz || !t.v_xyz || !t.m_scaling || !t.v_scaling ||
+            !t.m_rotation || !t.v_rotation || !t.m_opacity || !t.v_opacity || t.step_xyz < 1 || t.step_scaling < 1 ||
+            t.step_rotation < 1 || t.step_opacity < 1 || (a.normals_precomp && (!t.aux || !t.Rw2c)) ||
+            (t.scale_reg_sums && (!t.scale_reg_gout || !t.trans || !t.scale)) ||
+            (t.accum && (!t.denom || !t.max_radii)) ||
+            (t.next_scales && (!t.next_rots || !t.next_opac || (t.next_normals && (!t.next_campos || !t.next_Rw2c || !t.next_aux))))) {
+            vcr_set_error("backward tail: inconsistent VcrGeometryStep"); return 1;
+        }
+        if ((((uintptr_t)t.rotation) | ((uintptr_t)t.m_rotation) | ((uintptr_t)t.v_rotation) | ((uintptr_t)t.next_rots)) & 15) {
+            vcr_set_error("backward tail: quaternion arrays must be 16-byte aligned"); return 1;
+        }
+    }
     const int gx = (a.W + VCR_TILE - 1) / VCR_TILE, gy = (a.H + VCR_TILE - 1) / VCR_TILE;
     GeomState g = GeomState::view(const_cast<void*>(io->geom), N, a.S);
     BinState b = BinState::view(const_cast<void*>(io->binning), gx * gy);
@@ -658,7 +681,20 @@ extern "C" int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* 
     if (a.colors_precomp == nullptr) io2.dL_dcolors = nullptr;
     if (a.shs == nullptr) io2.dL_drgb = nullptr;
     StageTimer tm(ST_PREPROCESS_BWD, st);
+    if (tail) return vcr_launch_preprocess_backward_tail(a, g, io->radii, sgrad, sgrad_sem, io2, *tail, st);
     return vcr_launch_preprocess_backward(a, g, io->radii, sgrad, sgrad_sem, io2, st);
+}
+}  // namespace
+
+extern "C" int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* io, vcr_alloc_fn alloc, void* user,
+                                      void* stream) {
+    return backward_impl(args, io, nullptr, alloc, user, stream);
+}
+
+extern "C" int vcr_rasterize_backward_tail(const VcrRasterArgs* args, VcrBackwardIO* io, const VcrGeometryStep* tail,
+                                           vcr_alloc_fn alloc, void* user, void* stream) {
+    if (!tail) { vcr_set_error("vcr_rasterize_backward_tail: tail is NULL"); return 1; }
+    return backward_impl(args, io, tail, alloc, user, stream);
 }
 
 // A HIP stream whose kernels may only run on the compute units whose bits are set in `mask` (`nwords` 32-bit words, bit i of the

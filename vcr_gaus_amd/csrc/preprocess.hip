@@ -4,6 +4,7 @@
 // Reference call sites: gaussian_renderer/__init__.py:61-120 (inputs), :83-87 (colour rule),
 // tools/general_utils.py:98-130 (covariance from scale/rotation), scene/cameras.py:68-70 (matrices).
 #include "vcr_common.h"
+#include "model_math.h"
 #include "composite_math.h"
 #include <stdlib.h>
 
@@ -428,10 +429,15 @@ __global__ void __launch_bounds__(256) colour_fwd_kernel(VcrRasterArgs a, GeomSt
     }
 }
 
-template <bool STAGE>
+// TAIL: the static tail of the training iteration (model_math.h: activation adjoint, l1_scale gradient, densification
+// statistics, Adam on xyz / scaling / rotation / opacity, activation for the next camera) follows in the SAME thread, on the
+// gradients still in registers: dL/d(means3D, means2D, scales, rotations, opacities, normals) are never written.
+struct TailArgs { VcrGeometryStep t; GeomBias gb; };
+
+template <bool STAGE, bool TAIL>
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, GeomState g, const int32_t* __restrict__ radii,
                                                              const GradRec* __restrict__ sgrad,
-                                                             const float* __restrict__ sgrad_sem, VcrBackwardIO io) {
+                                                             const float* __restrict__ sgrad_sem, VcrBackwardIO io, TailArgs ta) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int blk_base = blockIdx.x * 256, blk_cnt = min(256, a.N - blk_base);
@@ -591,6 +597,24 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
     }
     if (!live) return;
 
+    if (TAIL) {
+        if (io.dL_dcolors) { io.dL_dcolors[i3] = dcol[0]; io.dL_dcolors[i3 + 1] = dcol[1]; io.dL_dcolors[i3 + 2] = dcol[2]; }
+        if (io.dL_drgb) { io.dL_drgb[i3] = dcol[0]; io.dL_drgb[i3 + 1] = dcol[1]; io.dL_drgb[i3 + 2] = dcol[2]; }
+        if (io.dL_dsemantics)
+            for (int k = 0; k < a.S; ++k) io.dL_dsemantics[(size_t)i * a.S + k] = vis ? sgrad_sem[(size_t)i * a.S + k] : 0.f;
+        TailGrads tg;
+        tg.dp[0] = dp[0]; tg.dp[1] = dp[1]; tg.dp[2] = dp[2];
+        tg.ds[0] = dsc[0]; tg.ds[1] = dsc[1]; tg.ds[2] = dsc[2];
+        tg.dn[0] = dn[0]; tg.dn[1] = dn[1]; tg.dn[2] = dn[2];
+        const bool dens = io.dL_dmeans2D_densify != nullptr;         // (which screen gradient feeds the statistics: a flag here)
+        tg.dm2[0] = dens ? dm2a[0] : dm2[0]; tg.dm2[1] = dens ? dm2a[1] : dm2[1];
+        tg.dq = make_float4(dq[0], dq[1], dq[2], dq[3]);
+        tg.dop = dop;
+        tg.radius = radii[i];
+        tg.has_n = a.normals_precomp != nullptr;
+        geometry_step_one<true>(ta.t, ta.gb, i, tg);
+        return;
+    }
     io.dL_dmeans3D[i3] = dp[0]; io.dL_dmeans3D[i3 + 1] = dp[1]; io.dL_dmeans3D[i3 + 2] = dp[2];
     io.dL_dmeans2D[i3] = dm2[0]; io.dL_dmeans2D[i3 + 1] = dm2[1]; io.dL_dmeans2D[i3 + 2] = 0.f;
     if (io.dL_dmeans2D_densify) {
@@ -995,11 +1019,27 @@ int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const in
                                    const float* sgrad_sem, VcrBackwardIO& io, hipStream_t st) {
     if (a.N == 0) return 0;
     const int blocks = (a.N + 255) / 256;
+    const TailArgs none = {};
     if (a.shs && a.K == SH_K && io.dL_dshs)        // (LDS rows only for the coalesced write-back of a materialised SH gradient)
-        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(blocks), dim3(256), 256 * SH_ROW * sizeof(float), st, a, g, radii,
-                           sgrad, sgrad_sem, io);
+        hipLaunchKernelGGL((preprocess_bwd_kernel<true, false>), dim3(blocks), dim3(256), 256 * SH_ROW * sizeof(float), st, a, g,
+                           radii, sgrad, sgrad_sem, io, none);
     else
-        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(blocks), dim3(256), 0, st, a, g, radii, sgrad, sgrad_sem, io);
+        hipLaunchKernelGGL((preprocess_bwd_kernel<false, false>), dim3(blocks), dim3(256), 0, st, a, g, radii, sgrad, sgrad_sem, io,
+                           none);
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// projection backward + the static tail of the iteration in one kernel (vcr_rasterize_backward_tail).  `io.dL_dmeans2D_densify`
+// non-NULL only says WHICH screen gradient the densification statistics take (nothing is written through it).
+int vcr_launch_preprocess_backward_tail(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const GradRec* sgrad,
+                                        const float* sgrad_sem, VcrBackwardIO& io, const VcrGeometryStep& t, hipStream_t st) {
+    if (a.N == 0) return 0;
+    TailArgs ta;
+    ta.t = t;
+    vcr_geometry_bias(t, ta.gb);
+    hipLaunchKernelGGL((preprocess_bwd_kernel<false, true>), dim3((a.N + 255) / 256), dim3(256), 0, st, a, g, radii, sgrad,
+                       sgrad_sem, io, ta);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;
 }

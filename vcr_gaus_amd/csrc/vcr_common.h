@@ -171,6 +171,8 @@ int vcr_side_grid(int N);     // workgroups of a side-stream kernel (one per CU 
 int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const int32_t* radii,
                                    const GradRec* sgrad, const float* sgrad_sem, VcrBackwardIO& io,
                                    hipStream_t st);
+int vcr_launch_preprocess_backward_tail(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const GradRec* sgrad,
+                                        const float* sgrad_sem, VcrBackwardIO& io, const VcrGeometryStep& t, hipStream_t st);
 size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits);
 size_t vcr_duplicate_status_bytes(int N);
 // Depth keys (round 4): key = bits(z) - bits(VCR_NEAR) of the view-space depth z > VCR_NEAR -- monotone in z, and below

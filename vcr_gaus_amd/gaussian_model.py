@@ -33,13 +33,18 @@ class GeometrySink:
       * `armed` + `grads` / `saved` / `scale_reg`: the fused static tail.  With an ARMED sink the activation backward does not
         launch its kernel but leaves the upstream gradients (w.r.t. activated scales / rotations / opacities / camera normals)
         and what it saved, and the loss node leaves the FACTORS of the l1_scale gradient; `FusedAdam.geometry_step` consumes both;
+      * `tail` / `done`: the same tail INSIDE the rasterizer's backward (`vcr_rasterize_backward_tail`): `tail()` -> the
+        argument block + commit of `FusedAdam.prepare_geometry_step(in_registers=True)`; the rasterizer node (which holds this
+        sink through its `RasterOptions`) calls it, sets `done`, and returns no gradient for means / scales / rotations /
+        opacities / normals, so the activation backward has nothing left to do;
       * `sums`: the trainer's cache of the loss node's fp64 reduction buffer, {device: [buffer, in use]} (re-zeroed by the
         finalize kernel, so it can be re-used from step to step instead of being allocated and cleared)."""
-    __slots__ = ("armed", "grads", "saved", "scale_reg", "defer_scale_grad", "scale_grad", "sums")
+    __slots__ = ("armed", "grads", "saved", "scale_reg", "defer_scale_grad", "scale_grad", "sums", "tail", "done")
 
-    def __init__(self, armed=True, defer_scale_grad=False, sums=None):
+    def __init__(self, armed=True, defer_scale_grad=False, sums=None, tail=None):
         self.armed, self.grads, self.saved, self.scale_reg = armed, None, None, None
         self.defer_scale_grad, self.scale_grad, self.sums = defer_scale_grad, None, sums
+        self.tail, self.done = tail, False
 
 
 class _FusedActivate(torch.autograd.Function):
@@ -60,8 +65,11 @@ class _FusedActivate(torch.autograd.Function):
                                             cp.data_ptr(), Rw.data_ptr(), scales.data_ptr(), rots.data_ptr(), opac.data_ptr(),
                                             nrm.data_ptr() if want_normal else None, aux.data_ptr(), _lib.stream_of(xyz)))
         ctx.save_for_backward(sr, rr, orr, Rw, aux)
+        ctx.set_materialize_grads(False)
         ctx.want_normal = want_normal
         ctx.sink = sink
+        if sink is not None and sink.armed:
+            sink.saved = (sr, rr, orr, Rw, aux)          # (the tail may run before this node's backward: inside the rasterizer's)
         if want_normal:
             return scales, rots, opac, nrm
         return scales, rots, opac
@@ -69,12 +77,10 @@ class _FusedActivate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_scales, d_rots, d_opac, d_nrm=None):
         lib = _lib.load()
+        if d_scales is None and d_rots is None and d_opac is None and d_nrm is None:
+            return (None,) * 8                   # (e.g. the rasterizer's backward has applied the static tail itself)
         sr, rr, orr, Rw, aux = ctx.saved_tensors
         N = sr.shape[0]
-
-        def p(t):
-            return None if t is None else t.contiguous().float().data_ptr()
-
         keep = [None if t is None else t.contiguous().float() for t in (d_scales, d_rots, d_opac, d_nrm)]
         if ctx.sink is not None and ctx.sink.armed and ctx.sink.grads is None:
             # fused static tail: `FusedAdam.geometry_step` applies this adjoint together with Adam in one pass
@@ -154,30 +160,32 @@ class FusedAdam:
                 g["params"][0].grad = None
 
     @torch.no_grad()
-    def geometry_step(self, model, sink, grad2d=None, radii=None):
-        """The static tail of an iteration in ONE launch (`vcr_geometry_step`): adjoint of the fused activation + l1_scale
-        gradient (from `sink`) -> densification statistics (`grad2d` [N,3] = `means2D_densify.grad`, `radii`; None = skip)
-        -> Adam on xyz / scaling / rotation / opacity.  Same arithmetic as activate-backward + `add_densification_stats` +
-        `step()` on those groups; their `.grad` must not be set elsewhere (`_xyz.grad` is consumed and cleared here)."""
-        lib = _lib.load()
+    def prepare_geometry_step(self, model, sink, grad2d=None, radii=None, in_registers=False, stats=False):
+        """-> (VcrGeometryStep, commit): the argument block of the static tail and the host bookkeeping to run once the launch
+        has been accepted (Adam step counters, `_xyz.grad`).  `in_registers`: the form `vcr_rasterize_backward_tail` takes
+        -- no upstream gradient arrays (they stay inside the projection-backward kernel), `stats` instead of `grad2d` /
+        `radii`, and xyz always stepped."""
         groups = {g["name"]: g for g in self.param_groups}
-        keep, (sr, rr, orr, Rw, aux) = sink.grads, sink.saved
-        d_scales, d_rots, d_opac, d_nrm = keep
+        sr, rr, orr, Rw, aux = sink.saved
+        if in_registers:
+            d_scales = d_rots = d_opac = d_nrm = None
+        else:
+            d_scales, d_rots, d_opac, d_nrm = sink.grads
         N = model._xyz.shape[0]
-        if N == 0:
-            return
         for name, raw in (("scaling", sr), ("rotation", rr), ("opacity", orr)):
             if raw.data_ptr() != groups[name]["params"][0].data_ptr():
                 raise RuntimeError(f"geometry_step: the backward saw another `{name}` tensor than the optimizer holds")
-        gx = model._xyz.grad
+        gx = None if in_registers else model._xyz.grad
+        step_xyz = in_registers or gx is not None
         st = {k: self._state(groups[k]) for k in ("xyz", "scaling", "rotation", "opacity")}
         # the counters are advanced only once the launch has been accepted: a failed call must not shift the bias correction
-        nxt = {k: st[k]["step"] + (1 if (k != "xyz" or gx is not None) else 0) for k in st}
+        nxt = {k: st[k]["step"] + (1 if (k != "xyz" or step_xyz) else 0) for k in st}
         ptr = lambda t: None if t is None else t.data_ptr()
         gxc = None if gx is None else gx.contiguous()
         sreg = sink.scale_reg
+        want_stats = stats if in_registers else grad2d is not None
         a = _lib.VcrGeometryStep(
-            N=N, step_xyz=nxt["xyz"] if gx is not None else 0, step_scaling=nxt["scaling"],
+            N=N, step_xyz=nxt["xyz"] if step_xyz else 0, step_scaling=nxt["scaling"],
             step_rotation=nxt["rotation"], step_opacity=nxt["opacity"],
             xyz=model._xyz.data_ptr(), scaling=sr.data_ptr(), rotation=rr.data_ptr(), opacity=orr.data_ptr(),
             d_means3D=ptr(gxc), d_scales=ptr(d_scales), d_rots=ptr(d_rots), d_opac=ptr(d_opac), d_normals=ptr(d_nrm),
@@ -190,14 +198,30 @@ class FusedAdam:
             m_opacity=st["opacity"]["exp_avg"].data_ptr(), v_opacity=st["opacity"]["exp_avg_sq"].data_ptr(),
             lr_xyz=float(groups["xyz"]["lr"]), lr_scaling=float(groups["scaling"]["lr"]), lr_rotation=float(groups["rotation"]["lr"]),
             lr_opacity=float(groups["opacity"]["lr"]), beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
-            grad2d=ptr(grad2d), radii=ptr(radii),
-            accum=None if grad2d is None else model.xyz_gradient_accum.data_ptr(),
-            denom=None if grad2d is None else model.denom.data_ptr(),
-            max_radii=None if grad2d is None else model.max_radii2D.data_ptr())
-        _lib.check(lib.vcr_geometry_step(C.byref(a), _lib.stream_of(model._xyz)))
-        for k in st:
-            st[k]["step"] = nxt[k]
-        model._xyz.grad = None
+            grad2d=None if in_registers else ptr(grad2d), radii=None if in_registers else ptr(radii),
+            accum=model.xyz_gradient_accum.data_ptr() if want_stats else None,
+            denom=model.denom.data_ptr() if want_stats else None,
+            max_radii=model.max_radii2D.data_ptr() if want_stats else None)
+        a._keep = (gxc, d_scales, d_rots, d_opac, d_nrm, grad2d, radii, sink.saved, sreg)     # (alive until the launch)
+
+        def commit():
+            for k in st:
+                st[k]["step"] = nxt[k]
+            model._xyz.grad = None
+
+        return a, commit
+
+    @torch.no_grad()
+    def geometry_step(self, model, sink, grad2d=None, radii=None):
+        """The static tail of an iteration in ONE launch (`vcr_geometry_step`): adjoint of the fused activation + l1_scale
+        gradient (from `sink`) -> densification statistics (`grad2d` [N,3] = `means2D_densify.grad`, `radii`; None = skip)
+        -> Adam on xyz / scaling / rotation / opacity.  Same arithmetic as activate-backward + `add_densification_stats` +
+        `step()` on those groups; their `.grad` must not be set elsewhere (`_xyz.grad` is consumed and cleared here)."""
+        if model._xyz.shape[0] == 0:
+            return
+        a, commit = self.prepare_geometry_step(model, sink, grad2d, radii)
+        _lib.check(_lib.load().vcr_geometry_step(C.byref(a), _lib.stream_of(model._xyz)))
+        commit()
 
     @torch.no_grad()
     def step_sh_from_rgb(self, drgb, dirs, sh_degree, stream=None):

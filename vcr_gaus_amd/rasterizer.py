@@ -90,15 +90,20 @@ class RasterOptions:
       colour_sh_update callable() -> (_lib.VcrShUpdate, keep-alive) or None: SH Adam step fused into the colour evaluation.
       sort_stream      torch.cuda.Stream: depth keys + depth sort run there, beside the projection.
       quad_lists       bin the tile instances per 8x8 quad instead of per 16x16 tile (`VcrRasterArgs.quad_lists`): identical
-                       results, fewer gathers in the compositing kernels, more sort entries -- pays for small footprints."""
-    __slots__ = ("sh_grad", "colour_stream", "colour_hook", "colour_sh_update", "sort_stream", "quad_lists")
+                       results, fewer gathers in the compositing kernels, more sort entries -- pays for small footprints.
+      tail             an object with `.armed`, `.done` and `.tail()` -> (_lib.VcrGeometryStep, commit) or None (the trainer's
+                       `GeometrySink`): when armed, the BACKWARD of this call applies the static tail of the training
+                       iteration inside its projection-backward kernel (`vcr_rasterize_backward_tail`), calls `commit()`,
+                       sets `.done` and returns no gradient for means3D / means2D / opacities / scales / rotations / normals."""
+    __slots__ = ("sh_grad", "colour_stream", "colour_hook", "colour_sh_update", "sort_stream", "quad_lists", "tail")
 
     def __init__(self, sh_grad="full", colour_stream=None, colour_hook=None, colour_sh_update=None, sort_stream=None,
-                 quad_lists=False):
+                 quad_lists=False, tail=None):
         if sh_grad not in ("full", "rgb"):
             raise ValueError("sh_grad must be 'full' or 'rgb'")
         self.sh_grad, self.colour_stream, self.colour_hook = sh_grad, colour_stream, colour_hook
         self.colour_sh_update, self.sort_stream, self.quad_lists = colour_sh_update, sort_stream, bool(quad_lists)
+        self.tail = tail
 
 
 DEFAULT_OPTIONS = RasterOptions()
@@ -226,6 +231,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             ctx.num_dist = int(num_dist)
             ctx.quad_lists = int(a.quad_lists)
             ctx.rgb_mode = opts.sh_grad == "rgb" and t["shs"] is not None
+            ctx.tail = opts.tail
             ctx.save_for_backward(radii)
             ctx.mark_non_differentiable(radii)
             return out, radii
@@ -260,23 +266,33 @@ class _RasterizeGaussians(torch.autograd.Function):
         def new(*shape):
             return torch.empty(shape, dtype=torch.float32, device=dev)
 
-        d_means3D, d_means2D, d_opac = new(N, 3), new(N, 3), new(N, 1)
-        d_dens = new(N, 3) if ctx.has else None
         rgb_mode = ctx.rgb_mode
+        # the static tail of the iteration inside this backward: gradients w.r.t. the geometry stay in registers
+        sink, tail = ctx.tail, None
+        if sink is not None and sink.armed and not sink.done and N > 0 and t["scales"] is not None and t["cov"] is None \
+                and (rgb_mode or t["shs"] is None):
+            tail = sink.tail()
+        if tail is not None:
+            d_means3D = d_means2D = d_opac = d_dens = None
+        else:
+            d_means3D, d_means2D, d_opac = new(N, 3), new(N, 3), new(N, 1)
+            d_dens = new(N, 3) if ctx.has else None
         d_shs = new(*t["shs"].shape) if (t["shs"] is not None and not rgb_mode) else None
         d_shr = new(*t["shs_rest"].shape) if (t["shs_rest"] is not None and not rgb_mode) else None
         d_rgb = new(N, 3) if rgb_mode else None
         v_dirs = new(N, 3) if rgb_mode else None
         d_col = new(N, 3) if t["colors"] is not None else None
-        d_nrm = new(N, 3) if t["normals"] is not None else None
+        d_nrm = new(N, 3) if (t["normals"] is not None and tail is None) else None
         d_sem = new(N, S) if t["sem"] is not None else None
-        d_sc = new(N, 3) if t["scales"] is not None else None
-        d_rot = new(N, 4) if t["rots"] is not None else None
+        d_sc = new(N, 3) if (t["scales"] is not None and tail is None) else None
+        d_rot = new(N, 4) if (t["rots"] is not None and tail is None) else None
         d_cov = new(N, 6) if t["cov"] is not None else None
         io = _lib.VcrBackwardIO(dL_dout=_ptr(g), geom=_ptr(ctx.state[_lib.BUF_GEOM]),
                                 binning=_ptr(ctx.state[_lib.BUF_BINNING]), image=_ptr(ctx.state[_lib.BUF_IMAGE]),
                                 radii=_ptr(radii), num_rendered=ctx.num_rendered, dL_dmeans3D=_ptr(d_means3D),
-                                dL_dmeans2D=_ptr(d_means2D), dL_dmeans2D_densify=_ptr(d_dens), dL_dshs=_ptr(d_shs),
+                                dL_dmeans2D=_ptr(d_means2D),
+                                dL_dmeans2D_densify=_ptr(d_dens) if tail is None else (_ptr(radii) if ctx.has else None),   # (tail: a flag)
+                                dL_dshs=_ptr(d_shs),
                                 dL_dshs_rest=_ptr(d_shr), dL_drgb=_ptr(d_rgb), view_dirs=_ptr(v_dirs), dL_dcolors=_ptr(d_col), dL_dnormals=_ptr(d_nrm), dL_dsemantics=_ptr(d_sem),
                                 dL_dopacities=_ptr(d_opac), dL_dscales=_ptr(d_sc), dL_drotations=_ptr(d_rot),
                                 dL_dcov3D=_ptr(d_cov))
@@ -284,7 +300,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         stream = torch.cuda.current_stream(dev).cuda_stream
         try:
             with torch.cuda.device(dev):
-                _check(lib.vcr_rasterize_backward(a, io, al.cb, None, stream))
+                if tail is not None:
+                    _check(lib.vcr_rasterize_backward_tail(a, io, tail[0], al.cb, None, stream))
+                    tail[1]()
+                    sink.done = True
+                else:
+                    _check(lib.vcr_rasterize_backward(a, io, al.cb, None, stream))
         finally:
             al.close()
         if rgb_mode:

@@ -84,10 +84,12 @@ class Trainer:
         self._factorised_base = self.factorised_sh
         self.side = None
         self._pending_sh = None          # (drgb, view_dirs, sh_degree) of the last backward, not yet applied
+        self._zero_campos = None
         # Fused static tail (round 3): on iterations without densify / prune / reset surgery a single process runs the adjoint
         # of the fused activation, the l1_scale gradient, the densification statistics and Adam on xyz / scaling / rotation /
         # opacity as ONE kernel (`FusedAdam.geometry_step`) instead of five.  VCR_NO_FUSED_GEOMETRY=1 keeps the modular form.
         self.fuse_geometry = not os.environ.get("VCR_NO_FUSED_GEOMETRY")
+        self.fuse_raster_tail = not os.environ.get("VCR_NO_RASTER_TAIL")       # (the tail inside the rasterizer's backward)
         # third stream: depth keys + depth sort beside the projection (two-stream form only).  Measured: neutral at 1-2 M
         # Gaussians (1.61 vs 1.61, 2.50-2.58 vs 2.49-2.58 ms/step), -4 % at 5 M (4.53 vs 4.74), where the 8 sort launches
         # over 5 M keys are long enough to matter: used from 3 M Gaussians on.
@@ -294,9 +296,14 @@ class Trainer:
             self.model.optimizer.grad_scale = 1.0
             return
         if self.world == 1 and not getattr(self, "force_collectives", False):   # single-rank factorised path: no collectives
-            drgb = rec.take_sh_factors()[0].contiguous()
-            campos = self.cameras[self._picked[0]].camera_center.float().reshape(1, 3).contiguous()
-            self.model._features_dc.grad, self.model._features_rest.grad = self._sh_grads_from_rgb(drgb[None].contiguous(), campos)
+            # the view directions are those the backward stored with dL/drgb, not re-derived from the positions: the static
+            # tail may already have moved them (it runs inside the rasterizer's backward).  A unit vector minus a zero
+            # "camera centre" is that direction again.
+            drgb, dirs = rec.take_sh_factors()
+            if self._zero_campos is None or self._zero_campos.device != drgb.device:
+                self._zero_campos = torch.zeros(1, 3, device=drgb.device)
+            self.model._features_dc.grad, self.model._features_rest.grad = \
+                self._sh_grads_from_rgb(drgb[None].contiguous(), self._zero_campos, xyz=dirs.contiguous())
             self.model.optimizer.grad_scale = 1.0
             return
         works = []
@@ -384,14 +391,16 @@ class Trainer:
             if collectives and self.exchange_algo == "rs_ag" and self.world > 1:
                 self.last_exchange += "+rs_ag"
 
-    def _sh_grads_from_rgb(self, drgb_all, campos_all):
-        """sum over the step's views of basis_k(dir_view) x dL/drgb_view (HIP kernel vcr_sh_grad_from_rgb)."""
+    def _sh_grads_from_rgb(self, drgb_all, campos_all, xyz=None):
+        """sum over the step's views of basis_k(dir_view) x dL/drgb_view (HIP kernel vcr_sh_grad_from_rgb); dir_view =
+        normalised (xyz - campos_view), `xyz` defaulting to the model's positions."""
         from . import _lib
         m = self.model
         lib = _lib.load()
         N = m._xyz.shape[0]
         d_dc, d_rest = torch.empty_like(m._features_dc), torch.empty_like(m._features_rest)
-        _lib.check(lib.vcr_sh_grad_from_rgb(N, int(m.active_sh_degree), int(drgb_all.shape[0]), m._xyz.detach().data_ptr(),
+        _lib.check(lib.vcr_sh_grad_from_rgb(N, int(m.active_sh_degree), int(drgb_all.shape[0]),
+                                            (m._xyz.detach() if xyz is None else xyz).data_ptr(),
                                             campos_all.data_ptr(), drgb_all.data_ptr(), d_dc.data_ptr(), d_rest.data_ptr(),
                                             _lib.stream_of(drgb_all)))
         return d_dc, d_rest
@@ -538,11 +547,6 @@ class Trainer:
         if not overlap and self._pending_sh is not None:
             self.join_side()
         fuse = overlap and not os.environ.get("VCR_NO_FUSED_SH_COLOUR")
-        opts = RasterOptions("rgb" if self.factorised_sh else "full", self.side if overlap else None,
-                             self._launch_pending_sh if (overlap and not fuse) else None,
-                             self._pending_sh_update if fuse else None,
-                             self.sort_stream if (overlap and m._xyz.shape[0] >= self.sort_stream_min_gaussians) else None,
-                             quad_lists=self._quad_on)
         surgery = (it < cfg.optim.densify_until_iter and it > cfg.optim.densify_from_iter
                    and it % cfg.optim.densification_interval == 0) \
             or it % cfg.optim.opacity_reset_interval == 0 or it in cfg.optim.prune.iterations \
@@ -556,6 +560,17 @@ class Trainer:
         # the iteration's side channel (see GeometrySink): armed = the one-kernel static tail; the l1_scale gradient joins the
         # activation backward's kernel; the loss node's reduction buffer is this trainer's
         sink = gaussian_model.GeometrySink(armed=armed, defer_scale_grad=True, sums=self._loss_sums)
+        # ... and, with the factorised SH gradient, the tail runs INSIDE the rasterizer's backward (projection backward +
+        # activation adjoint + statistics + Adam in one kernel): the geometry gradients never reach memory
+        raster_tail = armed and self.fuse_raster_tail and self.factorised_sh
+        if raster_tail:
+            stats_on = it < cfg.optim.densify_until_iter
+            sink.tail = lambda: m.optimizer.prepare_geometry_step(m, sink, in_registers=True, stats=stats_on)
+        opts = RasterOptions("rgb" if self.factorised_sh else "full", self.side if overlap else None,
+                             self._launch_pending_sh if (overlap and not fuse) else None,
+                             self._pending_sh_update if fuse else None,
+                             self.sort_stream if (overlap and m._xyz.shape[0] >= self.sort_stream_min_gaussians) else None,
+                             quad_lists=self._quad_on, tail=sink if raster_tail else None)
         m._geom_sink = sink
         ok, left = False, None
         try:
@@ -577,20 +592,23 @@ class Trainer:
         finally:
             m._geom_sink = None
             sink.armed = False
+            sink.tail = None                                     # (its closure refers to the sink: no cycle left behind)
             left, sink.scale_grad = sink.scale_grad, None        # (never survives the step, also on errors)
-        if sink.grads is None and sink.scale_reg is not None:
+        if not sink.done and sink.grads is None and sink.scale_reg is not None:
             left = fused_losses.scale_grad_from_factors(sink.scale_reg)        # (no activation backward ran: ordinary path)
         if ok and left is not None:                 # (no activation backward consumed it: add it the ordinary way)
             m._scaling.grad = left if m._scaling.grad is None else m._scaling.grad + left
-        geom = armed and sink.grads is not None
+        geom = armed and (sink.done or sink.grads is not None)
+        self.last_tail = "raster" if sink.done else ("kernel" if geom else "modular")     # (which form of the tail ran)
         with torch.no_grad():
             self._exchange_grads(overlap, surgery, data["raster"])
             if geom:
                 # activation adjoint + l1_scale gradient + densification statistics + Adam on the four geometry groups
                 stats = it < cfg.optim.densify_until_iter
-                vp = data["viewspace_points_densify"]
-                m.optimizer.geometry_step(m, sink, grad2d=vp.grad.contiguous() if (stats and vp.grad is not None) else None,
-                                          radii=data["radii"] if stats else None)
+                if not sink.done:                  # (done: the rasterizer's backward has applied the tail itself)
+                    vp = data["viewspace_points_densify"]
+                    m.optimizer.geometry_step(m, sink, grad2d=vp.grad.contiguous() if (stats and vp.grad is not None) else None,
+                                              radii=data["radii"] if stats else None)
                 # the one-kernel tail has applied Adam to these groups; a gradient that reached them by another path (a loss
                 # built on the plain getters) would be applied a SECOND time by optimizer.step() below
                 stray = [k for k in ("_scaling", "_rotation", "_opacity") if getattr(m, k).grad is not None]
