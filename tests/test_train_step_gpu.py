@@ -176,24 +176,39 @@ def test_tail_inside_the_rasterizer_backward_equals_the_separate_kernel(device):
     kernel, geometry gradients in registers) against `vcr_rasterize_backward` followed by `vcr_geometry_step`: the same
     per-Gaussian functions (model_math.h), so after one step parameters, second moments and statistics agree to the rounding
     of differently contracted expressions plus the atomics' order of two separate renders; eight steps: the trajectory
-    criterion.  Single-stream and two-stream forms."""
+    criterion.  Single-stream and two-stream forms.  Third run: without the tail's evaluation of the NEXT camera's activations
+    (`ActivationCache`), i.e. with the stand-alone activation kernel at the start of every step."""
     from vcr_gaus_amd import synthetic
     from vcr_gaus_amd.trainer import make_synthetic_trainer
     raw = synthetic.make_gaussians(6000, seed=12)
     raw["scaling"] = raw["scaling"] + 1.2
     for two_stream in (False, True):
         runs = []
-        for raster_tail in (False, True):
+        for raster_tail, prefetch in ((False, True), (True, True), (True, False)):
             cams = synthetic.make_cameras(3, 128, 96, 110.0, device=device)
             tr = make_synthetic_trainer(raw, cams, device, preset="tnt", overlap_sh=two_stream, overlap_min_gaussians=0,
                                         force_factorised=True, optim={"densify_from_iter": 10 ** 9, "prune": {"iterations": []}})
-            tr.fuse_raster_tail = raster_tail
+            tr.fuse_raster_tail, tr.prefetch_activation = raster_tail, prefetch
             m = tr.model
             snaps = []
             for it in range(8):
+                had = getattr(m, "_act_cache", None)
                 tr.train_step()
                 assert tr.last_tail == ("raster" if raster_tail else "kernel")
                 assert m._xyz.grad is None and m._scaling.grad is None
+                assert (had is not None) == (prefetch and it > 0)
+                cache = getattr(m, "_act_cache", None)
+                assert (cache is not None) == prefetch and (cache is None or cache is not had)
+                if cache is not None and it in (0, 5):          # what the tail wrote is the activation kernel's output
+                    from vcr_gaus_amd.gaussian_model import fused_activate
+                    nxt = tr.cameras[tr._prefetched[0]]
+                    assert cache.matches(m, nxt.camera_center, nxt.R_w2c, True)
+                    m._act_cache = None
+                    with torch.no_grad():
+                        fresh = fused_activate(m, nxt.camera_center, nxt.R_w2c, True)
+                    m._act_cache = cache
+                    for got, want in zip(cache.tensors[:4], fresh):
+                        assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
                 if it == 0:
                     tr.join_side()
                     snaps.append({k: getattr(m, a).detach().clone() for k, a in PARAMS.items()})
@@ -204,20 +219,21 @@ def test_tail_inside_the_rasterizer_backward_equals_the_separate_kernel(device):
             snaps.append({k: getattr(m, a).detach().clone() for k, a in PARAMS.items()})
             assert all(m.optimizer.state[k]["step"] == 8 for k in ("xyz", "scaling", "rotation", "opacity"))
             runs.append(snaps)
-        a, b = runs
+        a = runs[0]
         lr = {"xyz": 1.6e-4 * 4, "scaling": 5e-3, "rotation": 1e-3, "opacity": 0.05, "f_dc": 2.5e-3, "f_rest": 1.25e-4}
-        for k in PARAMS:
-            d = (a[0][k] - b[0][k]).abs()
-            assert float((d > 2e-2 * lr[k]).double().mean()) < 2e-3, (two_stream, k, float(d.max()))
-        for k in a[1]:
-            assert torch.allclose(a[1][k], b[1][k], rtol=2e-3, atol=1e-12), k
-        assert float(a[2]["accum"].abs().max()) > 0
-        assert torch.allclose(a[2]["accum"], b[2]["accum"], rtol=1e-3, atol=1e-9) and torch.equal(a[2]["denom"], b[2]["denom"])
-        assert torch.equal(a[2]["radii"], b[2]["radii"])
-        for k in PARAMS:
-            d = (a[3][k] - b[3][k]).abs()
-            tol = 5e-3 * max(1.0, float(a[3][k].abs().max()))
-            assert float((d > tol).double().mean()) < 5e-3, (two_stream, k, float(d.max()))
+        for b in runs[1:]:
+            for k in PARAMS:
+                d = (a[0][k] - b[0][k]).abs()
+                assert float((d > 2e-2 * lr[k]).double().mean()) < 2e-3, (two_stream, k, float(d.max()))
+            for k in a[1]:
+                assert torch.allclose(a[1][k], b[1][k], rtol=2e-3, atol=1e-12), k
+            assert float(a[2]["accum"].abs().max()) > 0
+            assert torch.allclose(a[2]["accum"], b[2]["accum"], rtol=1e-3, atol=1e-9) and torch.equal(a[2]["denom"], b[2]["denom"])
+            assert torch.equal(a[2]["radii"], b[2]["radii"])
+            for k in PARAMS:
+                d = (a[3][k] - b[3][k]).abs()
+                tol = 5e-3 * max(1.0, float(a[3][k].abs().max()))
+                assert float((d > tol).double().mean()) < 5e-3, (two_stream, k, float(d.max()))
 
 
 @pytest.mark.parametrize("preset", ["dtu_c3", "tnt"])

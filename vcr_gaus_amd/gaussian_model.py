@@ -39,37 +39,41 @@ class GeometrySink:
         opacities / normals, so the activation backward has nothing left to do;
       * `sums`: the trainer's cache of the loss node's fp64 reduction buffer, {device: [buffer, in use]} (re-zeroed by the
         finalize kernel, so it can be re-used from step to step instead of being allocated and cleared)."""
-    __slots__ = ("armed", "grads", "saved", "scale_reg", "defer_scale_grad", "scale_grad", "sums", "tail", "done")
+    __slots__ = ("armed", "grads", "saved", "scale_reg", "defer_scale_grad", "scale_grad", "sums", "tail", "done", "want_normal")
 
     def __init__(self, armed=True, defer_scale_grad=False, sums=None, tail=None):
         self.armed, self.grads, self.saved, self.scale_reg = armed, None, None, None
         self.defer_scale_grad, self.scale_grad, self.sums = defer_scale_grad, None, sums
-        self.tail, self.done = tail, False
+        self.tail, self.done, self.want_normal = tail, False, None
 
 
 class _FusedActivate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, scaling, rotation, opacity, xyz, campos, R_w2c, want_normal, sink=None):
+    def forward(ctx, scaling, rotation, opacity, xyz, campos, R_w2c, want_normal, sink=None, pre=None):
         lib = _lib.load()
         N = xyz.shape[0]
         dev = xyz.device
         sr, rr, orr = scaling.detach().contiguous(), rotation.detach().contiguous(), opacity.detach().contiguous()
-        scales = torch.empty(N, 3, device=dev)
-        rots = torch.empty(N, 4, device=dev)
-        opac = torch.empty(N, 1, device=dev)
-        nrm = torch.empty(N, 3, device=dev) if want_normal else None
-        aux = torch.empty(N, dtype=torch.uint8, device=dev)
-        cp = campos.detach().contiguous().float()
         Rw = R_w2c.detach().contiguous().float()
-        _lib.check(lib.vcr_activate_forward(N, sr.data_ptr(), rr.data_ptr(), orr.data_ptr(), xyz.detach().contiguous().data_ptr(),
-                                            cp.data_ptr(), Rw.data_ptr(), scales.data_ptr(), rots.data_ptr(), opac.data_ptr(),
-                                            nrm.data_ptr() if want_normal else None, aux.data_ptr(), _lib.stream_of(xyz)))
+        if pre is not None:           # the previous iteration's static tail has already evaluated this (ActivationCache)
+            scales, rots, opac, nrm, aux = pre
+        else:
+            scales = torch.empty(N, 3, device=dev)
+            rots = torch.empty(N, 4, device=dev)
+            opac = torch.empty(N, 1, device=dev)
+            nrm = torch.empty(N, 3, device=dev) if want_normal else None
+            aux = torch.empty(N, dtype=torch.uint8, device=dev)
+            cp = campos.detach().contiguous().float()
+            _lib.check(lib.vcr_activate_forward(N, sr.data_ptr(), rr.data_ptr(), orr.data_ptr(), xyz.detach().contiguous().data_ptr(),
+                                                cp.data_ptr(), Rw.data_ptr(), scales.data_ptr(), rots.data_ptr(), opac.data_ptr(),
+                                                nrm.data_ptr() if want_normal else None, aux.data_ptr(), _lib.stream_of(xyz)))
         ctx.save_for_backward(sr, rr, orr, Rw, aux)
         ctx.set_materialize_grads(False)
         ctx.want_normal = want_normal
         ctx.sink = sink
         if sink is not None and sink.armed:
             sink.saved = (sr, rr, orr, Rw, aux)          # (the tail may run before this node's backward: inside the rasterizer's)
+            sink.want_normal = want_normal
         if want_normal:
             return scales, rots, opac, nrm
         return scales, rots, opac
@@ -78,14 +82,14 @@ class _FusedActivate(torch.autograd.Function):
     def backward(ctx, d_scales, d_rots, d_opac, d_nrm=None):
         lib = _lib.load()
         if d_scales is None and d_rots is None and d_opac is None and d_nrm is None:
-            return (None,) * 8                   # (e.g. the rasterizer's backward has applied the static tail itself)
+            return (None,) * 9                   # (e.g. the rasterizer's backward has applied the static tail itself)
         sr, rr, orr, Rw, aux = ctx.saved_tensors
         N = sr.shape[0]
         keep = [None if t is None else t.contiguous().float() for t in (d_scales, d_rots, d_opac, d_nrm)]
         if ctx.sink is not None and ctx.sink.armed and ctx.sink.grads is None:
             # fused static tail: `FusedAdam.geometry_step` applies this adjoint together with Adam in one pass
             ctx.sink.grads, ctx.sink.saved = keep, (sr, rr, orr, Rw, aux)
-            return (None,) * 8
+            return (None,) * 9
         ds, dr, do = torch.empty_like(sr), torch.empty_like(rr), torch.empty_like(orr)
         extra = None
         if ctx.sink is not None and ctx.sink.scale_grad is not None:          # l1_scale gradient of this iteration's loss node
@@ -96,13 +100,40 @@ class _FusedActivate(torch.autograd.Function):
                                              *[None if t is None else t.data_ptr() for t in keep],
                                              None if extra is None else extra.data_ptr(),
                                              ds.data_ptr(), dr.data_ptr(), do.data_ptr(), _lib.stream_of(sr)))
-        return ds, dr, do, None, None, None, None, None
+        return ds, dr, do, None, None, None, None, None, None
+
+
+class ActivationCache:
+    """Activated scales / rotations / opacities (+ camera-space normals) that the static tail of the PREVIOUS iteration wrote
+    for the camera of this one (`VcrGeometryStep.next_*`: the parameters are in registers there anyway).  One-shot: the next
+    `fused_activate` on the model takes it if -- and only if -- it asks for the same camera tensors, the same `want_normal`
+    and the raw parameters are the tensors (storage and version counter) the tail updated; anything else drops it."""
+    __slots__ = ("campos", "R", "want_normal", "tensors", "stamp")
+
+    @staticmethod
+    def stamp_of(pc):
+        return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (pc._scaling, pc._rotation, pc._opacity, pc._xyz))
+
+    def __init__(self, pc, campos, R, want_normal, tensors):
+        self.campos, self.R, self.want_normal, self.tensors = campos, R, want_normal, tensors
+        self.stamp = self.stamp_of(pc)
+
+    def matches(self, pc, campos, R, want_normal):
+        return (campos is self.campos or campos.data_ptr() == self.campos.data_ptr()) and \
+            (R is self.R or R.data_ptr() == self.R.data_ptr()) and bool(want_normal) == bool(self.want_normal) and \
+            self.stamp == self.stamp_of(pc)
 
 
 def fused_activate(pc, camera_center, R_w2c, want_normal=True):
     """-> (scales[N,3], rotations[N,4], opacity[N,1], normals_cam[N,3]) from the raw parameters."""
+    pre = None
+    cache = getattr(pc, "_act_cache", None)
+    if cache is not None:
+        pc._act_cache = None
+        if cache.matches(pc, camera_center, R_w2c, want_normal):
+            pre = cache.tensors
     return _FusedActivate.apply(pc._scaling, pc._rotation, pc._opacity, pc._xyz, camera_center, R_w2c, want_normal,
-                                getattr(pc, "_geom_sink", None))
+                                getattr(pc, "_geom_sink", None), pre)
 
 
 class FusedAdam:
@@ -160,7 +191,7 @@ class FusedAdam:
                 g["params"][0].grad = None
 
     @torch.no_grad()
-    def prepare_geometry_step(self, model, sink, grad2d=None, radii=None, in_registers=False, stats=False):
+    def prepare_geometry_step(self, model, sink, grad2d=None, radii=None, in_registers=False, stats=False, next_cam=None):
         """-> (VcrGeometryStep, commit): the argument block of the static tail and the host bookkeeping to run once the launch
         has been accepted (Adam step counters, `_xyz.grad`).  `in_registers`: the form `vcr_rasterize_backward_tail` takes
         -- no upstream gradient arrays (they stay inside the projection-backward kernel), `stats` instead of `grad2d` /
@@ -203,23 +234,36 @@ class FusedAdam:
             denom=model.denom.data_ptr() if want_stats else None,
             max_radii=model.max_radii2D.data_ptr() if want_stats else None)
         a._keep = (gxc, d_scales, d_rots, d_opac, d_nrm, grad2d, radii, sink.saved, sreg)     # (alive until the launch)
+        nxt_act = None
+        if next_cam is not None:          # (campos [3], R_w2c [3,3], want_normal): the kernel also activates for that camera
+            campos, Rn, wn = next_cam
+            dev = model._xyz.device
+            if campos.is_cuda and Rn.is_cuda and campos.dtype == torch.float32 and Rn.dtype == torch.float32 \
+                    and campos.is_contiguous() and Rn.is_contiguous():
+                nxt_act = (torch.empty(N, 3, device=dev), torch.empty(N, 4, device=dev), torch.empty(N, 1, device=dev),
+                           torch.empty(N, 3, device=dev) if wn else None, torch.empty(N, dtype=torch.uint8, device=dev))
+                a.next_campos, a.next_Rw2c = campos.data_ptr(), Rn.data_ptr()
+                a.next_scales, a.next_rots, a.next_opac = (t.data_ptr() for t in nxt_act[:3])
+                if wn:
+                    a.next_normals, a.next_aux = nxt_act[3].data_ptr(), nxt_act[4].data_ptr()
 
         def commit():
             for k in st:
                 st[k]["step"] = nxt[k]
             model._xyz.grad = None
+            model._act_cache = None if nxt_act is None else ActivationCache(model, next_cam[0], next_cam[1], next_cam[2], nxt_act)
 
         return a, commit
 
     @torch.no_grad()
-    def geometry_step(self, model, sink, grad2d=None, radii=None):
+    def geometry_step(self, model, sink, grad2d=None, radii=None, next_cam=None):
         """The static tail of an iteration in ONE launch (`vcr_geometry_step`): adjoint of the fused activation + l1_scale
         gradient (from `sink`) -> densification statistics (`grad2d` [N,3] = `means2D_densify.grad`, `radii`; None = skip)
         -> Adam on xyz / scaling / rotation / opacity.  Same arithmetic as activate-backward + `add_densification_stats` +
         `step()` on those groups; their `.grad` must not be set elsewhere (`_xyz.grad` is consumed and cleared here)."""
         if model._xyz.shape[0] == 0:
             return
-        a, commit = self.prepare_geometry_step(model, sink, grad2d, radii)
+        a, commit = self.prepare_geometry_step(model, sink, grad2d, radii, next_cam=next_cam)
         _lib.check(_lib.load().vcr_geometry_step(C.byref(a), _lib.stream_of(model._xyz)))
         commit()
 

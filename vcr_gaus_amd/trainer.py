@@ -90,6 +90,9 @@ class Trainer:
         # opacity as ONE kernel (`FusedAdam.geometry_step`) instead of five.  VCR_NO_FUSED_GEOMETRY=1 keeps the modular form.
         self.fuse_geometry = not os.environ.get("VCR_NO_FUSED_GEOMETRY")
         self.fuse_raster_tail = not os.environ.get("VCR_NO_RASTER_TAIL")       # (the tail inside the rasterizer's backward)
+        # ... which also evaluates the activations for the NEXT iteration's camera while the updated parameters are in registers
+        self.prefetch_activation = not os.environ.get("VCR_NO_ACT_PREFETCH")
+        self._prefetched = None          # cameras of the next iteration, drawn ahead by `_peek_next_camera`
         # third stream: depth keys + depth sort beside the projection (two-stream form only).  Measured: neutral at 1-2 M
         # Gaussians (1.61 vs 1.61, 2.50-2.58 vs 2.49-2.58 ms/step), -4 % at 5 M (4.53 vs 4.74), where the 8 sort launches
         # over 5 M keys are long enough to matter: used from 3 M Gaussians on.
@@ -194,14 +197,32 @@ class Trainer:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
 
     # ---- camera batch: `world` cameras per step, rank r takes the r-th (`trainer.py:326-328`) -------
-    def _next_cameras(self):
+    def _draw_cameras(self):
         picked = []
         for _ in range(self.world):
             if not self.view_order:
                 self.view_order = list(range(len(self.cameras)))
             picked.append(self.view_order.pop(self.rng.randint(0, len(self.view_order) - 1)))
+        return picked
+
+    def _next_cameras(self):
+        picked, self._prefetched = (self._prefetched if self._prefetched is not None else self._draw_cameras()), None
         self._picked = picked
         return picked
+
+    def _peek_next_camera(self):
+        """The camera of the NEXT iteration, drawn now (same draws, same order: nothing else uses the generator between the
+        static tail of an iteration without surgery and the start of the next one) so that the tail can already evaluate the
+        activations for it (`VcrGeometryStep.next_*`).  -> (camera_center, R_w2c, want_normal) or None."""
+        if not self.prefetch_activation:
+            return None
+        if self._prefetched is None:
+            self._prefetched = self._draw_cameras()
+        cam = self.cameras[self._prefetched[self.rank]]
+        R = getattr(cam, "R_w2c", None)
+        if R is None or not torch.is_tensor(cam.camera_center):
+            return None
+        return cam.camera_center, R
 
     # ---- losses (`trainer.py:233-321`) -------------------------------------------------------------------
     def active_extra_losses(self, it):
@@ -481,6 +502,7 @@ class Trainer:
         self.current_iteration = int(first_iter)
         self._stats_delta, self._visi_delta, self._stats_dirty = None, None, False
         self._pending_sh, self.visi_list = None, None
+        self.model._act_cache = None
 
     # ---- visibility / importance passes (`tools/prune.py:6-69`, `trainer.py:688-702`), camera-sharded ------------
     @torch.no_grad()
@@ -563,9 +585,13 @@ class Trainer:
         # ... and, with the factorised SH gradient, the tail runs INSIDE the rasterizer's backward (projection backward +
         # activation adjoint + statistics + Adam in one kernel): the geometry gradients never reach memory
         raster_tail = armed and self.fuse_raster_tail and self.factorised_sh
+        def next_cam():            # (evaluated when the tail is prepared: the sink then knows this render's `want_normal`)
+            nc = self._peek_next_camera() if sink.want_normal is not None else None
+            return None if nc is None else nc + (sink.want_normal,)
+
         if raster_tail:
             stats_on = it < cfg.optim.densify_until_iter
-            sink.tail = lambda: m.optimizer.prepare_geometry_step(m, sink, in_registers=True, stats=stats_on)
+            sink.tail = lambda: m.optimizer.prepare_geometry_step(m, sink, in_registers=True, stats=stats_on, next_cam=next_cam())
         opts = RasterOptions("rgb" if self.factorised_sh else "full", self.side if overlap else None,
                              self._launch_pending_sh if (overlap and not fuse) else None,
                              self._pending_sh_update if fuse else None,
@@ -608,7 +634,7 @@ class Trainer:
                 if not sink.done:                  # (done: the rasterizer's backward has applied the tail itself)
                     vp = data["viewspace_points_densify"]
                     m.optimizer.geometry_step(m, sink, grad2d=vp.grad.contiguous() if (stats and vp.grad is not None) else None,
-                                              radii=data["radii"] if stats else None)
+                                              radii=data["radii"] if stats else None, next_cam=next_cam())
                 # the one-kernel tail has applied Adam to these groups; a gradient that reached them by another path (a loss
                 # built on the plain getters) would be applied a SECOND time by optimizer.step() below
                 stray = [k for k in ("_scaling", "_rotation", "_opacity") if getattr(m, k).grad is not None]
@@ -740,6 +766,7 @@ class BenchTrainer:
         tr._stats_delta, tr._visi_delta, tr._stats_dirty = None, None, False
         tr.current_iteration, rng_state, tr.view_order, lrs, m.active_sh_degree = host
         tr.rng.setstate(rng_state)
+        tr._prefetched, m._act_cache = None, None           # (drawn / evaluated for the priming run's next step)
         for g, (name, lr) in zip(m.optimizer.param_groups, lrs):
             g["lr"] = lr
         torch.cuda.synchronize()
