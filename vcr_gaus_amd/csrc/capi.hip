@@ -98,12 +98,6 @@ hipEvent_t colour_event(int k) {
     return e[k];
 }
 
-hipEvent_t readback_event() {
-    static thread_local hipEvent_t e = nullptr;
-    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
-    return e;
-}
-
 __global__ void fill_background_kernel(int P, int C, const float* __restrict__ bg, float* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
@@ -339,13 +333,13 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         // while the host wakes up, sizes the instance buffers and enqueues the rest
         Readback* rb = pinned_readback();
         Published* pub = pinned_published();
-        hipEvent_t ev = readback_event();
-        if (!rb || !pub || !ev) { vcr_set_error("hipHostMalloc / hipEventCreate for the readback failed"); return join_streams(); }
+        if (!rb || !pub) { vcr_set_error("hipHostMalloc for the readback failed"); return join_streams(); }
         static thread_local uint32_t seq_counter = 0;
         const uint32_t seq = ++seq_counter ? seq_counter : ++seq_counter;      // never 0
         hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(256), 0, st, vis_counter, pub, seq);
         VCR_HIP_CHECK_JOIN(hipGetLastError());
-        VCR_HIP_CHECK_JOIN(hipEventRecord(ev, st));
+        // (no event behind the publish kernel: a marker packet between it and the depth sort costs the main stream ~10 us per
+        //  step; the slow path of the hand-over below drains the stream instead)
         g_ht.mark(HostTrace::PUBLISH);
         if (!split_sort) {
             StageTimer tm(ST_DEPTHSORT, st);
@@ -355,8 +349,8 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         // error return below first joins it (the caller's retry / error handling must not see an un-joined stream).
         auto fail_joined = join_streams;
         g_ht.mark(HostTrace::DEPTH_SORT);
-        {   // spin on the published sequence number for at most ~2 ms of wall time, then sleep in the event (which also
-            // surfaces a device fault or a failed launch as an error instead of a hang)
+        {   // spin on the published sequence number for at most ~2 ms of wall time, then sleep in a stream synchronisation (which
+            // also surfaces a device fault or a failed launch as an error instead of a hang)
             const auto t_spin = std::chrono::steady_clock::now();
             unsigned spins = 0;
             while (pub->seq != seq) {
@@ -365,8 +359,8 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
 #endif
                 if ((++spins & 1023u) == 0 &&
                     std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(2)) {
-                    const hipError_t e = hipEventSynchronize(ev);
-                    if (e != hipSuccess) { vcr_set_error("readback event: %s", hipGetErrorString(e)); return fail_joined(); }
+                    const hipError_t e = hipStreamSynchronize(st);
+                    if (e != hipSuccess) { vcr_set_error("instance-count hand-over: %s", hipGetErrorString(e)); return fail_joined(); }
                     break;
                 }
             }
