@@ -369,3 +369,54 @@ def test_fused_loss_path_is_chosen_by_the_losses_active_at_the_iteration():
     assert early == ["entropy"]
     late = Trainer.active_extra_losses(me, 10 ** 6)
     assert "depth_var" in late and "entropy" in late and ("curv" in late) == ("depth_normal" in me.weights)
+
+
+def test_camera_prefetch_keeps_the_draw_sequence_and_activation_cache_is_strict():
+    """Host logic of the fused tail's look-ahead: drawing the next iteration's cameras early (`Trainer._peek_next_camera`)
+    leaves the sequence of `_next_cameras` (`trainer.py:326-328`: pop a random remaining view) unchanged, also for several ranks
+    and with peeks only on some iterations; an `ActivationCache` is taken only for the camera tensors, `want_normal` and raw
+    parameters (storage AND version counter) it was made for."""
+    import random
+    from types import SimpleNamespace
+    from vcr_gaus_amd.gaussian_model import ActivationCache
+    from vcr_gaus_amd.trainer import Trainer
+
+    def trainer(world):
+        cams = [SimpleNamespace(camera_center=torch.full((3,), float(i)), R_w2c=torch.eye(3) * (i + 1)) for i in range(7)]
+        me = SimpleNamespace(rng=random.Random(3), view_order=[], cameras=cams, world=world, rank=world - 1, _prefetched=None,
+                             prefetch_activation=True, _picked=None)
+        for name in ("_draw_cameras", "_next_cameras", "_peek_next_camera"):
+            setattr(me, name, getattr(Trainer, name).__get__(me))
+        return me
+
+    for world in (1, 3):
+        plain, ahead = trainer(world), trainer(world)
+        want = [plain._next_cameras() for _ in range(40)]
+        got = []
+        for it in range(40):
+            got.append(ahead._next_cameras())
+            assert ahead._picked == got[-1] and ahead._prefetched is None
+            if it % 3 != 1:                            # (iterations with surgery do not look ahead)
+                centre, R = ahead._peek_next_camera()
+                assert ahead._peek_next_camera()[0] is centre                       # (a second look does not draw again)
+                nxt = ahead.cameras[ahead._prefetched[ahead.rank]]
+                assert centre is nxt.camera_center and R is nxt.R_w2c and ahead._picked == got[-1]
+        assert got == want
+    off = trainer(1)
+    off.prefetch_activation = False
+    assert off._peek_next_camera() is None and off._prefetched is None
+
+    pc = SimpleNamespace(_scaling=torch.zeros(5, 3), _rotation=torch.zeros(5, 4), _opacity=torch.zeros(5, 1), _xyz=torch.zeros(5, 3))
+    centre, R = torch.zeros(3), torch.eye(3)
+    cache = ActivationCache(pc, centre, R, True, ("scales", "rots", "opac", "nrm", "aux"))
+    assert cache.matches(pc, centre, R, True)
+    assert not cache.matches(pc, centre, R, False) and not cache.matches(pc, torch.zeros(3), R, True)
+    assert not cache.matches(pc, centre, torch.eye(3), True)
+    pc._opacity.add_(1.0)                              # an in-place edit of a raw parameter: version counter
+    assert not cache.matches(pc, centre, R, True)
+    cache = ActivationCache(pc, centre, R, True, ())
+    pc._xyz = torch.zeros(5, 3)                        # a replaced parameter tensor (densify / prune / restore): storage
+    assert not cache.matches(pc, centre, R, True)
+    cache = ActivationCache(pc, centre, R, True, ())
+    pc._scaling = torch.zeros(6, 3)
+    assert not cache.matches(pc, centre, R, True)
