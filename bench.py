@@ -421,6 +421,8 @@ def main():
                        "exchange": trainer.exchange(), "exchange_collective": args.exchange if world > 1 else None,
                        "step": trainer.describe(), "ranks": world, "side_stream_cus": args.side_cus or None,
                        "quad_lists_below": trainer.tr.quad_lists_below, "quad_lists": bool(trainer.tr._quad_on), "arena_bytes": trainer.arena_bytes,
+                       "static_tail": getattr(trainer.tr, "last_tail", None),
+                       "activation_prefetch": bool(getattr(trainer.tr, "prefetch_activation", False)) and getattr(trainer.tr, "last_tail", None) != "modular",
                        "dist_backend": (dist.get_backend() if world > 1 else None), "env_switches": switches()},
             "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": per_step[0], "max": per_step[-1], "slowest_step_index": in_order.index(per_step[-1]),
                         "note": "per-step GPU-timeline spread (events after every step); `value` uses the wall clock of all K steps"},
