@@ -213,7 +213,7 @@ class Trainer:
     def _peek_next_camera(self):
         """The camera of the NEXT iteration, drawn now (same draws, same order: nothing else uses the generator between the
         static tail of an iteration without surgery and the start of the next one) so that the tail can already evaluate the
-        activations for it (`VcrGeometryStep.next_*`).  -> (camera_center, R_w2c, want_normal) or None."""
+        activations for it (`VcrGeometryStep.next_*`).  -> (camera_center, R_w2c) of this rank's next camera, or None."""
         if not self.prefetch_activation:
             return None
         if self._prefetched is None:
