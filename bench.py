@@ -164,7 +164,7 @@ def cpu_loss_chain(H, W):
 
 def pmc_value(counter, kernel="composite_fwd", names=("sq", "grbm")):
     import csv
-    for rnd in ("r4", "r3", "r2", "r1"):
+    for rnd in ("r5", "r4", "r3", "r2", "r1"):
         for name in names:
             path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{name}.csv")
             if os.path.exists(path):
@@ -197,7 +197,7 @@ def pmc_traffic(kernel="composite_fwd_v2_kernel"):
     the x2 the MI355X guide prescribes (uncalibrated for this gather pattern)."""
     import csv
     vals = {}
-    rnd = next((r for r in ("r4", "r3", "r2", "r1") if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_pmc_fetch.csv"))), "r1")
+    rnd = next((r for r in ("r5", "r4", "r3", "r2", "r1") if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_pmc_fetch.csv"))), "r1")
     pmc_traffic.source = f"profiles/{rnd}_pmc_{{fetch,write}}.csv (rocprofv3 --pmc, separate passes)"
     meta = os.path.join(ROOT, "profiles", f"{rnd}_pmc_meta.json")
     pmc_traffic.meta = json.load(open(meta)) if os.path.exists(meta) else None      # R / R' / camera of the counter passes
@@ -401,10 +401,22 @@ def main():
     if rank == 0:
         P = W * H
         R = trainer.last_R
+        E, V = trainer.last_E, trainer.last_V
         ms_fwd = prof["composite_fwd"][0] / max(prof["composite_fwd"][1], 1)
         alg_bytes = (60 + 4 * sem) * R + (4 * (8 + sem) + 20) * P
         achieved = alg_bytes / (ms_fwd * 1e-3) / 1e9 if ms_fwd > 0 else 0.0
+        # the same figure on the instances the kernel really walks: E <= R after the projection's exact per-tile rejection
+        alg_emitted = (60 + 4 * sem) * E + (4 * (8 + sem) + 20) * P
+        ach_emitted = alg_emitted / (ms_fwd * 1e-3) / 1e9 if ms_fwd > 0 else 0.0
         stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof_all.items()}
+        # K7, the compositing backward (the longest kernel of the step): SURVEY 8(d) lower bound = records + image state +
+        # incoming image gradients read, one read-modify-write of the 60 + 4S gradient bytes per VISIBLE Gaussian; its average
+        # comes from the untimed all-stages pass (HIP events around the launch), so the timed steps carry one event pair only
+        ms_bwd = prof_all["composite_bwd"][0] / max(prof_all["composite_bwd"][1], 1)
+        alg_bwd = (60 + 4 * sem) * R + (8 * (8 + sem) + 20) * P + 2 * (60 + 4 * sem) * V
+        alg_bwd_emitted = alg_bwd - (60 + 4 * sem) * (R - E)
+        ach_bwd = alg_bwd / (ms_bwd * 1e-3) / 1e9 if ms_bwd > 0 else 0.0
+        traffic_bwd = pmc_traffic("composite_bwd_rows_kernel") if args.workload == "metric_1m_1080p" else None
         raster_fwd_ms = sum(stages[k] for k in ["preprocess", "depth_sort_scan", "binning", "composite_fwd"])
         shape = trainer.scene_shape()            # one extra (untimed) debug render: longest tile list, covered pixels
         line = {
@@ -431,6 +443,7 @@ def main():
             "stage_ms": stages,
             "roofline": {"kernel": "composite_fwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "frac_emitted": ach_emitted / HBM_PEAK_GBS, "algorithmic_bytes_emitted": alg_emitted,
                          "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                          "traffic": pmc_traffic() if args.workload == "metric_1m_1080p" else None,
                          "traffic_source": getattr(pmc_traffic, "source", None),
@@ -441,10 +454,19 @@ def main():
                          # peak; `executed_*`: what the kernel really issues (SQ_INSTS_VALU of the committed PMC pass; the
                          # per-quad culling skips most pairs) and the share of the launch the VALUs are busy.
                          "valu": valu_block(R, ms_fwd, args.workload)},
+            "roofline_bwd": {"kernel": "composite_bwd", "bound": "hbm", "achieved": ach_bwd, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ach_bwd / HBM_PEAK_GBS,
+                             "frac_emitted": (alg_bwd_emitted / (ms_bwd * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_bwd > 0 else 0.0,
+                             "algorithmic_bytes": alg_bwd, "algorithmic_bytes_emitted": alg_bwd_emitted, "avg_ms": ms_bwd,
+                             "avg_from": "untimed all-stages pass of the same steps (HIP events around the launch)",
+                             "traffic": traffic_bwd, "traffic_source": getattr(pmc_traffic, "source", None) if traffic_bwd else None,
+                             "bytes_are": "SURVEY 8(d) K7 lower bound: (60+4S) R + (8 C + 20) P + 2 (60+4S) V"},
         }
         if world == 1 and args.workload == "metric_1m_1080p" and not args.no_context:
             line["roofline"]["dense_variant"] = trainer.dense_variant_roofline(3.5, HBM_PEAK_GBS, sem)
             line["schedule_inclusive"] = schedule_inclusive(trainer)
+            # SURVEY 8(d) defines the metric "densify amortised": this is that figure, beside the steady-state `value`
+            line["value_densify_amortised"] = line["schedule_inclusive"]["iters_per_s"]
             del trainer
             torch.cuda.empty_cache()
             line["fullframe_variant"] = measure_variant("fullframe_1m_1080p", dev)

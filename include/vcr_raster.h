@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 17
+#define VCR_ABI_VERSION 18
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -127,6 +127,8 @@ typedef struct VcrBackwardIO {
     const void*  image;
     const int32_t* radii;    /* [N] as returned by forward */
     int64_t      num_rendered;
+    int64_t      num_emitted;    /* VcrForwardOut.num_emitted of the forward call (ABI 18): locates the per-chunk transmittance
+                                    checkpoints the forward left behind the lists of the BINNING buffer */
     float* dL_dmeans3D;      /* [N,3] */
     float* dL_dmeans2D;      /* [N,3] (x,y in NDC units, z = 0) */
     float* dL_dmeans2D_densify; /* [N,3] sum over pixels of |per-pixel dL/dxy| (NDC units), or NULL */
@@ -143,6 +145,12 @@ typedef struct VcrBackwardIO {
     float* dL_dscales;       /* [N,3] or NULL */
     float* dL_drotations;    /* [N,4] or NULL */
     float* dL_dcov3D;        /* [N,6] or NULL */
+    /* optional (ABI 18), both or neither: this render's camera rotation [3,3] and the aux bytes of vcr_activate_forward.  When
+     * given, dL_dnormals is written as the gradient w.r.t. the WORLD-space shortest-axis column the normal was built from
+     * (flip sign and camera rotation of this view undone: sgn * Rw2c^T dL/dn_cam) -- the form ranks of a data-parallel step
+     * can sum, since it no longer depends on the rank's camera (vcr_geometry_step with normals_world = 1 consumes it). */
+    const float*   normals_Rw2c;
+    const uint8_t* normals_aux;
 } VcrBackwardIO;
 
 int vcr_abi_version(void);
@@ -238,8 +246,8 @@ int vcr_knn3_mean_dist2(int N, const float* points, float* out, void* stream);
 int vcr_adam_step(int ntensors, float* const* params, const float* const* grads, float* const* exp_avg,
                   float* const* exp_avg_sq, const int64_t* numel, const float* lr, float beta1, float beta2,
                   float eps, int step, float grad_scale, void* stream);
-/* The static tail of a training iteration in ONE pass over the Gaussians (single process, no densify / prune / reset this
- * iteration): adjoint of the fused activation (the four upstream gradients are those of vcr_rasterize_backward w.r.t. the
+/* The static tail of a training iteration in ONE pass over the Gaussians (no densify / prune / reset this iteration; data
+ * parallel: on the all-reduced ACTIVATED-space gradients, grad_scale = 1 / world, normals_world = 1): adjoint of the fused activation (the four upstream gradients are those of vcr_rasterize_backward w.r.t. the
  * ACTIVATED scales / rotations / opacities / camera-space normals of this iteration's render; `aux`, `Rw2c` as saved by
  * vcr_activate_forward) plus the l1_scale gradient (trainer.py:243-245; scale_reg_* NULL = none) -> densification statistics
  * (scene/gaussian_model.py:669-671, trainer.py:345; grad2d NULL = none) -> one torch.optim.Adam(eps) step on
@@ -247,7 +255,9 @@ int vcr_adam_step(int ntensors, float* const* params, const float* const* grads,
  * the UPDATED parameters for the next render's camera (next_* NULL = none).  Replaces vcr_activate_backward +
  * vcr_scale_reg_backward + vcr_densify_stats + vcr_adam_step + vcr_activate_forward on those four groups. */
 typedef struct VcrGeometryStep {
-    int32_t N, pad_;
+    int32_t N;
+    int32_t normals_world;                                           /* 1: d_normals is w.r.t. the world-space axis column
+                                                                        (VcrBackwardIO.normals_Rw2c), summed over ranks */
     int32_t step_xyz, step_scaling, step_rotation, step_opacity;     /* torch counts Adam steps per tensor (>= 1) */
     float *xyz, *scaling, *rotation, *opacity;                       /* raw parameters, updated in place */
     const float *d_means3D, *d_scales, *d_rots, *d_opac, *d_normals; /* upstream gradients (any may be NULL) */
@@ -256,6 +266,8 @@ typedef struct VcrGeometryStep {
     const float *trans, *scale;                                      /* [3] each: normalised bounding box */
     float *m_xyz, *v_xyz, *m_scaling, *v_scaling, *m_rotation, *v_rotation, *m_opacity, *v_opacity;
     float lr_xyz, lr_scaling, lr_rotation, lr_opacity, beta1, beta2, eps;
+    float grad_scale;                                                /* > 0: multiplies the five upstream gradients (1 / world
+                                                                        after a sum all-reduce); the l1_scale term is added once */
     const float* grad2d; const int32_t* radii; float *accum, *denom, *max_radii;
     const float *next_campos, *next_Rw2c;
     float *next_scales, *next_rots, *next_opac, *next_normals; uint8_t* next_aux;
@@ -401,6 +413,12 @@ int  vcr_profile_read(float* ms, int32_t* launches, int n);
  * surviving (quad, Gaussian) pair really hits.  out[0..64]: forward, out[65..129]: backward; accumulated over all launches
  * since the last reset.  Returns 1 in ordinary builds. */
 int  vcr_debug_hit_histogram(uint32_t out[130], int reset);
+/* Diagnostics: with `on`, every vcr_rasterize_backward of this host thread keeps a copy of its screen-space accumulators
+ * (GradRec [N] = 16 floats per Gaussian, raw sums as the compositing backward left them, see csrc/vcr_common.h) before the
+ * projection backward consumes them; vcr_debug_read_sgrad copies the last one to HOST memory (synchronises the device).
+ * Used by profiles/grad_stage_errors.py to tell the error of the compositing backward from that of the projection backward. */
+int  vcr_debug_keep_sgrad(int on);
+int  vcr_debug_read_sgrad(float* host_out, int N);
 
 #ifdef __cplusplus
 }

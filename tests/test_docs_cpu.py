@@ -37,3 +37,27 @@ def test_every_cited_path_exists():
                 if not hit:
                     missing.append((doc, q))
     assert not missing, sorted(set(missing))
+
+
+def test_documents_quote_the_current_abi_and_switch_set():
+    """INTEGRATION.md quoted ABI 16 while header and binding were at 17.  Every `ABI <n>` / `vcr_abi_version`
+    (<n>) in the documents must be the header's number, and the switch table must list exactly the variables the code reads."""
+    hdr = open(os.path.join(ROOT, "include", "vcr_raster.h")).read()
+    abi = int(re.search(r"#define VCR_ABI_VERSION (\d+)", hdr).group(1))
+    for doc in ["INTEGRATION.md", "README.md"]:
+        text = open(os.path.join(ROOT, doc)).read()
+        for m in re.finditer(r"`vcr_abi_version` \((\d+)\)|\(ABI (\d+)\)|ABI version (\d+)", text):
+            n = int(next(g for g in m.groups() if g))
+            assert n == abi, f"{doc} quotes ABI {n}, the header says {abi}"
+    # environment variables read by the product code
+    read = set()
+    for path in glob.glob(os.path.join(ROOT, "vcr_gaus_amd", "**", "*"), recursive=True) + \
+            glob.glob(os.path.join(ROOT, "diff_gaussian_rasterization", "*.py")) + [os.path.join(ROOT, "bench.py")]:
+        if os.path.isfile(path) and path.endswith((".py", ".hip", ".h")):
+            src = open(path, errors="ignore").read()
+            read |= set(re.findall(r"(?:getenv\(|environ\.get\(|environ\[)\s*\"(VCR_[A-Z0-9_]+)\"", src))
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 4. Run-time switches"):text.index("## 5.")]
+    table = set(re.findall(r"^\| `(VCR_[A-Z0-9_]+)`", sec, flags=re.M))
+    assert read == table, f"code reads {sorted(read)}, the table lists {sorted(table)}"
+    assert len(table) <= 3

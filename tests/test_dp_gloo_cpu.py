@@ -398,3 +398,75 @@ def test_reduce_scatter_all_gather_exchange_equals_the_all_reduce(tmp_path, worl
         assert torch.allclose(rs[0][("allreduce", "params")][k], rs[0][("rs_ag", "params")][k], rtol=1e-6, atol=1e-7)
         for r in range(1, world):
             assert torch.equal(rs[r][("rs_ag", "params")][k], rs[0][("rs_ag", "params")][k])
+
+
+# ---- round 5: the bucket of the ONE-KERNEL tail under data parallelism carries ACTIVATED-space gradients --------------------
+class _NamedModel:
+    """The four geometry groups under their real names + one more group (semantic features), as `Trainer._allreduce_grads(sink=...)`
+    tells them apart."""
+
+    def __init__(self):
+        g = torch.Generator().manual_seed(1)
+        self._xyz = torch.nn.Parameter(torch.randn(N, 3, generator=g))
+        self._scaling = torch.nn.Parameter(torch.randn(N, 3, generator=g))
+        self._rotation = torch.nn.Parameter(torch.randn(N, 4, generator=g))
+        self._opacity = torch.nn.Parameter(torch.randn(N, 1, generator=g))
+        self._objects_dc = torch.nn.Parameter(torch.randn(N, 1, 2, generator=g))
+        self.optimizer = StubOptim([])
+        self.optimizer.param_groups = [{"params": [p], "lr": 0.1, "name": n} for n, p in
+                                       [("xyz", self._xyz), ("opacity", self._opacity), ("scaling", self._scaling),
+                                        ("rotation", self._rotation), ("obj_dc", self._objects_dc)]]
+
+
+def _activated_grads(view):
+    g = torch.Generator().manual_seed(900 + view)
+    return dict(xyz=torch.randn(N, 3, generator=g), scales=torch.randn(N, 3, generator=g), rots=torch.randn(N, 4, generator=g),
+                opac=torch.randn(N, 1, generator=g), nworld=torch.randn(N, 3, generator=g), obj=torch.randn(N, 1, 2, generator=g))
+
+
+def activated_worker(rank, world, port, out, with_normals):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vcr_gaus_amd.gaussian_model import GeometrySink
+    m = _NamedModel()
+    tr = Trainer(make_config("tnt"), m, list(range(8)), 1.0, torch.device("cpu"), world=world, rank=rank, seed=3)
+    tr.factorised_sh = False
+    cams = tr._next_cameras()
+    a = _activated_grads(cams[rank])
+    m._xyz.grad, m._objects_dc.grad = a["xyz"].clone(), a["obj"].clone()
+    sink = GeometrySink(armed=True)
+    sink.grads = [a["scales"].clone(), a["rots"].clone(), a["opac"].clone(), a["nworld"].clone() if with_normals else None]
+    tr._allreduce_grads(sink=sink)
+    # the raw-parameter gradients of the geometry groups do not exist in this form of the step
+    assert m._scaling.grad is None and m._rotation.grad is None and m._opacity.grad is None
+    assert (sink.grads[3] is None) == (not with_normals)
+    assert sink.grads[1].data_ptr() % 16 == 0                       # (the kernel reads the quaternion gradient as float4)
+    torch.save(dict(cams=cams, xyz=m._xyz.grad.clone(), grads=[None if t is None else t.clone() for t in sink.grads],
+                    obj=m._objects_dc.grad.clone(), scale=m.optimizer.grad_scale), out + f".{rank}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,with_normals", [(2, True), (2, False), (3, True)])
+def test_activated_space_bucket_equals_single_process_sum(tmp_path, world, with_normals):
+    """the data-parallel step exchanges the gradients w.r.t. (mean, activated scales, unit quaternion, opacity,
+    world-space axis column) -- 56 B per Gaussian -- and runs the one-kernel tail on the SUM; every rank must hold the same sums,
+    equal to one process adding up the same views, with the other groups' raw gradients riding in the same bucket."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "act.pt")
+    mp.spawn(activated_worker, args=(world, port, out, with_normals), nprocs=world, join=True)
+    rs = [torch.load(out + f".{r}") for r in range(world)]
+    tot = None
+    for v in rs[0]["cams"]:
+        a = _activated_grads(v)
+        tot = a if tot is None else {k: tot[k] + a[k] for k in a}
+    for r in rs:
+        assert r["cams"] == rs[0]["cams"] and r["scale"] == 1.0 / world
+        assert torch.equal(r["xyz"], rs[0]["xyz"]) and torch.equal(r["obj"], rs[0]["obj"])
+        for x, y in zip(r["grads"], rs[0]["grads"]):
+            assert (x is None and y is None) or torch.equal(x, y)
+    assert torch.allclose(rs[0]["xyz"], tot["xyz"], atol=1e-6) and torch.allclose(rs[0]["obj"], tot["obj"], atol=1e-6)
+    for got, k in zip(rs[0]["grads"], ("scales", "rots", "opac", "nworld")):
+        if got is None:
+            assert k == "nworld" and not with_normals
+        else:
+            assert got.shape == tot[k].shape and torch.allclose(got, tot[k], atol=1e-6), k

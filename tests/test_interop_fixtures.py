@@ -90,6 +90,32 @@ def _wire_key(group_name):
     return {"classifier.weight": "classifier.0", "classifier.bias": "classifier.1"}.get(group_name, group_name)
 
 
+def test_checkpoint_written_under_numpy_1_loads(tmp_path):
+    """The reference's environment (pytorch 2.0.1) implies numpy 1.x, whose scalars pickle as `numpy.core.multiarray.scalar`;
+    g10 was written under numpy 2 (`numpy._core...`).  The same file with the 1.x global name must load too."""
+    import zipfile
+    from vcr_gaus_amd.trainer import load_capture
+    src = os.path.join(G, "g10_chkpnt3.pth")
+    dst = str(tmp_path / "chkpnt_numpy1.pth")
+    n = 0
+    with zipfile.ZipFile(src) as zi, zipfile.ZipFile(dst, "w", zipfile.ZIP_STORED) as zo:
+        for item in zi.infolist():
+            data = zi.read(item.filename)
+            if item.filename.endswith("data.pkl"):
+                n = data.count(b"cnumpy._core.multiarray\nscalar\n")
+                data = data.replace(b"cnumpy._core.multiarray\nscalar\n", b"cnumpy.core.multiarray\nscalar\n")   # (GLOBAL opcode: newline-terminated)
+            zo.writestr(item, data)
+    assert n > 0, "fixture holds no numpy scalar any more"
+    a, it_a = load_capture(src)
+    b, it_b = load_capture(dst)
+    assert it_a == it_b and len(a) == len(b)
+    for x, y in zip(a, b):
+        if torch.is_tensor(x):
+            assert torch.equal(x, y)
+        elif not isinstance(x, dict):
+            assert x == y or (x != x and y != y)
+
+
 def test_reference_checkpoint_restores_into_this_model():
     m, ckpt, it, nxt, cfg = _restored("cpu")
     assert it == 3 and m.active_sh_degree == 2 and abs(m.spatial_lr_scale - 2.5) < 1e-12

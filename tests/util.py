@@ -218,7 +218,7 @@ def sampled_tile_parity(device, cam, inp, dirs, bg, stride, min_inst, name, min_
     (zero outside the subset).  Gaussians under a flipped pixel (< 5 %, asserted) are left out of the gradient check.
     `own_yardstick`: for scenes the tabulated "full" yardstick was not measured on (a TRAINED model: needle-shaped Gaussians
     whose fp32 conic carries far more rounding than the synthetic blobs'), the oracle is also evaluated in fp32 on the same
-    subset and the max-norm tolerance of a tensor becomes max(table, 3 x the fp32 oracle's own max-norm error)."""
+    subset and every figure of a tensor's tolerance (max-norm, p99, p99.9) becomes max(table, 3 x the fp32 oracle's own)."""
     n = inp["means3D"].shape[0]
     H, W = cam.image_height, cam.image_width
     (out, radii), hl = hip_forward(cam, inp, dirs, bg, device, requires_grad=True)
@@ -269,10 +269,15 @@ def sampled_tile_parity(device, cam, inp, dirs, bg, stride, min_inst, name, min_
     (out * wgt.float().to(device)).sum().backward()
 
     def tol(k, a, b):
+        """own yardstick: every figure of the tensor's tolerance becomes max(table, 3 x the fp32 oracle's own error on this
+        subset) -- max-norm AND the element-wise quantiles (round 4 widened the max-norm only, and the trained scene's p99.9
+        sat within 4 % of a tolerance measured on synthetic blobs)"""
+        t = grad_tolerance(k, "full")
         if l32 is None:
-            return None
-        own = grad_stats(a, b)["maxnorm"]
-        return max(grad_tolerance(k, "full")[0], 3.0 * own)
+            return dict(maxnorm_tol=t[0], p99_tol=t[1], p999_tol=t[2])
+        own = grad_stats(a, b)
+        return dict(maxnorm_tol=max(t[0], 3.0 * own["maxnorm"]), p99_tol=max(t[1], 3.0 * own["p99"]),
+                    p999_tol=max(t[2], 3.0 * own["p999"]))
 
     for k in ["means3D", "shs", "normals", "opac", "scales", "rots", "m2", "sem"]:
         if rl.get(k) is None or hl[k] is None:
@@ -280,7 +285,7 @@ def sampled_tile_parity(device, cam, inp, dirs, bg, stride, min_inst, name, min_
         gfull = hl[k].grad.cpu()
         assert float(gfull[~hit].abs().max()) == 0.0 if (~hit).any() else True, f"{k}: gradient outside the sampled subset"
         assert_grads_close(gfull[hit][clean], rl[k].grad[clean], f"{name}:{k}", regime="full",
-                           maxnorm_tol=tol(k, l32[k].grad[clean], rl[k].grad[clean]) if l32 is not None else None)
+                           **tol(k, l32[k].grad[clean] if l32 is not None else None, rl[k].grad[clean]))
     assert_grads_close(hl["m2d"].grad.cpu()[hit][clean][:, :2], rl["m2d"].grad[clean][:, :2], f"{name}:m2d", regime="full",
-                       maxnorm_tol=tol("m2d", l32["m2d"].grad[clean][:, :2], rl["m2d"].grad[clean][:, :2]) if l32 is not None else None)
+                       **tol("m2d", l32["m2d"].grad[clean][:, :2] if l32 is not None else None, rl["m2d"].grad[clean][:, :2]))
     return dict(instances=inst, flipped=bad, sampled_pixels=int(o.shape[1]), subset=int(hit.sum()))

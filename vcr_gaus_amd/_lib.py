@@ -16,7 +16,7 @@ c_int_p = C.POINTER(C.c_int32)
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 BUF_GEOM, BUF_BINNING, BUF_IMAGE, BUF_SCRATCH = 0, 1, 2, 3
-ABI_VERSION = 17         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
+ABI_VERSION = 18         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
 
 
 class VcrShUpdate(C.Structure):
@@ -29,11 +29,11 @@ class VcrShUpdate(C.Structure):
 
 
 class VcrGeometryStep(C.Structure):
-    _fields_ = [(k, C.c_int32) for k in ("N", "pad_", "step_xyz", "step_scaling", "step_rotation", "step_opacity")] + [(k, C.c_void_p) for k in (
+    _fields_ = [(k, C.c_int32) for k in ("N", "normals_world", "step_xyz", "step_scaling", "step_rotation", "step_opacity")] + [(k, C.c_void_p) for k in (
         "xyz", "scaling", "rotation", "opacity", "d_means3D", "d_scales", "d_rots", "d_opac", "d_normals", "aux", "Rw2c",
         "scale_reg_gout", "scale_reg_sums", "trans", "scale", "m_xyz", "v_xyz", "m_scaling", "v_scaling", "m_rotation",
         "v_rotation", "m_opacity", "v_opacity")] + [(k, C.c_float) for k in (
-            "lr_xyz", "lr_scaling", "lr_rotation", "lr_opacity", "beta1", "beta2", "eps")] + [(k, C.c_void_p) for k in (
+            "lr_xyz", "lr_scaling", "lr_rotation", "lr_opacity", "beta1", "beta2", "eps", "grad_scale")] + [(k, C.c_void_p) for k in (
                 "grad2d", "radii", "accum", "denom", "max_radii", "next_campos", "next_Rw2c", "next_scales", "next_rots",
                 "next_opac", "next_normals", "next_aux")]
 
@@ -82,11 +82,11 @@ class VcrVisibilityBatch(C.Structure):
 class VcrBackwardIO(C.Structure):
     _fields_ = [
         ("dL_dout", C.c_void_p), ("geom", C.c_void_p), ("binning", C.c_void_p), ("image", C.c_void_p),
-        ("radii", C.c_void_p), ("num_rendered", C.c_int64),
+        ("radii", C.c_void_p), ("num_rendered", C.c_int64), ("num_emitted", C.c_int64),
         ("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dmeans2D_densify", C.c_void_p),
         ("dL_dshs", C.c_void_p), ("dL_dshs_rest", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_drgb", C.c_void_p), ("view_dirs", C.c_void_p), ("dL_dnormals", C.c_void_p),
         ("dL_dsemantics", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
-        ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
+        ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("normals_Rw2c", C.c_void_p), ("normals_aux", C.c_void_p),
     ]
 
 
@@ -153,6 +153,8 @@ SYMBOLS = {
     "vcr_profile_num_stages": (C.c_int, []),
     "vcr_profile_read": (C.c_int, [c_float_p, c_int_p, C.c_int]),
     "vcr_debug_hit_histogram": (C.c_int, [C.POINTER(C.c_uint32), C.c_int]),
+    "vcr_debug_keep_sgrad": (C.c_int, [C.c_int]),
+    "vcr_debug_read_sgrad": (C.c_int, [C.c_void_p, C.c_int]),
 }
 STAGES = ["preprocess", "depth_sort_scan", "binning", "composite_fwd", "composite_bwd", "preprocess_bwd"]
 

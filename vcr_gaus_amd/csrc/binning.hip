@@ -27,11 +27,13 @@ constexpr int DUP_ROUNDS = 4;                       // Gaussians per thread: 102
 //   * masked rectangles (<= 32 tiles, nearly all): every lane walks the set bits of ITS mask -- a handful of iterations;
 //   * unmasked giants: wave-cooperatively and load-balanced -- the wave's giant counts are prefix-summed in LDS and every
 //     lane binary-searches the Gaussian its slot belongs to, so a screen-filling Gaussian does not serialise a lane.
-// `status`: one zeroed 64-bit word per block; `ticket`: one zeroed word.
+// `status`: one 64-bit word per block, [call number `seq`: 30 bits | flag: 2 | value: 32] -- the buffer is library-owned and is
+// NOT cleared between calls (round 5): a word counts only if it carries this call's number (anything an earlier call left
+// reads as "not there yet"); `ticket`: one word, zero between calls (the block that draws the last ticket resets it).
 template <bool QL>      // QL: 64-bit cell masks (upper word in rect_hi); the per-tile form compiles to its 32-bit walk
 __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, const uint32_t* __restrict__ ids_sorted,
                                                         unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket,
-                                                        const uint2* __restrict__ rect, const uint32_t* __restrict__ rect_hi,
+                                                        uint32_t seq, const uint2* __restrict__ rect, const uint32_t* __restrict__ rect_hi,
                                                         uint2* __restrict__ inst_out, uint2* __restrict__ ranges, int num_tiles,
                                                         int gx_keys) {
     __shared__ uint32_t s_gend[4][64], s_start[4][64], s_id[4][64];
@@ -40,9 +42,13 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int gx = gx_keys;                             // keys per row: tiles, or 8x8 cells in quad-list mode (rect is in the same unit)
     for (int t = blockIdx.x * 256 + threadIdx.x; t < num_tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);   // empty tiles
-    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+    if (threadIdx.x == 0) {
+        s_bid = atomicAdd(ticket, 1u);
+        if (s_bid == gridDim.x - 1) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every ticket is out
+    }
     __syncthreads();
     const int bid = (int)s_bid;
+    const unsigned long long tag = (unsigned long long)seq << 34;
     // round r of this block covers the Gaussians base + r*256 + tid of the depth order
     const int base = bid * (256 * DUP_ROUNDS);
     uint32_t id[DUP_ROUNDS], cnt[DUP_ROUNDS], inc[DUP_ROUNDS], mhi[DUP_ROUNDS];
@@ -75,15 +81,16 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
     if (wv == 0) {                                       // decoupled look-back by the first wave
         uint32_t excl = 0;
         if (bid > 0) {
-            if (lane == 0) __hip_atomic_store(status + bid, ST_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(status + bid, tag | ST_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int look = bid - 1;
             for (;;) {
                 const int b = look - lane;
                 unsigned long long sv = ST_PREFIX;        // lanes past block 0 count as a zero prefix
                 if (b >= 0) {
-                    do { sv = __hip_atomic_load(status + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((sv >> 32) == 0);
+                    do { sv = __hip_atomic_load(status + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    while ((sv >> 34) != (unsigned long long)seq || ((sv >> 32) & 3ull) == 0);
                 }
-                const unsigned long long pm = __builtin_amdgcn_ballot_w64((sv >> 32) == 2);
+                const unsigned long long pm = __builtin_amdgcn_ballot_w64(((sv >> 32) & 3ull) == 2);
                 const int first = pm ? __builtin_ctzll(pm) : 64;                 // nearest block with a full prefix
                 uint32_t v = lane <= first ? (uint32_t)sv : 0u;
                 for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
@@ -93,7 +100,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
             }
         }
         if (lane == 0) {
-            __hip_atomic_store(status + bid, ST_PREFIX | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(status + bid, tag | ST_PREFIX | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_prefix = excl;
         }
     }
@@ -176,8 +183,8 @@ size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits) {
     return vcr_align(b0 > b2 ? b0 : b2);
 }
 
-// look-back status words of the emission kernel (+ its ticket word at the end), zeroed by the caller
-size_t vcr_duplicate_status_bytes(int N) { return vcr_align(sizeof(unsigned long long) * (size_t)((N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS) + 2)); }
+// look-back status words of the emission kernel
+size_t vcr_duplicate_status_words(int N) { return (size_t)((N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS) + 2); }
 
 // depth order of the N Gaussians (ties by index): three stable passes over the 27 low bits of the depth keys (see vcr_common.h).
 // (pair_a, pair_b): N 8-byte records each -- pair_a holds the (key, id) records in that order afterwards; `totals`:
@@ -202,15 +209,15 @@ int vcr_depth_sort_far(int N, uint2* pair_a, uint32_t* ids_sorted, uint32_t* tot
 // NULL when the tile bits take at most two passes); keys_b / point_list: the sorted result.
 // R: the number of instances the emission kernel writes (the host's read-back of the projection kernel's count).
 int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const uint32_t* ids_sorted,
-                           unsigned long long* status, int64_t R, int tile_bits, uint2* inst, uint2* pair_a, uint2* pair_b,
+                           unsigned long long* status, uint32_t* ticket, uint32_t seq, int64_t R, int tile_bits, uint2* inst,
+                           uint2* pair_a, uint2* pair_b,
                            uint32_t* keys_b, uint32_t* point_list, uint2* ranges, uint32_t* tile_order, uint32_t* meta,
                            int num_tiles, uint32_t* totals, void* temp, size_t temp_bytes, hipStream_t st) {
 #ifdef VCR_DETERMINISTIC_BWD
     const bool no_lpt = true, no_snake = true;       // test-only build: identity launch order (the counting sort of tile_order
                                                      // places tiles of equal length in the order its LDS atomics resolve)
 #else
-    static const bool no_lpt = getenv("VCR_NO_LPT") != nullptr;          // experiment switches
-    static const bool no_snake = getenv("VCR_NO_SNAKE") != nullptr;
+    const bool no_lpt = false, no_snake = false;     // (longest-first, folded launch order: DESIGN.md section 4 holds the A/B)
 #endif
     const int gx_tiles = (a.W + VCR_TILE - 1) / VCR_TILE;
     const bool ql = a.quad_lists != 0;
@@ -220,12 +227,11 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
         return vcr_launch_tile_order(num_tiles, ranges, tile_order, meta, 0, false, false, st, ql ? gx_keys : 0);   // identity order
     }
     const int blocks = (a.N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS);
-    uint32_t* ticket = reinterpret_cast<uint32_t*>(status + blocks + 1);
     if (ql)
-        hipLaunchKernelGGL(duplicate_kernel<true>, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, ticket, g.rect,
+        hipLaunchKernelGGL(duplicate_kernel<true>, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, ticket, seq, g.rect,
                            g.rect_hi, inst, ranges, num_keys, gx_keys);
     else
-        hipLaunchKernelGGL(duplicate_kernel<false>, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, ticket, g.rect,
+        hipLaunchKernelGGL(duplicate_kernel<false>, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, ticket, seq, g.rect,
                            g.rect_hi, inst, ranges, num_keys, gx_keys);
     VCR_HIP_CHECK(hipGetLastError());
     if (vcr_sort_pairs(R, nullptr, nullptr, inst, pair_a, pair_b, keys_b, point_list, 0, tile_bits, (uint32_t*)temp, totals, st,

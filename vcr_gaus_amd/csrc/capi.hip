@@ -44,13 +44,8 @@ struct StageTimer {
     }
 };
 
-// device counters of one forward call, zeroed by ONE memset together with the emission kernel's look-back words:
-// visible-count slots and tile-instance-count slots
-#define VCR_CTR_WORDS (3 * VCR_VIS_SLOTS + 64)          // + the `far` flag word (vcr_common.h)
 struct Readback { uint32_t V[VCR_VIS_SLOTS]; uint32_t R[VCR_VIS_SLOTS]; };
-// what the host polls: totals + a sequence number published by the device AFTER the totals (system-scope fence).
-// R: tile instances of the 3-sigma rectangles (what the reference counts), E: instances really emitted (exact rejection)
-struct Published { unsigned long long R, E; uint32_t V; uint32_t far; volatile uint32_t seq; };
+typedef VcrPublished Published;      // (vcr_common.h: published by the projection's last workgroup)
 
 Published* pinned_published() {
     static thread_local Published* p = nullptr;
@@ -62,27 +57,76 @@ Published* pinned_published() {
     return p;
 }
 
-// One block: fold the counter slots and publish the totals to pinned host memory.  The host spins on `seq` instead of
-// sleeping in hipEventSynchronize, whose wake-up latency (interrupt path) can exceed the ~0.15 ms of sort work that is
-// queued behind this kernel to cover it.
-__global__ void __launch_bounds__(256) publish_counts_kernel(const uint32_t* __restrict__ slots, Published* host, uint32_t seq) {
-    __shared__ unsigned long long s_r[4], s_e[4];
-    __shared__ uint32_t s_v[4];
-    unsigned long long r = 0, e = 0; uint32_t v = 0;
-    for (int k = threadIdx.x; k < VCR_VIS_SLOTS; k += 256) { v += slots[k]; r += slots[VCR_VIS_SLOTS + k]; e += slots[2 * VCR_VIS_SLOTS + k]; }
-    for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o); r += __shfl_xor(r, o); e += __shfl_xor(e, o); }
-    if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = v; s_r[threadIdx.x >> 6] = r; s_e[threadIdx.x >> 6] = e; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        host->R = s_r[0] + s_r[1] + s_r[2] + s_r[3];
-        host->E = s_e[0] + s_e[1] + s_e[2] + s_e[3];
-        host->V = s_v[0] + s_v[1] + s_v[2] + s_v[3];
-        host->far = slots[VCR_FAR_FLAG_WORD];
-        __threadfence_system();
-        host->seq = seq;
+// ---- library-owned device scratch (round 5) ------------------------------------------------------------------------------
+// Small state that used to be carved out of the caller's per-call scratch and cleared by a memset launch in front of every call:
+//   * `ctr`: the projection's counter block (vcr_common.h) -- zero between calls, the kernels clean up after themselves;
+//   * `status`: look-back words of the emission kernel, tagged with `seq` instead of being cleared;
+//   * `grad`: the backward's per-Gaussian accumulators (GradRec [N] + semantic gradients) -- zero between calls, the projection
+//     backward clears every record behind its own read (was a 64 B x N memset per backward).
+// One set per (host thread, stream): calls on one stream are ordered, calls on different streams get different sets (a forward
+// call returns only after its projection has published, but its emission kernel and a backward run asynchronously).  `dirty`
+// flags make the next call clear a block that a failed call may have left half-used.
+struct StreamScratch {
+    uint32_t* ctr = nullptr; bool ctr_dirty = true;
+    unsigned long long* status = nullptr; size_t status_words = 0;
+    uint32_t seq = 0;
+    char* grad = nullptr; size_t grad_bytes = 0; bool grad_dirty = true;
+};
+constexpr uint32_t SEQ_MAX = (1u << 30) - 1u;
+
+struct ScratchMap {
+    std::vector<std::pair<hipStream_t, StreamScratch*>> sets;
+    ~ScratchMap() {}                 // (process exit: the runtime may already be gone -- nothing is freed here)
+};
+
+StreamScratch* stream_scratch(hipStream_t st) {
+    static thread_local ScratchMap m;
+    for (auto& kv : m.sets) if (kv.first == st) return kv.second;
+    if (m.sets.size() >= 64) {       // a caller cycling through streams: start over (hipFree synchronises the device)
+        for (auto& kv : m.sets) { (void)hipFree(kv.second->ctr); (void)hipFree(kv.second->status); (void)hipFree(kv.second->grad); delete kv.second; }
+        m.sets.clear();
     }
+    StreamScratch* sc = new StreamScratch();
+    if (hipMalloc((void**)&sc->ctr, sizeof(uint32_t) * VCR_CTR_WORDS) != hipSuccess) { delete sc; return nullptr; }
+    m.sets.emplace_back(st, sc);
+    return sc;
 }
 
+// counter block ready (zero) + status words for `words` look-back entries; advances the call number.  Stream-ordered.
+int scratch_begin_forward(StreamScratch* sc, size_t words, hipStream_t st) {
+    if (sc->ctr_dirty) { VCR_HIP_CHECK(hipMemsetAsync(sc->ctr, 0, sizeof(uint32_t) * VCR_CTR_WORDS, st)); }
+    sc->ctr_dirty = true;            // until this call's projection has published (it then left the block zero)
+    if (words > sc->status_words) {
+        if (sc->status) VCR_HIP_CHECK(hipFree(sc->status));
+        sc->status = nullptr; sc->status_words = 0;
+        const size_t cap = words + words / 4 + 64;
+        VCR_HIP_CHECK(hipMalloc((void**)&sc->status, sizeof(unsigned long long) * cap));
+        VCR_HIP_CHECK(hipMemsetAsync(sc->status, 0, sizeof(unsigned long long) * cap, st));
+        sc->status_words = cap;
+        sc->seq = 0;
+    }
+    if (sc->seq >= SEQ_MAX) {        // the 30-bit call number wraps: clear the tags once
+        VCR_HIP_CHECK(hipMemsetAsync(sc->status, 0, sizeof(unsigned long long) * sc->status_words, st));
+        sc->seq = 0;
+    }
+    ++sc->seq;
+    return 0;
+}
+
+// accumulators of `bytes` bytes, zero.  Stream-ordered.
+int scratch_begin_backward(StreamScratch* sc, size_t bytes, hipStream_t st) {
+    if (bytes > sc->grad_bytes) {
+        if (sc->grad) VCR_HIP_CHECK(hipFree(sc->grad));
+        sc->grad = nullptr; sc->grad_bytes = 0;
+        const size_t cap = vcr_align(bytes + bytes / 4);
+        VCR_HIP_CHECK(hipMalloc((void**)&sc->grad, cap));
+        sc->grad_bytes = cap;
+        sc->grad_dirty = true;
+    }
+    if (sc->grad_dirty) { VCR_HIP_CHECK(hipMemsetAsync(sc->grad, 0, sc->grad_bytes, st)); }
+    sc->grad_dirty = true;           // until both kernels of this backward have been accepted
+    return 0;
+}
 
 Readback* pinned_readback() {
     static thread_local Readback* p = nullptr;
@@ -144,41 +188,6 @@ int validate(const VcrRasterArgs* a) {
     return 0;
 }
 
-// Diagnostics (VCR_HOST_TRACE=1): wall-clock of the HOST inside vcr_rasterize_forward, split at the points named below; the mean
-// of every 200 calls goes to stderr.  "spin" near zero means the host arrives late at the hand-over (host-bound), a large value
-// means it waits for the device there.
-struct HostTrace {
-    enum { ENTRY = 0, PROJECTION, SIDE, PUBLISH, DEPTH_SORT, SPIN, ALLOC, BINNING, COMPOSITE, NSEG };
-    bool on = getenv("VCR_HOST_TRACE") != nullptr;
-    double acc[NSEG] = {};
-    double between = 0;                                 // from the return of one call to the entry of the next
-    int calls = 0;
-    std::chrono::steady_clock::time_point t, t_exit;
-    bool have_exit = false;
-    void begin() {
-        if (!on) return;
-        t = std::chrono::steady_clock::now();
-        if (have_exit) between += std::chrono::duration<double, std::micro>(t - t_exit).count();
-    }
-    void mark(int k) {
-        if (!on) return;
-        const auto n = std::chrono::steady_clock::now();
-        acc[k] += std::chrono::duration<double, std::micro>(n - t).count();
-        t = n;
-    }
-    void end() {
-        if (!on) return;
-        t_exit = std::chrono::steady_clock::now(); have_exit = true;
-        if (++calls == 200) {
-            static const char* names[NSEG] = {"entry+alloc", "projection", "side-stream", "publish", "depth-sort", "spin", "alloc", "binning", "composite"};
-            fprintf(stderr, "[vcr host trace, us per forward]");
-            for (int k = 0; k < NSEG; ++k) { fprintf(stderr, " %s %.1f", names[k], acc[k] / calls); acc[k] = 0; }
-            fprintf(stderr, " | between-calls %.1f\n", between / calls);
-            between = 0; calls = 0;
-        }
-    }
-};
-thread_local HostTrace g_ht;
 
 int tile_bits_for(int T) {
     int b = 1;
@@ -227,7 +236,6 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
     if ((a.f_count == 1 || a.f_count == 2) && !out->score) { vcr_set_error("score buffer is NULL"); return 1; }
     out->num_rendered = 0; out->num_visible = 0; out->max_tile_len = -1; out->num_emitted = -1;
     out->geom = out->binning = out->image = nullptr;
-    g_ht.begin();
 
     void* geom_p = alloc(user, VCR_BUF_GEOM, GeomState::bytes(N > 0 ? N : 1, a.S));
     void* img_p = alloc(user, VCR_BUF_IMAGE, ImageState::bytes(P));
@@ -242,24 +250,23 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         const int tbits = tile_bits_for(T) + (a.quad_lists ? 2 : 0);      // (quad lists: the key is the 8x8 cell)
         const size_t tmp1 = vcr_binning_temp_bytes(N, 0, tbits);
         const size_t nb = vcr_align(sizeof(uint32_t) * (size_t)N);
-        const size_t ctr_bytes = vcr_align(sizeof(uint32_t) * VCR_CTR_WORDS);
-        const size_t status_bytes = vcr_duplicate_status_bytes(N);       // look-back words + ticket of the emission kernel, zeroed with the counters
         const size_t tot_bytes = vcr_align(sizeof(uint32_t) * 2 * VCR_SORT_TOTALS_WORDS);   // digit totals of the two sorts (not zeroed)
-        // [depth keys | depth order | two buffers of 8-byte (key, id) records for the sort's passes | counters ...]
-        char* s1 = (char*)alloc(user, VCR_BUF_SCRATCH, 6 * nb + ctr_bytes + status_bytes + tot_bytes + tmp1);
+        // [depth keys | depth order | two buffers of 8-byte (key, id) records for the sort's passes | digit totals | sort scratch]
+        char* s1 = (char*)alloc(user, VCR_BUF_SCRATCH, 6 * nb + tot_bytes + tmp1);
         if (!s1) { vcr_set_error("allocator returned NULL"); return 1; }
+        StreamScratch* sc = stream_scratch(st);          // counters + look-back words: library-owned, no memset launch (round 5)
+        if (!sc) { vcr_set_error("hipMalloc for the counter block failed"); return 1; }
+        if (scratch_begin_forward(sc, vcr_duplicate_status_words(N), st)) return 1;
         uint32_t* depth_key = (uint32_t*)s1;
         uint32_t* ids_sorted = (uint32_t*)(s1 + nb);
         uint2* pair_a = (uint2*)(s1 + 2 * nb);
         uint2* pair_b = (uint2*)(s1 + 4 * nb);
         uint32_t* ids = nullptr;                               // (unused by the projection kernel)
-        uint32_t* ctr = (uint32_t*)(s1 + 6 * nb);
-        unsigned long long* dup_status = (unsigned long long*)(s1 + 6 * nb + ctr_bytes);
-        uint32_t* vis_counter = ctr;
-        uint32_t* totals_depth = (uint32_t*)(s1 + 6 * nb + ctr_bytes + status_bytes);
+        unsigned long long* dup_status = sc->status;
+        uint32_t* vis_counter = sc->ctr;
+        uint32_t* totals_depth = (uint32_t*)(s1 + 6 * nb);
         uint32_t* totals_tile = totals_depth + VCR_SORT_TOTALS_WORDS;
-        void* temp1 = s1 + 6 * nb + ctr_bytes + status_bytes + tot_bytes;
-        VCR_HIP_CHECK(hipMemsetAsync(ctr, 0, ctr_bytes + status_bytes, st));
+        void* temp1 = s1 + 6 * nb + tot_bytes;
         // Work launched on the optional streams must be joined on EVERY exit (the scratch buffers go back to the caller's
         // stream-ordered allocator when this call returns): error returns go through join_streams().
         bool sort_launched = false, colour_launched = false;
@@ -277,7 +284,6 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
                 return join_streams();                                                                  \
             }                                                                                           \
         } while (0)
-        g_ht.mark(HostTrace::ENTRY);
         // optional sort stream: depth keys + depth sort of the N Gaussians start now, beside the projection
         const bool split_sort = a.sort_stream && a.sort_stream != stream;
         if (split_sort) {
@@ -303,14 +309,21 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         // two-stream form: geometry here, SH -> RGB on the colour stream behind whatever the caller queued there
         const bool split_colour = a.colour_stream && a.colour_stream != stream && a.shs && !a.colors_precomp;
         if (a.sh_update && !split_colour) { vcr_set_error("sh_update needs colour_stream and SH colours"); return join_streams(); }
+        // R, E and V go back to the host from the projection's last workgroup (no publish kernel, round 5); the depth sort and
+        // the offsets scan do not need them and keep the GPU busy while the host wakes up, sizes the instance buffers and
+        // enqueues the rest
+        Readback* rb = pinned_readback();
+        Published* pub = pinned_published();
+        if (!rb || !pub) { vcr_set_error("hipHostMalloc for the readback failed"); return join_streams(); }
+        static thread_local uint32_t seq_counter = 0;
+        const uint32_t seq = ++seq_counter ? seq_counter : ++seq_counter;      // never 0
         {
             StageTimer tm(ST_PREPROCESS, st);
             // (count-only modes 3 / 4 never read a colour: geometry-only projection, 36 against 105 us at 1 M Gaussians)
             const bool colour_here = !split_colour && a.f_count != 3 && a.f_count != 4;
-            if (vcr_launch_preprocess(a, g, out->radii, split_sort ? nullptr : depth_key, ids, vis_counter, colour_here, st))
+            if (vcr_launch_preprocess(a, g, out->radii, split_sort ? nullptr : depth_key, ids, vis_counter, colour_here, st, pub, seq))
                 return join_streams();
         }
-        g_ht.mark(HostTrace::PROJECTION);
         if (split_colour) {
             hipEvent_t e_geo = colour_event(0), e_col = colour_event(1);
             if (!e_geo || !e_col) { vcr_set_error("hipEventCreate for the colour stream failed"); return join_streams(); }
@@ -328,19 +341,8 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             }
             if (rc) return join_streams();
         }
-        g_ht.mark(HostTrace::SIDE);
-        // R and V go back to the host now; the depth sort and the offsets scan do not need them and keep the GPU busy
-        // while the host wakes up, sizes the instance buffers and enqueues the rest
-        Readback* rb = pinned_readback();
-        Published* pub = pinned_published();
-        if (!rb || !pub) { vcr_set_error("hipHostMalloc for the readback failed"); return join_streams(); }
-        static thread_local uint32_t seq_counter = 0;
-        const uint32_t seq = ++seq_counter ? seq_counter : ++seq_counter;      // never 0
-        hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(256), 0, st, vis_counter, pub, seq);
-        VCR_HIP_CHECK_JOIN(hipGetLastError());
-        // (no event behind the publish kernel: a marker packet between it and the depth sort costs the main stream ~10 us per
+        // (no event behind the projection: a marker packet between it and the depth sort costs the main stream ~10 us per
         //  step; the slow path of the hand-over below drains the stream instead)
-        g_ht.mark(HostTrace::PUBLISH);
         if (!split_sort) {
             StageTimer tm(ST_DEPTHSORT, st);
             if (vcr_depth_sort(N, depth_key, pair_a, pair_b, ids_sorted, totals_depth, temp1, st)) return join_streams();
@@ -348,7 +350,6 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         // From here on the colour stream may already be running work that consumed the caller's pending SH update: every
         // error return below first joins it (the caller's retry / error handling must not see an un-joined stream).
         auto fail_joined = join_streams;
-        g_ht.mark(HostTrace::DEPTH_SORT);
         {   // spin on the published sequence number for at most ~2 ms of wall time, then sleep in a stream synchronisation (which
             // also surfaces a device fault or a failed launch as an error instead of a hang)
             const auto t_spin = std::chrono::steady_clock::now();
@@ -367,7 +368,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             if (pub->seq != seq) { vcr_set_error("device did not publish the instance count"); return fail_joined(); }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
         }
-        g_ht.mark(HostTrace::SPIN);
+        sc->ctr_dirty = false;                              // (published: the last workgroup has left the counter block zero)
         R = (int64_t)pub->R;
         const int64_t E = (int64_t)pub->E;                  // what the emission kernel will write: sizes everything below
         if (pub->far) {          // a visible Gaussian beyond the 27-bit key range: one more pass over the upper key bits, behind the sort
@@ -380,10 +381,12 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         out->num_emitted = E;
         if (R >= (1ll << 32)) { vcr_set_error("more than 2^32 tile instances"); return fail_joined(); }
 
-        void* bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(E, T));
+        const bool with_ckpt = a.f_count == 0;              // training forward: per-chunk transmittance checkpoints for the backward
+        void* bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(E, T, with_ckpt));
         if (!bin_p) { vcr_set_error("allocator returned NULL"); return fail_joined(); }
         BinState b = BinState::view(bin_p, T);
         out->binning = bin_p;
+        im.t_ckpt = with_ckpt ? BinState::ckpt_of(bin_p, E, T) : nullptr;
         const size_t tmp2 = vcr_binning_temp_bytes(N, E, tbits);
         const size_t rbts = vcr_align(sizeof(uint32_t) * (size_t)(E > 0 ? E : 1));
         const bool third = vcr_sort_passes(tbits) > 2;      // (more than 16 tile bits: a second intermediate buffer)
@@ -391,20 +394,20 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         char* s2 = (char*)alloc(user, VCR_BUF_SCRATCH, (third ? 7 : 5) * rbts + tmp2);
         if (!s2) { vcr_set_error("allocator returned NULL"); return fail_joined(); }
         if (split_sort) VCR_HIP_CHECK_JOIN(hipStreamWaitEvent(st, colour_event(3), 0));  // the depth order is needed from here on
-        g_ht.mark(HostTrace::ALLOC);
         {
             StageTimer tm(ST_BINNING, st);
-            if (vcr_duplicate_and_sort(a, g, out->radii, ids_sorted, dup_status, E, tbits, (uint2*)s2, (uint2*)(s2 + 2 * rbts),
+            if (vcr_duplicate_and_sort(a, g, out->radii, ids_sorted, dup_status, sc->ctr + VCR_DUP_TICKET_WORD, sc->seq, E, tbits,
+                                       (uint2*)s2, (uint2*)(s2 + 2 * rbts),
                                        third ? (uint2*)(s2 + 5 * rbts) : nullptr, (uint32_t*)(s2 + 4 * rbts),
                                        b.point_list, b.ranges, b.tile_order, b.meta, T, totals_tile, s2 + (third ? 7 : 5) * rbts, tmp2, st))
                 return fail_joined();
         }
-        g_ht.mark(HostTrace::BINNING);
         out->num_rendered = R;
         if (a.debug) {                       // diagnostics only: longest per-tile list (one extra sync)
             VCR_HIP_CHECK_JOIN(hipMemsetAsync(vis_counter, 0, sizeof(uint32_t), st));
             hipLaunchKernelGGL(max_tile_len_kernel, dim3(32), dim3(256), 0, st, a.quad_lists ? 4 * T : T, b.ranges, vis_counter);
             VCR_HIP_CHECK_JOIN(hipMemcpyAsync(&rb->R[0], vis_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            VCR_HIP_CHECK_JOIN(hipMemsetAsync(vis_counter, 0, sizeof(uint32_t), st));          // (the block stays zero between calls)
             VCR_HIP_CHECK_JOIN(hipStreamSynchronize(st));
             out->max_tile_len = (int32_t)rb->R[0];
         }
@@ -413,8 +416,6 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             StageTimer tm(ST_COMPOSITE_FWD, st);
             if (vcr_launch_composite_forward(a, g, b, im, *out, st)) return fail_joined();
         }
-        g_ht.mark(HostTrace::COMPOSITE);
-        g_ht.end();
 #undef VCR_HIP_CHECK_JOIN
     } else {
         void* bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(0, T));
@@ -443,6 +444,7 @@ struct VisPool {
     hipStream_t st[VIS_STREAMS] = {};
     hipEvent_t fork = nullptr, join[VIS_STREAMS] = {};
     Published* pub = nullptr;                       // VIS_MAX_SETS pinned slots
+    StreamScratch sc[VIS_MAX_SETS];                 // counter block + look-back words of every buffer set (library-owned)
     bool ok = false;
 };
 
@@ -456,6 +458,8 @@ VisPool* vis_pool() {
         if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipHostMalloc((void**)&p.pub, sizeof(Published) * VIS_MAX_SETS, hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) return nullptr;
         memset(p.pub, 0, sizeof(Published) * VIS_MAX_SETS);
+        for (int k = 0; k < VIS_MAX_SETS; ++k)
+            if (hipMalloc((void**)&p.sc[k].ctr, sizeof(uint32_t) * VCR_CTR_WORDS) != hipSuccess) return nullptr;
         p.ok = true;
     }
     return &p;
@@ -485,7 +489,7 @@ struct VisSet {                   // buffers of one camera in flight; re-used by
     char* s1 = nullptr;
     int32_t* radii = nullptr;
     void* bin = nullptr; char* s2 = nullptr; int64_t cap = -1;      // instance-count dependent: grown on demand
-    uint32_t seq = 0;
+    uint32_t seq = 0, dseq = 0;                                     // publish number; tag of the emission kernel's look-back words
 };
 
 }  // namespace
@@ -517,10 +521,8 @@ extern "C" int vcr_visibility_batch(const VcrVisibilityBatch* vb, vcr_alloc_fn a
     // per-set buffer layout: as in vcr_rasterize_forward (no image state: the count modes do not write one)
     const size_t tmp1 = vcr_binning_temp_bytes(N, 0, tbits);
     const size_t nb = vcr_align(sizeof(uint32_t) * (size_t)N);
-    const size_t ctr_bytes = vcr_align(sizeof(uint32_t) * VCR_CTR_WORDS);
-    const size_t status_bytes = vcr_duplicate_status_bytes(N);
     const size_t tot_bytes = vcr_align(sizeof(uint32_t) * 2 * VCR_SORT_TOTALS_WORDS);
-    const size_t s1_bytes = 7 * nb + ctr_bytes + status_bytes + tot_bytes + tmp1;           // (+ nb: the radii of this camera)
+    const size_t s1_bytes = 7 * nb + tot_bytes + tmp1;           // (+ nb: the radii of this camera)
     VisSet vs[VIS_MAX_SETS];
     for (int k = 0; k < sets; ++k) {
         vs[k].geom = alloc(user, VCR_BUF_SCRATCH, GeomState::bytes(N, 0));
@@ -560,14 +562,13 @@ extern "C" int vcr_visibility_batch(const VcrVisibilityBatch* vb, vcr_alloc_fn a
             GeomState g = GeomState::view(v.geom, N, 0);
             uint32_t* depth_key = (uint32_t*)v.s1;
             uint32_t* ids_sorted = (uint32_t*)(v.s1 + nb);
-            uint32_t* ctr = (uint32_t*)(v.s1 + 7 * nb);
-            uint32_t* totals_depth = (uint32_t*)(v.s1 + 7 * nb + ctr_bytes + status_bytes);
-            void* temp1 = v.s1 + 7 * nb + ctr_bytes + status_bytes + tot_bytes;
-            if (hipMemsetAsync(ctr, 0, ctr_bytes + status_bytes, cs) != hipSuccess) { vcr_set_error("visibility batch: memset failed"); rc = 1; break; }
-            if (vcr_launch_preprocess(a, g, v.radii, depth_key, nullptr, ctr, false, cs)) { rc = 1; break; }
+            StreamScratch& sc = pool->sc[c - c0];
+            uint32_t* totals_depth = (uint32_t*)(v.s1 + 7 * nb);
+            void* temp1 = v.s1 + 7 * nb + tot_bytes;
+            if (scratch_begin_forward(&sc, vcr_duplicate_status_words(N), cs)) { rc = 1; break; }
+            v.dseq = sc.seq;
             v.seq = ++seq_counter ? seq_counter : ++seq_counter;
-            hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(256), 0, cs, ctr, pool->pub + (c - c0), v.seq);
-            if (hipGetLastError() != hipSuccess) { vcr_set_error("visibility batch: publish launch failed"); rc = 1; break; }
+            if (vcr_launch_preprocess(a, g, v.radii, depth_key, nullptr, sc.ctr, false, cs, pool->pub + (c - c0), v.seq)) { rc = 1; break; }
             if (vcr_depth_sort(N, depth_key, (uint2*)(v.s1 + 2 * nb), (uint2*)(v.s1 + 4 * nb), ids_sorted, totals_depth, temp1, cs)) { rc = 1; break; }
         }
         // back half: the host sizes the instance buffers of camera c while the later cameras' front halves run
@@ -576,10 +577,12 @@ extern "C" int vcr_visibility_batch(const VcrVisibilityBatch* vb, vcr_alloc_fn a
             hipStream_t cs = pool->st[(c - c0) % nstreams];
             Published* pub = pool->pub + (c - c0);
             if (wait_published(pub, v.seq, cs)) { rc = 1; break; }
+            StreamScratch& sc = pool->sc[c - c0];
+            sc.ctr_dirty = false;                   // (published: the projection left the counter block zero)
             const int64_t R = (int64_t)pub->R, E = (int64_t)pub->E;
             if (pub->far && vcr_depth_sort_far(N, (uint2*)(v.s1 + 2 * nb), (uint32_t*)(v.s1 + nb),
-                                               (uint32_t*)(v.s1 + 7 * nb + ctr_bytes + status_bytes),
-                                               v.s1 + 7 * nb + ctr_bytes + status_bytes + tot_bytes, cs)) { rc = 1; break; }
+                                               (uint32_t*)(v.s1 + 7 * nb),
+                                               v.s1 + 7 * nb + tot_bytes, cs)) { rc = 1; break; }
             if (vb->num_rendered) vb->num_rendered[c] = R;
             if (vb->num_visible) vb->num_visible[c] = (int32_t)pub->V;
             if (R >= (1ll << 32)) { vcr_set_error("more than 2^32 tile instances"); rc = 1; break; }
@@ -599,9 +602,9 @@ extern "C" int vcr_visibility_batch(const VcrVisibilityBatch* vb, vcr_alloc_fn a
             GeomState g = GeomState::view(v.geom, N, 0);
             BinState b = BinState::view(v.bin, T);
             uint32_t* ids_sorted = (uint32_t*)(v.s1 + nb);
-            unsigned long long* dup_status = (unsigned long long*)(v.s1 + 7 * nb + ctr_bytes);
-            uint32_t* totals_tile = (uint32_t*)(v.s1 + 7 * nb + ctr_bytes + status_bytes) + VCR_SORT_TOTALS_WORDS;
-            if (vcr_duplicate_and_sort(a, g, v.radii, ids_sorted, dup_status, E, tbits, (uint2*)v.s2, (uint2*)(v.s2 + 2 * rbts),
+            uint32_t* totals_tile = (uint32_t*)(v.s1 + 7 * nb) + VCR_SORT_TOTALS_WORDS;
+            if (vcr_duplicate_and_sort(a, g, v.radii, ids_sorted, sc.status, sc.ctr + VCR_DUP_TICKET_WORD, v.dseq, E, tbits,
+                                       (uint2*)v.s2, (uint2*)(v.s2 + 2 * rbts),
                                        third ? (uint2*)(v.s2 + 5 * rbts) : nullptr, (uint32_t*)(v.s2 + 4 * rbts), b.point_list,
                                        b.ranges, b.tile_order, b.meta, T, totals_tile, v.s2 + (third ? 7 : 5) * rbts, tmp2, cs)) { rc = 1; break; }
             ImageState im;
@@ -616,7 +619,14 @@ extern "C" int vcr_visibility_batch(const VcrVisibilityBatch* vb, vcr_alloc_fn a
     return rc;
 }
 
+#ifdef VCR_DBG_ACC64
+int vcr_dbg_acc64_begin(int N, hipStream_t st);
+int vcr_dbg_acc64_end(int N, GradRec* sgrad, hipStream_t st);
+#endif
 namespace {
+thread_local bool g_keep_sgrad = false;
+thread_local float* g_sgrad_copy = nullptr;
+thread_local int g_sgrad_copy_n = 0;
 // vcr_rasterize_backward (tail == nullptr) and vcr_rasterize_backward_tail
 int backward_impl(const VcrRasterArgs* args, VcrBackwardIO* io, const VcrGeometryStep* tail, vcr_alloc_fn alloc, void* user,
                   void* stream) {
@@ -629,6 +639,7 @@ int backward_impl(const VcrRasterArgs* args, VcrBackwardIO* io, const VcrGeometr
     if (N == 0) return 0;
     if (!io->dL_dout || !io->geom || !io->binning || !io->image || !io->radii) { vcr_set_error("backward: required pointer is NULL"); return 1; }
     if (!tail && (!io->dL_dmeans3D || !io->dL_dmeans2D || !io->dL_dopacities)) { vcr_set_error("backward: required pointer is NULL"); return 1; }
+    if ((io->normals_Rw2c == nullptr) != (io->normals_aux == nullptr)) { vcr_set_error("backward: normals_Rw2c and normals_aux go together"); return 1; }
     if (a.shs && !io->dL_dshs && !io->dL_drgb) { vcr_set_error("backward: dL_dshs and dL_drgb are both NULL"); return 1; }
     if (a.shs_rest && io->dL_dshs && !io->dL_dshs_rest) { vcr_set_error("backward: dL_dshs_rest is NULL"); return 1; }
     if (!tail && a.scales && (!io->dL_dscales || !io->dL_drotations)) { vcr_set_error("backward: dL_dscales/rotations NULL"); return 1; }
@@ -650,6 +661,7 @@ int backward_impl(const VcrRasterArgs* args, VcrBackwardIO* io, const VcrGeometr
             (t.next_scales && (!t.next_rots || !t.next_opac || (t.next_normals && (!t.next_campos || !t.next_Rw2c || !t.next_aux))))) {
             vcr_set_error("backward tail: inconsistent VcrGeometryStep"); return 1;
         }
+        if (!(t.grad_scale > 0.f) || t.normals_world) { vcr_set_error("backward tail: grad_scale must be > 0 and normals_world 0 (single process)"); return 1; }
         if ((((uintptr_t)t.rotation) | ((uintptr_t)t.m_rotation) | ((uintptr_t)t.v_rotation) | ((uintptr_t)t.next_rots)) & 15) {
             vcr_set_error("backward tail: quaternion arrays must be 16-byte aligned"); return 1;
         }
@@ -658,16 +670,39 @@ int backward_impl(const VcrRasterArgs* args, VcrBackwardIO* io, const VcrGeometr
     GeomState g = GeomState::view(const_cast<void*>(io->geom), N, a.S);
     BinState b = BinState::view(const_cast<void*>(io->binning), gx * gy);
     ImageState im = ImageState::view(const_cast<void*>(io->image), P);
+    if (io->num_rendered > 0 && io->num_emitted < 0) {       // (quad-list mode counts 8x8 cells: num_emitted may exceed num_rendered)
+        vcr_set_error("backward: num_emitted = %lld is not the forward's", (long long)io->num_emitted);
+        return 1;
+    }
+    im.t_ckpt = BinState::ckpt_of(const_cast<void*>(io->binning), io->num_emitted, gx * gy);
     const size_t gb = vcr_align(sizeof(GradRec) * (size_t)N);
     const size_t sb = vcr_align(sizeof(float) * (size_t)N * (a.S > 0 ? a.S : 1));
-    char* s = (char*)alloc(user, VCR_BUF_SCRATCH, gb + sb);
-    if (!s) { vcr_set_error("allocator returned NULL"); return 1; }
+    // the screen-space accumulators: library-owned, zero between calls (the projection backward clears what it reads)
+    StreamScratch* sc = stream_scratch(st);
+    if (!sc) { vcr_set_error("hipMalloc for the counter block failed"); return 1; }
+    if (scratch_begin_backward(sc, gb + sb, st)) return 1;
+    char* s = sc->grad;
     GradRec* sgrad = (GradRec*)s;
     float* sgrad_sem = (float*)(s + gb);
-    VCR_HIP_CHECK(hipMemsetAsync(s, 0, gb + sb, st));
+    (void)alloc; (void)user;
     if (io->num_rendered > 0) {
         StageTimer tm(ST_COMPOSITE_BWD, st);
+#ifdef VCR_DBG_ACC64
+        if (vcr_dbg_acc64_begin(N, st)) return 1;
+#endif
         if (vcr_launch_composite_backward(a, g, b, im, io->dL_dout, sgrad, sgrad_sem, st)) return 1;
+#ifdef VCR_DBG_ACC64
+        if (vcr_dbg_acc64_end(N, sgrad, st)) return 1;
+#endif
+    }
+    if (g_keep_sgrad) {                      // diagnostics (vcr_debug_keep_sgrad): the accumulators as the compositing backward left them
+        if (g_sgrad_copy_n < N) {
+            if (g_sgrad_copy) (void)hipFree(g_sgrad_copy);
+            g_sgrad_copy = nullptr; g_sgrad_copy_n = 0;
+            VCR_HIP_CHECK(hipMalloc((void**)&g_sgrad_copy, sizeof(GradRec) * (size_t)N));
+            g_sgrad_copy_n = N;
+        }
+        VCR_HIP_CHECK(hipMemcpyAsync(g_sgrad_copy, sgrad, sizeof(GradRec) * (size_t)N, hipMemcpyDeviceToDevice, st));
     }
     VcrBackwardIO io2 = *io;
     if (!a.normals_precomp) io2.dL_dnormals = nullptr;
@@ -675,10 +710,20 @@ int backward_impl(const VcrRasterArgs* args, VcrBackwardIO* io, const VcrGeometr
     if (a.colors_precomp == nullptr) io2.dL_dcolors = nullptr;
     if (a.shs == nullptr) io2.dL_drgb = nullptr;
     StageTimer tm(ST_PREPROCESS_BWD, st);
-    if (tail) return vcr_launch_preprocess_backward_tail(a, g, io->radii, sgrad, sgrad_sem, io2, *tail, st);
-    return vcr_launch_preprocess_backward(a, g, io->radii, sgrad, sgrad_sem, io2, st);
+    const int rc = tail ? vcr_launch_preprocess_backward_tail(a, g, io->radii, sgrad, sgrad_sem, io2, *tail, st)
+                        : vcr_launch_preprocess_backward(a, g, io->radii, sgrad, sgrad_sem, io2, st);
+    if (!rc) sc->grad_dirty = false;         // (both kernels accepted: the accumulators are zero again when they have run)
+    return rc;
 }
 }  // namespace
+
+extern "C" int vcr_debug_keep_sgrad(int on) { g_keep_sgrad = on != 0; return 0; }
+extern "C" int vcr_debug_read_sgrad(float* host_out, int N) {
+    if (!g_sgrad_copy || N > g_sgrad_copy_n || !host_out) { vcr_set_error("vcr_debug_read_sgrad: no copy of %d records held", N); return 1; }
+    VCR_HIP_CHECK(hipDeviceSynchronize());
+    VCR_HIP_CHECK(hipMemcpy(host_out, g_sgrad_copy, sizeof(GradRec) * (size_t)N, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 extern "C" int vcr_rasterize_backward(const VcrRasterArgs* args, VcrBackwardIO* io, vcr_alloc_fn alloc, void* user,
                                       void* stream) {

@@ -78,6 +78,22 @@ __device__ __forceinline__ uint2 list_range(const uint2* __restrict__ ranges, in
     return ranges[(2 * (tile / gx) + (quad >> 1)) * gxc + 2 * (tile % gx) + (quad & 1)];
 }
 
+// Transmittance checkpoints (round 5).  The forward stores every pixel's T at the START of each 64-entry chunk c >= 1 of the list
+// it walks (c = 0 starts at T = 1); the backward, which recovers T back to front by T_i = T_{i+1} / (1 - alpha_i), replaces its
+// recovered value by the forward's own at every chunk boundary, so the rounding of that division chain is bounded by the few
+// contributors a pixel has inside ONE chunk instead of growing over the whole list (profiles/r5_bwd_algorithm_emulation.txt:
+// a +-1 ulp reciprocal in an un-anchored chain doubles the gradient error of an fp32 evaluation; anchored it is back at 1.0x).
+// Record of chunk c of list l (tile, or 8x8 cell in quad-list mode) = slot (begin_l >> 6) + c + l: lists are laid out in index
+// order, begin_{l'} >= begin_l + len_l and l' >= l + 1 for a later non-empty list, so floor(begin_{l'} / 64) + l' >=
+// floor(begin_l / 64) + ceil(len_l / 64) + l -- slots never collide and stay below E / 64 + lists.  A slot holds the 256 pixels
+// of the tile (64 per quad wave, quad-local row-major) or, in quad-list mode, the 64 pixels of the cell.
+template <bool QL>
+__device__ __forceinline__ size_t ckpt_base(uint32_t begin, int gxc, int tile, int gx, int quad) {
+    if (!QL) return ((size_t)(begin >> 6) + (size_t)tile) * 256u + (size_t)quad * 64u;
+    return ((size_t)(begin >> 6) + (size_t)((2 * (tile / gx) + (quad >> 1)) * gxc + 2 * (tile % gx) + (quad & 1))) * 64u;
+}
+#define VCR_CKPT_STRIDE (QL ? 64u : 256u)
+
 // ================= one wave = one 8x8 quad, no LDS, no barriers ==========================================
 // Each lane first acts as a CULLER for one Gaussian of the tile list (exact minimum of the conic form over
 // the quad's pixel rectangle against the alpha >= 1/255 threshold), a 64-bit ballot compacts the survivors,
@@ -129,6 +145,19 @@ __device__ __forceinline__ void live_box(unsigned long long live, float X0, floa
 #ifndef VCR_KO
 #define VCR_KO 0
 #endif
+// Diagnostic builds for the gradient-error attribution of round 5 (profiles/r5_grad_ratio_table_*.txt; results are as valid
+// as the default build's, only slower): -DVCR_DBG_PIX64 keeps the per-pixel recurrences of the backward (transmittance
+// recovery, suffix sum, dL/dalpha) in fp64; -DVCR_DBG_ACC64 accumulates the per-Gaussian screen-space sums with fp64 atomics
+// into a side buffer that is rounded to the GradRec once.
+#ifdef VCR_DBG_ACC64
+__device__ double* g_acc64 = nullptr;
+#define VCR_GRAD_ATOMIC(GID, K, VAL) atomicAdd(g_acc64 + (size_t)(GID) * 16 + (K), (double)(VAL))
+#else
+#define VCR_GRAD_ATOMIC(GID, K, VAL) atomicAdd(reinterpret_cast<float*>(sgrad + (GID)) + (K), (VAL))
+#endif
+#ifndef VCR_DBG_PIX64
+#define VCR_DBG_PIX64 0
+#endif
 // -DVCR_HITHIST: instrumented build that counts, per surviving (quad, Gaussian) pair, how many of the 64 pixels it hits
 // (forward: bins 0..64, backward: 65..129); read with vcr_debug_hit_histogram (profiles/hit_histogram.py)
 #ifdef VCR_HITHIST
@@ -145,8 +174,13 @@ __device__ unsigned int g_hithist[130];
 #ifndef VCR_BWD_SPARSE_HITS
 #define VCR_BWD_SPARSE_HITS 0
 #endif
-#ifndef VCR_BWD_WAVES
-#define VCR_BWD_WAVES 4          // waves per SIMD the backward is compiled for: 4 (no spills) 540 us, 5 (5 spills) 560 us, 6 657 us, 3 539 us at 1 M / 1080p
+// -DVCR_T_ANCHOR=0: experiment build without the per-chunk re-anchoring of the recovered transmittance (rounds 1-4);
+// -DVCR_RCP_NEWTON=1: one Newton step on the v_rcp_f32 of the recovery (both A/B'd in profiles/r5_grad_ratio_table_*.txt)
+#ifndef VCR_T_ANCHOR
+#define VCR_T_ANCHOR 1
+#endif
+#ifndef VCR_RCP_NEWTON
+#define VCR_RCP_NEWTON 0
 #endif
 
 
@@ -170,13 +204,17 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
                                                                const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ meta,
                                                                int num_tiles, int gxc, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                                float* __restrict__ moments, float* __restrict__ out,
-                                                               int32_t* __restrict__ count, float* __restrict__ score) {
+                                                               int32_t* __restrict__ count, float* __restrict__ score,
+                                                               float* __restrict__ ckpt) {
     const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
     int sub;
     const int tile = work_item(tile_order, meta, num_tiles, sub);
     if (tile < 0) return;
     const PixelMap pm = pixel_of_thread(tile, gx, a.W, a.H, sub);
     const uint2 range = list_range<QL>(ranges, gxc, tile, gx, threadIdx.x >> 6);
+    // this lane's slot in a checkpoint record: quad-local row-major pixel index
+    float* const ck = FC == 0 ? ckpt + ckpt_base<QL>(range.x, gxc, tile, gx, threadIdx.x >> 6) +
+                                    (size_t)((pm.y & 7) * 8 + (pm.x & 7)) : nullptr;
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // S <= 2 without count mode: the semantic features come with the record (GeomRec pad slots) and take the place of the id
@@ -184,11 +222,6 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
     constexpr int WREC = (S > 0 && !SEM_IN_REC) ? 320 : 256;   // per wave: 4 (+1 with semantics) planes x 64 slots x 16 B
     __shared__ float4 s_rec_all[4 * WREC];                // (conflict-free b128 writes)
     float4* const srec = s_rec_all + wv * WREC;
-#ifdef VCR_TIMING
-    const long long t_start = wall_clock64();
-    int n_surv = 0, n_hit = 0, n_chunks = 0;
-    long long t_cull = 0, t_surv = 0, t_mark = 0;
-#endif
     const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8 + (sub < 0 ? 0 : (sub & 1) * 4));
     const float Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8 + (sub < 0 ? 0 : (sub >> 1) * 4));
     const f2 fxy = {(float)pm.x, (float)pm.y};
@@ -222,22 +255,16 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
     while (pos < range.y) {
         uint32_t nnid; float4 nq0, nq1, nq2 = zero4, nq3 = zero4, nqs = zero4; bool nnvalid;
         const uint32_t npos = pos + 64;
+        if (FC == 0 && pos != range.x && pm.inside) ck[(size_t)((pos - range.x) >> 6) * VCR_CKPT_STRIDE] = T;
         VCR_GATHER_FWD(nid, nq0, nq1, nq2, nq3);                     // records of the next chunk
         if (!SEM_IN_REC) VCR_GATHER_SEM(nid, nqs);
         VCR_LOAD_ID(npos + 64 + lane, range.y, nnid, nnvalid);       // ids of the chunk after that
-#ifdef VCR_TIMING
-        t_mark = wall_clock64();
-#endif
         float bx0, by0, bw, bh;
         live_box(__builtin_amdgcn_ballot_w64(!done), X0, Y0, bx0, by0, bw, bh);
         const bool keep = valid && quad_touch(q0, q1, bx0, by0, bw, bh);
         unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
         int chunk_cnt = 0; unsigned long long chunk_seen = 0;       // FC 3 / 4 (see below)
         (void)chunk_cnt; (void)chunk_seen;
-#ifdef VCR_TIMING
-        n_chunks++; n_surv += __popcll(m);
-        { const long long t2 = wall_clock64(); t_cull += t2 - t_mark; t_mark = t2; }
-#endif
         // Survivors stage their record -- rescaled for the shading loop, see gauss_exponent() -- in this wave's private LDS
         // planes; the shading loop then fetches one survivor per iteration with four wave-uniform ds_read_b128 (LDS
         // broadcast reads, 4 CU cycles each) one survivor ahead.  v_readlane_b32 costs 8.3 SIMD cycles on gfx950
@@ -340,9 +367,6 @@ _Pragma("unroll")                                                               
                 b = nb;
             }
         }
-#ifdef VCR_TIMING
-        t_surv += wall_clock64() - t_mark;
-#endif
         // count modes 3 / 4: lane j holds what entry j of this chunk collected -- ONE atomic / store instruction per chunk
         // instead of one per survivor (`id` is this lane's entry of the current chunk)
         if (FC == 3 && chunk_cnt != 0) atomicAdd(count + id, chunk_cnt);
@@ -350,19 +374,6 @@ _Pragma("unroll")                                                               
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;        // every pixel of the quad has T < 1e-4
         pos = npos; id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; qs = nqs; valid = nvalid; nid = nnid; nvalid = nnvalid;
     }
-#ifdef VCR_TIMING
-    if (lane == 0 && count) {       // experiment builds only: (start, end) wall-clock ticks per wave
-        reinterpret_cast<long long*>(count)[4 * (blockIdx.x * 4 + wv)] = t_start;
-        reinterpret_cast<long long*>(count)[4 * (blockIdx.x * 4 + wv) + 1] = wall_clock64();
-        // bits 48..: where the wave ran -- HW_ID (wave / SIMD / CU / SH / SE ids) and the XCC id
-        unsigned hw_id, xcc_id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
-        const unsigned long long place = ((unsigned long long)(xcc_id & 0xF) << 12) | ((hw_id >> 4) & 0xFFF);   // simd[1:0] pipe[3:2] cu[7:4] sh[8] se[11:9]
-        reinterpret_cast<long long*>(count)[4 * (blockIdx.x * 4 + wv) + 2] = (long long)((place << 48) | ((unsigned long long)(n_chunks & 0xFFFF) << 32) | (unsigned)n_surv);
-        reinterpret_cast<long long*>(count)[4 * (blockIdx.x * 4 + wv) + 3] = (t_cull << 32) | (t_surv & 0xFFFFFFFF);
-    }
-#endif
     const float C0 = acc_c01.x, C1 = acc_c01.y, C2 = acc_c2n.x, N0 = acc_c2n.y, N1 = acc_n12.x, N2 = acc_n12.y;
     const float D = acc_da.x, A = acc_da.y;
     if (pm.inside) {
@@ -395,215 +406,117 @@ _Pragma("unroll")                                                               
     }
 }
 
-template <int S, bool ISECT, int ND, bool QL>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((S == 0 && ND == 0) ? VCR_BWD_WAVES : 4))) composite_bwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
-                                                               const float* __restrict__ semv,
-                                                               const uint32_t* __restrict__ point_list,
-                                                               const uint2* __restrict__ ranges,
-                                                               const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ meta,
-                                                               int num_tiles, int gxc, const float* __restrict__ final_T,
-                                                               const uint32_t* __restrict__ n_contrib,
-                                                               const float* __restrict__ moments,
-                                                               const float* __restrict__ dL_dout, GradRec* __restrict__ sgrad,
-                                                               float* __restrict__ sgrad_sem, int det_sel) {
-#ifdef VCR_DETERMINISTIC_BWD
-    // test-only build: the launcher issues one launch per (workgroup, wave) and every other wave leaves at once, so the fp32
-    // atomics of the whole backward happen in ONE fixed order (tile order, quad 0..3, list back to front)
-    if ((int)(blockIdx.x * 4 + (threadIdx.x >> 6)) != det_sel) return;
-#else
-    (void)det_sel;
-#endif
-    const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
-    int sub;
-    const int tile = work_item(tile_order, meta, num_tiles, sub);
-    if (tile < 0) return;
-    const PixelMap pm = pixel_of_thread(tile, gx, a.W, a.H, sub);
-    const uint2 range = list_range<QL>(ranges, gxc, tile, gx, threadIdx.x >> 6);
-    const int P = a.H * a.W;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    constexpr bool SEM_IN_REC = false;                    // (the backward needs the id for its atomics: semantics keep their plane)
-    constexpr int FC = 0;                                 // (VCR_LDS_FETCH: full records)
-    constexpr int WREC = S > 0 ? 320 : 256;               // per wave: 4 (+1 with semantics) planes x 64 slots x 16 B
-    __shared__ float4 s_rec_all[4 * WREC];
-    float4* const srec = s_rec_all + wv * WREC;
-    const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8 + (sub < 0 ? 0 : (sub & 1) * 4));
-    const float Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8 + (sub < 0 ? 0 : (sub >> 1) * 4));
-    const f2 fxy = {(float)pm.x, (float)pm.y};
-    float rx = 0.f, ry = 0.f, rz = 1.f;
-    if (ISECT && pm.inside) { rx = a.dirs[pm.pix]; ry = a.dirs[P + pm.pix]; rz = a.dirs[2 * P + pm.pix]; }
-
-    float g[8 + (S > 0 ? S : 0)];
-#pragma unroll
-    for (int c = 0; c < 8 + S; ++c) g[c] = pm.inside ? dL_dout[c * (size_t)P + pm.pix] : 0.f;
-    float gm2 = 0.f;                               // ND == 2: gradients of (sum w d) fold into g[3], of (sum w d^2) here
-    if (ND == 2 && pm.inside) { g[3] += dL_dout[(8 + S) * (size_t)P + pm.pix]; gm2 = dL_dout[(9 + S) * (size_t)P + pm.pix]; }
-    const float Tf = pm.inside ? final_T[pm.pix] : 1.f;
-    float gm1 = 0.f;                                // ND == 1: gradients on sum w m / sum w m^2 from dist = A*M2 - M1^2
-    const float zc_map = VCR_ZFAR / (VCR_ZFAR - VCR_ZNEAR);
-    if (ND == 1 && pm.inside) {
-        const float gd = dL_dout[(8 + S) * (size_t)P + pm.pix];
-        const float m1 = moments[pm.pix], m2 = moments[P + pm.pix];
-        gm1 = -2.f * m1 * gd; gm2 = (1.f - Tf) * gd; g[7] += m2 * gd;
-    }
-    const uint32_t lastc = pm.inside ? n_contrib[pm.pix] : 0u;
-    const float bgdot = Tf * (a.bg[0] * g[0] + a.bg[1] * g[1] + a.bg[2] * g[2]);
-    // deepest contributor of this quad (1-based index in the tile list)
-    uint32_t maxc = lastc;
-    for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, o));
-    if (maxc == 0) return;                                 // wave-uniform
-    // Bsuf = bgdot + sum over the Gaussians behind the current one of w_j (f_j . g)
-    float T = Tf, Bsuf = bgdot;
-    const f2 g01 = {g[0], g[1]}, g24 = {g[2], g[4]}, g56 = {g[5], g[6]}, ryz = {ry, rz};
-
-    int chunk = (int)((maxc - 1) / 64);                    // chunks of 64 list entries, walked back to front
-    uint32_t id, nid; float4 q0, q1, q2, q3, qs = {0.f, 0.f, 0.f, 0.f}; bool valid, nvalid;
-    const uint32_t lim = range.x + maxc;
-    VCR_LOAD_ID(range.x + (uint32_t)chunk * 64u + lane, lim, id, valid);
-    VCR_GATHER_REC(id, q0, q1, q2, q3);
-    VCR_GATHER_SEM(id, qs);
-    VCR_LOAD_ID(chunk > 0 ? range.x + (uint32_t)(chunk - 1) * 64u + lane : lim, lim, nid, nvalid);
-    for (; chunk >= 0; --chunk) {
-        uint32_t nnid; float4 nq0, nq1, nq2, nq3, nqs = {0.f, 0.f, 0.f, 0.f}; bool nnvalid;
-        VCR_GATHER_REC(nid, nq0, nq1, nq2, nq3);
-        VCR_GATHER_SEM(nid, nqs);
-        VCR_LOAD_ID(chunk > 1 ? range.x + (uint32_t)(chunk - 2) * 64u + lane : lim, lim, nnid, nnvalid);
-        float bx0, by0, bw, bh;
-        live_box(__builtin_amdgcn_ballot_w64(lastc > (uint32_t)chunk * 64u), X0, Y0, bx0, by0, bw, bh);
-        const bool keep = valid && quad_touch(q0, q1, bx0, by0, bw, bh);
-        unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-        if (keep) {
-            srec[0 * 64 + lane] = make_float4(q0.x, q0.y, -VCR_L2E * q1.x, -VCR_L2E * q1.z);
-            srec[1 * 64 + lane] = make_float4(-VCR_L2E * q1.y, __builtin_amdgcn_logf(q0.w), q0.z, q1.w);
-            srec[2 * 64 + lane] = make_float4(q2.x, q2.y, q2.z, q3.x);
-            srec[3 * 64 + lane] = make_float4(q3.y, q3.z, __uint_as_float(id), 0.f);
-            if (S > 0) srec[4 * 64 + lane] = qs;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // Gradient slots of one (pixel, Gaussian) pair: expects r1..r3 (staged record), d, u, araw and `hit` in scope; defines
-        // gid, v[8] (16 raw slots, GradRec order) and vs[S]; updates T and Bsuf.  Lanes without a hit produce zeros.
+// ---- shading macros of the compositing backward (one survivor, all 64 lanes = the whole 8x8 quad) ---------------------------
+// Used by the row-packed kernel below for the chunks where packing does not pay (the round-2 kernel that was built from them
+// alone, `composite_bwd_v2`, left the library in round 5: profiles/r3_bwd_rows_ab.txt holds its A/B).
+// Gradient slots of one (pixel, Gaussian) pair: expects r1..r3 (staged record), d, u, araw and `hit` in scope; defines
+// gid, v[8] (16 raw slots, GradRec order) and vs[S]; updates T and Bsuf.  Lanes without a hit produce zeros.
 #define VCR_BWD_MATH(R)                                                                                                  \
-            const f2 c01 = {r2.x, r2.y}, c2n = {r2.z, r2.w}, n12 = {r3.x, r3.y};                                         \
-            const float zc = r1.z, pl = r1.w;                                                                            \
-            const uint32_t gid = __float_as_uint(r3.z);                                                                  \
-            f2 v[8];                                                                                                     \
-            float vs[S > 0 ? S : 1];                                                                                     \
-            {                                                                                                            \
-                const float ah = hit ? araw : 0.f;                                                                       \
-                const float alpha = fminf(VCR_ALPHA_MAX, ah);                                                            \
-                const float inv1ma = fast_rcp(1.f - alpha);                                                              \
-                T *= inv1ma;                                                                                             \
-                const float w = alpha * T;                                                                               \
-                float dep = zc, iden = 0.f;                                                                              \
-                bool isect = false;                                                                                      \
-                if (ISECT) {                                                                                             \
-                    const float den = fmaf(c2n.y, rx, fmaf(n12.x, ry, n12.y * rz));   /* (explicit: both copies of the macro must round alike) */                                              \
-                    isect = den > VCR_PLANE_EPS;                                                                         \
-                    iden = isect ? fast_rcp(den) : 0.f;                                                                  \
-                    dep = isect ? pl * iden * rz : zc;                                                                   \
-                }                                                                                                        \
-                f2 fa = pk_fma(c01, g01, f2{g[7], 0.f});                                                                 \
-                fa = pk_fma(c2n, g24, fa);                                                                               \
-                fa = pk_fma(n12, g56, fa);                                                                               \
-                float fg = fmaf(dep, g[3], fa.x + fa.y);                                                                 \
-                if (ND == 2) fg += dep * dep * gm2;                                                                      \
-                float md = 0.f, idep = 0.f;                                                                              \
-                if (ND == 1) {                                                                                           \
-                    idep = fast_rcp(dep);                                                                                \
-                    md = -zc_map * VCR_ZNEAR * idep;                                                                     \
-                    fg += md * gm1 + md * md * gm2;                                                                      \
-                }                                                                                                        \
-                { const float4 r4_ = R##4; const float sv_[4] = {r4_.x, r4_.y, r4_.z, r4_.w};                            \
+    const f2 c01 = {r2.x, r2.y}, c2n = {r2.z, r2.w}, n12 = {r3.x, r3.y};                                         \
+    const float zc = r1.z, pl = r1.w;                                                                            \
+    const uint32_t gid = __float_as_uint(r3.z);                                                                  \
+    f2 v[8];                                                                                                     \
+    float vs[S > 0 ? S : 1];                                                                                     \
+    {                                                                                                            \
+        const float ah = hit ? araw : 0.f;                                                                       \
+        const float alpha = fminf(VCR_ALPHA_MAX, ah);                                                            \
+        const float oma_ = 1.f - alpha;                                                                          \
+        float inv1ma = fast_rcp(oma_);                                                                           \
+        if (VCR_RCP_NEWTON) inv1ma = fmaf(fmaf(-oma_, inv1ma, 1.f), inv1ma, inv1ma);                              \
+        T *= inv1ma;                                                                                             \
+        const double inv_d_ = 1.0 / (1.0 - (double)alpha);                                                       \
+        if (VCR_DBG_PIX64) { Td *= inv_d_; T = (float)Td; }                                                      \
+        const float w = VCR_DBG_PIX64 ? (float)((double)alpha * Td) : alpha * T;                                 \
+        float dep = zc, iden = 0.f;                                                                              \
+        bool isect = false;                                                                                      \
+        if (ISECT) {                                                                                             \
+            const float den = fmaf(c2n.y, rx, fmaf(n12.x, ry, n12.y * rz));   /* (explicit: both copies of the macro must round alike) */                                              \
+            isect = den > VCR_PLANE_EPS;                                                                         \
+            iden = isect ? fast_rcp(den) : 0.f;                                                                  \
+            dep = isect ? pl * iden * rz : zc;                                                                   \
+        }                                                                                                        \
+        f2 fa = pk_fma(c01, g01, f2{g[7], 0.f});                                                                 \
+        fa = pk_fma(c2n, g24, fa);                                                                               \
+        fa = pk_fma(n12, g56, fa);                                                                               \
+        float fg = fmaf(dep, g[3], fa.x + fa.y);                                                                 \
+        if (ND == 2) fg += dep * dep * gm2;                                                                      \
+        float md = 0.f, idep = 0.f;                                                                              \
+        if (ND == 1) {                                                                                           \
+            idep = fast_rcp(dep);                                                                                \
+            md = -zc_map * VCR_ZNEAR * idep;                                                                     \
+            fg += md * gm1 + md * md * gm2;                                                                      \
+        }                                                                                                        \
+        { const float4 r4_ = R##4; const float sv_[4] = {r4_.x, r4_.y, r4_.z, r4_.w};                            \
 _Pragma("unroll")                                                                                                        \
-                for (int k = 0; k < S; ++k) fg += sv_[k] * g[8 + k]; }                                                   \
-                const float dL_dalpha = fmaf(T, fg, -Bsuf * inv1ma);                                                     \
-                Bsuf = fmaf(w, fg, Bsuf);                                                                                \
-                const float pw = ah * dL_dalpha;                                                                         \
-                const f2 pp = splat(pw);                                                                                 \
-                v[0] = u * pp;                                                                                           \
-                v[1] = f2{fabsf(v[0].x), fabsf(v[0].y)};                                                                 \
-                const f2 dp = d * pp;                                                                                    \
-                v[2] = d * dp;                                                                                           \
-                v[3] = f2{d.x * dp.y, pw};                                                                               \
-                const f2 ww = splat(w);                                                                                  \
-                v[4] = ww * g01;                                                                                         \
-                const float wd = w * (ND == 2 ? g[3] + 2.f * dep * gm2                                                   \
-                                              : (ND == 1 ? g[3] + (gm1 + 2.f * md * gm2) * zc_map * VCR_ZNEAR * idep * idep : g[3])); \
-                v[5] = f2{w * g24.x, isect ? 0.f : wd};                                                                  \
-                const float k1 = wd * rz * iden;                                                                         \
-                const float k2 = -k1 * pl * iden;                                                                        \
-                v[6] = f2{k1, fmaf(k2, rx, w * g24.y)};                                                                  \
-                v[7] = pk_fma(splat(k2), ryz, ww * g56);                                                                 \
+        for (int k = 0; k < S; ++k) fg += sv_[k] * g[8 + k]; }                                                   \
+        float dL_dalpha = fmaf(T, fg, -Bsuf * inv1ma);                                                           \
+        Bsuf = fmaf(w, fg, Bsuf);                                                                                \
+        if (VCR_DBG_PIX64) {                                                                                     \
+            dL_dalpha = (float)(Td * (double)fg - Bd * inv_d_);                                                  \
+            Bd += (double)alpha * Td * (double)fg;                                                               \
+        }                                                                                                        \
+        const float pw = ah * dL_dalpha;                                                                         \
+        const f2 pp = splat(pw);                                                                                 \
+        v[0] = u * pp;                                                                                           \
+        v[1] = f2{fabsf(v[0].x), fabsf(v[0].y)};                                                                 \
+        const f2 dp = d * pp;                                                                                    \
+        v[2] = d * dp;                                                                                           \
+        v[3] = f2{d.x * dp.y, pw};                                                                               \
+        const f2 ww = splat(w);                                                                                  \
+        v[4] = ww * g01;                                                                                         \
+        const float wd = w * (ND == 2 ? g[3] + 2.f * dep * gm2                                                   \
+                                      : (ND == 1 ? g[3] + (gm1 + 2.f * md * gm2) * zc_map * VCR_ZNEAR * idep * idep : g[3])); \
+        v[5] = f2{w * g24.x, isect ? 0.f : wd};                                                                  \
+        const float k1 = wd * rz * iden;                                                                         \
+        const float k2 = -k1 * pl * iden;                                                                        \
+        v[6] = f2{k1, fmaf(k2, rx, w * g24.y)};                                                                  \
+        v[7] = pk_fma(splat(k2), ryz, ww * g56);                                                                 \
 _Pragma("unroll")                                                                                                        \
-                for (int k = 0; k < S; ++k) vs[k] = w * g[8 + k];                                                        \
-            }
-        // Shading + gradient of one survivor whose staged record sits in R0..R3 (see the forward kernel for the staging).
-        // Branch-free inside: lanes without a hit run with alpha = 0, which makes T, Bsuf and every slot a no-op / zero.
-        // Slots are RAW sums; preprocess_bwd applies the per-Gaussian constants (GradRec in vcr_common.h).
-#define VCR_SHADE_BWD(R, B)                                                                                              \
-        do {                                                                                                             \
-            const float4 r0 = R##0, r1 = R##1, r2 = R##2, r3 = R##3; const int sb_ = (B);                                \
-            const uint32_t idx1 = (uint32_t)chunk * 64u + (uint32_t)sb_ + 1u;                                            \
-            const f2 gxy = {r0.x, r0.y}, sAC = {r0.z, r0.w};                                                             \
-            const f2 d = gxy - fxy;                                                                                      \
-            f2 u; float hs;                                                                                              \
-            const float e = gauss_exponent(d, sAC, r1.x, r1.y, u, hs);                                                   \
-            const float araw = __builtin_amdgcn_exp2f(e);                                                                \
-            const bool hit = idx1 <= lastc && hs <= 0.f && araw >= VCR_ALPHA_MIN;                                        \
-            const unsigned long long hitm_ = __builtin_amdgcn_ballot_w64(hit);                                           \
-            VCR_COUNT_HITS(65, hitm_);                                                                                   \
-            if (hitm_ != 0) {                                                                                            \
-            VCR_BWD_MATH(R);                                                                                             \
-            if (VCR_BWD_SPARSE_HITS > 0 && __popcll(hitm_) <= VCR_BWD_SPARSE_HITS) {                                    \
-                /* one or two pixels hit: no wave reduction -- the hitting lanes add their 16 values themselves            */ \
-                if (hit) {                                                                                               \
-                    float* dst_ = reinterpret_cast<float*>(sgrad + gid);                                                 \
-_Pragma("unroll")                                                                                                        \
-                    for (int j = 0; j < 8; ++j) { atomicAdd(dst_ + 2 * j, v[j].x); atomicAdd(dst_ + 2 * j + 1, v[j].y); }  \
-                }                                                                                                        \
-            } else {                                                                                                     \
-            float r4[4];                                                                                                 \
-            if (VCR_KO & 4) { r4[0] = v[0].x + v[4].x; r4[1] = v[1].y + v[5].y; r4[2] = v[2].x + v[6].y; r4[3] = v[3].y + v[7].x; } \
-            else wave_reduce16(v, r4);                                                                                   \
-            if ((lane & 15) < 4) {                                                                                       \
-                const int sub = lane & 15;                                                                               \
-                const float val = sub == 0 ? r4[0] : (sub == 1 ? r4[1] : (sub == 2 ? r4[2] : r4[3]));                    \
-                const int k = 8 * (lane >> 5) + 4 * ((lane >> 4) & 1) + sub;                                             \
-                if ((VCR_KO & 2) ? val == 1.2345e-30f : val != 0.f) atomicAdd(reinterpret_cast<float*>(sgrad + gid) + k, val); \
-            }                                                                                                            \
-            }                                                                                                            \
-            if (S > 0) {     /* semantic gradients: DPP row sums only (no cross-row ds_bpermute round trips); the four row   */ \
-                float ts = 0.f;  /* totals of feature k sit in lanes 16 r + k and go out as ONE atomic instruction            */ \
-_Pragma("unroll")                                                                                                        \
-                for (int k = 0; k < S; ++k) { const float t = row_sum16(vs[k]); ts = (lane & 15) == k ? t : ts; }            \
-                if ((lane & 15) < S && ts != 0.f) atomicAdd(sgrad_sem + (size_t)gid * S + (lane & 15), ts);              \
-            }                                                                                                            \
-            }                                                                                                            \
-        } while (0)
-        if (m && !(VCR_KO & 1)) {
-            float4 A0, A1, A2, A3, A4 = {0.f, 0.f, 0.f, 0.f}, B0, B1, B2, B3, B4 = {0.f, 0.f, 0.f, 0.f};
-            int b = 63 - __builtin_clzll(m);
-            m &= ~(1ull << b);
-            VCR_LDS_FETCH(A, b);
-            for (;;) {                                   // back to front, ping-pong as in the forward kernel
-                int nb = m ? 63 - __builtin_clzll(m) : 0;
-                bool more = m != 0;
-                m &= ~(1ull << nb);
-                VCR_LDS_FETCH(B, nb);
-                VCR_SHADE_BWD(A, b);
-                if (!more) break;
-                b = nb;
-                nb = m ? 63 - __builtin_clzll(m) : 0;
-                more = m != 0;
-                m &= ~(1ull << nb);
-                VCR_LDS_FETCH(A, nb);
-                VCR_SHADE_BWD(B, b);
-                if (!more) break;
-                b = nb;
-            }
-        }
-        id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; qs = nqs; valid = nvalid; nid = nnid; nvalid = nnvalid;
+        for (int k = 0; k < S; ++k) vs[k] = w * g[8 + k];                                                        \
     }
-}
+// Shading + gradient of one survivor whose staged record sits in R0..R3 (see the forward kernel for the staging).
+// Branch-free inside: lanes without a hit run with alpha = 0, which makes T, Bsuf and every slot a no-op / zero.
+// Slots are RAW sums; preprocess_bwd applies the per-Gaussian constants (GradRec in vcr_common.h).
+#define VCR_SHADE_BWD(R, B)                                                                                              \
+do {                                                                                                             \
+    const float4 r0 = R##0, r1 = R##1, r2 = R##2, r3 = R##3; const int sb_ = (B);                                \
+    const uint32_t idx1 = (uint32_t)chunk * 64u + (uint32_t)sb_ + 1u;                                            \
+    const f2 gxy = {r0.x, r0.y}, sAC = {r0.z, r0.w};                                                             \
+    const f2 d = gxy - fxy;                                                                                      \
+    f2 u; float hs;                                                                                              \
+    const float e = gauss_exponent(d, sAC, r1.x, r1.y, u, hs);                                                   \
+    const float araw = __builtin_amdgcn_exp2f(e);                                                                \
+    const bool hit = idx1 <= lastc && hs <= 0.f && araw >= VCR_ALPHA_MIN;                                        \
+    const unsigned long long hitm_ = __builtin_amdgcn_ballot_w64(hit);                                           \
+    VCR_COUNT_HITS(65, hitm_);                                                                                   \
+    if (hitm_ != 0) {                                                                                            \
+    VCR_BWD_MATH(R);                                                                                             \
+    if (VCR_BWD_SPARSE_HITS > 0 && __popcll(hitm_) <= VCR_BWD_SPARSE_HITS) {                                    \
+        /* one or two pixels hit: no wave reduction -- the hitting lanes add their 16 values themselves            */ \
+        if (hit) {                                                                                               \
+            float* dst_ = reinterpret_cast<float*>(sgrad + gid);                                                 \
+_Pragma("unroll")                                                                                                        \
+            for (int j = 0; j < 8; ++j) { atomicAdd(dst_ + 2 * j, v[j].x); atomicAdd(dst_ + 2 * j + 1, v[j].y); }  \
+        }                                                                                                        \
+    } else {                                                                                                     \
+    float r4[4];                                                                                                 \
+    if (VCR_KO & 4) { r4[0] = v[0].x + v[4].x; r4[1] = v[1].y + v[5].y; r4[2] = v[2].x + v[6].y; r4[3] = v[3].y + v[7].x; } \
+    else wave_reduce16(v, r4);                                                                                   \
+    if ((lane & 15) < 4) {                                                                                       \
+        const int sub = lane & 15;                                                                               \
+        const float val = sub == 0 ? r4[0] : (sub == 1 ? r4[1] : (sub == 2 ? r4[2] : r4[3]));                    \
+        const int k = 8 * (lane >> 5) + 4 * ((lane >> 4) & 1) + sub;                                             \
+        if ((VCR_KO & 2) ? val == 1.2345e-30f : val != 0.f) VCR_GRAD_ATOMIC(gid, k, val);                        \
+    }                                                                                                            \
+    }                                                                                                            \
+    if (S > 0) {     /* semantic gradients: DPP row sums only (no cross-row ds_bpermute round trips); the four row   */ \
+        float ts = 0.f;  /* totals of feature k sit in lanes 16 r + k and go out as ONE atomic instruction            */ \
+_Pragma("unroll")                                                                                                        \
+        for (int k = 0; k < S; ++k) { const float t = row_sum16(vs[k]); ts = (lane & 15) == k ? t : ts; }            \
+        if ((lane & 15) < S && ts != 0.f) atomicAdd(sgrad_sem + (size_t)gid * S + (lane & 15), ts);              \
+    }                                                                                                            \
+    }                                                                                                            \
+} while (0)
 
 // ================= backward, row-packed: four 4x4 sub-blocks of the quad walk their OWN survivor lists ======================
 // The survivors of the 8x8 culling hit 10 of the 64 pixels on average (profiles/r3_hit_histogram_metric.txt) -- the wave
@@ -678,7 +591,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_RO
                                                                const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ meta,
                                                                int num_tiles, int gxc, const float* __restrict__ final_T,
                                                                const uint32_t* __restrict__ n_contrib,
-                                                               const float* __restrict__ moments,
+                                                               const float* __restrict__ moments, const float* __restrict__ ckpt,
                                                                const float* __restrict__ dL_dout, GradRec* __restrict__ sgrad,
                                                                float* __restrict__ sgrad_sem, int rows_bias, int rows_pair_cost, int det_sel) {
 #ifdef VCR_DETERMINISTIC_BWD
@@ -694,6 +607,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_RO
     if (tile < 0) return;
     const PixelMap pm = pixel_of_thread_rows(tile, gx, a.W, a.H, sub);
     const uint2 range = list_range<QL>(ranges, gxc, tile, gx, threadIdx.x >> 6);
+    const float* const ck = ckpt + ckpt_base<QL>(range.x, gxc, tile, gx, threadIdx.x >> 6) + (size_t)((pm.y & 7) * 8 + (pm.x & 7));
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = lane >> 4;
     constexpr bool SEM_IN_REC = false;
@@ -726,6 +640,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_RO
     for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, o));
     if (maxc == 0) return;                                 // wave-uniform
     float T = Tf, Bsuf = bgdot;
+    double Td = (double)Tf, Bd = (double)bgdot;      // (VCR_DBG_PIX64 only; dead otherwise)
+    (void)Td; (void)Bd;
     const f2 g01 = {g[0], g[1]}, g24 = {g[2], g[4]}, g56 = {g[5], g[6]}, ryz = {ry, rz};
 
     int chunk = (int)((maxc - 1) / 64);
@@ -740,6 +656,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_RO
         VCR_GATHER_REC(nid, nq0, nq1, nq2, nq3);
         VCR_GATHER_SEM(nid, nqs);
         VCR_LOAD_ID(chunk > 1 ? range.x + (uint32_t)(chunk - 2) * 64u + lane : lim, lim, nnid, nnvalid);
+        const float ckT = (chunk > 0 && pm.inside) ? ck[(size_t)chunk * VCR_CKPT_STRIDE] : 1.f;      // (see the v2 kernel)
         // cull against the live box of each 4x4 sub-block; one survivor mask per row
         const unsigned long long live = __builtin_amdgcn_ballot_w64(lastc > (uint32_t)chunk * 64u);
         unsigned long long mr[4];
@@ -817,7 +734,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_RO
                 if (hitm_ != 0) {                                                                                          \
                     VCR_BWD_MATH(R);                                                                                       \
                     const float tot = row_reduce16(v, lane);                                                               \
-                    if (tot != 0.f) atomicAdd(reinterpret_cast<float*>(sgrad + gid) + (lane & 15), tot);                   \
+                    if (tot != 0.f) VCR_GRAD_ATOMIC(gid, lane & 15, tot);                                                  \
                     if (S > 0) {                                                                                           \
                         float ts = 0.f;                                                                                    \
 _Pragma("unroll")                                                                                                          \
@@ -843,6 +760,7 @@ _Pragma("unroll")                                                               
                 if (++it >= iters) break;
             }
         }
+        if (VCR_T_ANCHOR && chunk > 0) { T = ckT; Td = (double)ckT; }
         id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; qs = nqs; valid = nvalid; nid = nnid; nvalid = nnvalid;
     }
 }
@@ -853,7 +771,7 @@ int launch_fwd_fc(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im
     const int gxc = a.quad_lists ? 2 * ((a.W + VCR_TILE - 1) / VCR_TILE) : 0;
 #define VCR_FWD_Q(FC, NDD, Q)                                                                                     \
     hipLaunchKernelGGL((composite_fwd_v2_kernel<S, ISECT, FC, NDD, Q>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
-                       b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, o.out, o.count, o.score)
+                       b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, o.out, o.count, o.score, im.t_ckpt)
 #define VCR_FWD(FC, NDD) do { if (gxc) { VCR_FWD_Q(FC, NDD, true); } else { VCR_FWD_Q(FC, NDD, false); } } while (0)
     switch (a.f_count) {
         case 0: VCR_FWD(0, ND); break;
@@ -883,26 +801,19 @@ template <bool ISECT, int ND>
 int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, const float* dL_dout, GradRec* sgrad,
                  float* sgrad_sem, int tiles, hipStream_t st) {
     const int gxc = a.quad_lists ? 2 * ((a.W + VCR_TILE - 1) / VCR_TILE) : 0;
-    static const bool rows = []() { const char* e = getenv("VCR_BWD_ROWS"); return e ? atoi(e) != 0 : true; }();
     // per chunk: row-packed loop iff 16 * max_r |list_r| + pair * sum_r |list_r| <= bias * |union_r list_r| (the second term
     // prices the atomics: an iteration with all four rows live issues 64 atomic lanes instead of 16).  bias 0 = never,
     // (64, 0) = always; (20, 2) from the sweep in profiles/r3_bwd_rows_ab.txt
-    static const int rows_bias = []() { const char* e = getenv("VCR_BWD_ROWS_BIAS"); return e ? atoi(e) : 20; }();
-    static const int rows_pair_cost = []() { const char* e = getenv("VCR_BWD_ROWS_PAIR"); return e ? atoi(e) : 2; }();
+    constexpr int rows_bias = 20, rows_pair_cost = 2;
 #ifdef VCR_DETERMINISTIC_BWD
     const int det_first = 0, det_last = 4 * (tiles + 3 * VCR_SPLIT_MAX);      // one launch per (workgroup, wave), in order
 #else
     const int det_first = -1, det_last = 0;
 #endif
 #define VCR_BWD_Q(SS, Q)                                                                                         \
-    for (int det = det_first; det < det_last; ++det) {                                                           \
-        if (rows)                                                                                                \
-            hipLaunchKernelGGL((composite_bwd_rows_kernel<SS, ISECT, ND, Q>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
-                               b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem, rows_bias, rows_pair_cost, det); \
-        else                                                                                                     \
-            hipLaunchKernelGGL((composite_bwd_v2_kernel<SS, ISECT, ND, Q>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
-                               b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, dL_dout, sgrad, sgrad_sem, det); \
-    }
+    for (int det = det_first; det < det_last; ++det)                                                             \
+        hipLaunchKernelGGL((composite_bwd_rows_kernel<SS, ISECT, ND, Q>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
+                           b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, im.t_ckpt, dL_dout, sgrad, sgrad_sem, rows_bias, rows_pair_cost, det);
 #define VCR_BWD(SS) do { if (gxc) { VCR_BWD_Q(SS, true) } else { VCR_BWD_Q(SS, false) } } while (0)
     switch (a.S) {
         case 0: VCR_BWD(0); break;
@@ -918,6 +829,30 @@ int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
 }
 
 }  // namespace
+
+#ifdef VCR_DBG_ACC64
+namespace {
+__global__ void acc64_to_sgrad_kernel(int N, const double* __restrict__ acc, float* __restrict__ sgrad) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)N * 16) sgrad[i] = (float)acc[i];
+}
+double* g_acc64_host = nullptr;
+}
+int vcr_dbg_acc64_begin(int N, hipStream_t st) {
+    VCR_HIP_CHECK(hipStreamSynchronize(st));
+    if (g_acc64_host) { VCR_HIP_CHECK(hipFree(g_acc64_host)); g_acc64_host = nullptr; }
+    VCR_HIP_CHECK(hipMalloc((void**)&g_acc64_host, sizeof(double) * 16 * (size_t)N));
+    VCR_HIP_CHECK(hipMemsetAsync(g_acc64_host, 0, sizeof(double) * 16 * (size_t)N, st));
+    VCR_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_acc64), &g_acc64_host, sizeof(double*), 0, hipMemcpyHostToDevice, st));
+    return 0;
+}
+int vcr_dbg_acc64_end(int N, GradRec* sgrad, hipStream_t st) {
+    hipLaunchKernelGGL(acc64_to_sgrad_kernel, dim3((unsigned)(((size_t)N * 16 + 255) / 256)), dim3(256), 0, st, N, g_acc64_host,
+                       reinterpret_cast<float*>(sgrad));
+    VCR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+#endif
 
 extern "C" int vcr_debug_hit_histogram(uint32_t out[130], int reset) {
 #ifdef VCR_HITHIST

@@ -49,7 +49,7 @@ __device__ __forceinline__ ActOut activate_one(const float l[3], float4 qr, floa
 __device__ __forceinline__ void activate_bwd_one(const float l[3], float4 qr, float oraw, const float* __restrict__ Rw2c, uint8_t aux,
                                                  bool has_s, const float ds[3], bool has_q, float4 dq, bool has_o, float dop,
                                                  bool has_n, const float dn[3], const float extra[3], float gs[3], float4& gq,
-                                                 float& go) {
+                                                 float& go, bool n_world = false) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) gs[k] = (has_s ? ds[k] * expf(l[k]) : 0.f) + extra[k];
     const float o = 1.f / (1.f + expf(-oraw));
@@ -62,10 +62,10 @@ __device__ __forceinline__ void activate_bwd_one(const float l[3], float4 qr, fl
         const int axis = aux & 3;
         const float sgn = (aux & 4) ? -1.f : 1.f;
         const float c0 = dn[0], c1 = dn[1], c2 = dn[2];
-        // n_cam = Rw2c * (sgn * R[:,axis])
-        const float w0 = sgn * (Rw2c[0] * c0 + Rw2c[3] * c1 + Rw2c[6] * c2);
-        const float w1 = sgn * (Rw2c[1] * c0 + Rw2c[4] * c1 + Rw2c[7] * c2);
-        const float w2 = sgn * (Rw2c[2] * c0 + Rw2c[5] * c1 + Rw2c[8] * c2);
+        // n_cam = Rw2c * (sgn * R[:,axis]); n_world: `dn` already is the gradient w.r.t. R[:,axis] (summed over the ranks' views)
+        const float w0 = n_world ? c0 : sgn * (Rw2c[0] * c0 + Rw2c[3] * c1 + Rw2c[6] * c2);
+        const float w1 = n_world ? c1 : sgn * (Rw2c[1] * c0 + Rw2c[4] * c1 + Rw2c[7] * c2);
+        const float w2 = n_world ? c2 : sgn * (Rw2c[2] * c0 + Rw2c[5] * c1 + Rw2c[8] * c2);
         float dR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         dR[axis] = w0; dR[3 + axis] = w1; dR[6 + axis] = w2;
         float h[4];
@@ -149,10 +149,15 @@ __device__ __forceinline__ void geometry_step_one(const VcrGeometryStep& a, cons
     }
     float gs[3], go;
     float4 gq;
-    const float4 dq_up = REGS ? t.dq : (a.d_rots ? reinterpret_cast<const float4*>(a.d_rots)[i] : make_float4(0.f, 0.f, 0.f, 0.f));
-    const float dop_up = REGS ? t.dop : (a.d_opac ? a.d_opac[i] : 0.f);
+    float4 dq_up = REGS ? t.dq : (a.d_rots ? reinterpret_cast<const float4*>(a.d_rots)[i] : make_float4(0.f, 0.f, 0.f, 0.f));
+    float dop_up = REGS ? t.dop : (a.d_opac ? a.d_opac[i] : 0.f);
+    // data parallel: the upstream gradients are sums over the ranks' views -- their mean is what Adam sees; the l1_scale term
+    // (`ex`, a function of the replicated parameters only) is added once, unscaled
+    const float gsc = a.grad_scale;
+    ds[0] *= gsc; ds[1] *= gsc; ds[2] *= gsc; dn[0] *= gsc; dn[1] *= gsc; dn[2] *= gsc;
+    dq_up.x *= gsc; dq_up.y *= gsc; dq_up.z *= gsc; dq_up.w *= gsc; dop_up *= gsc;
     activate_bwd_one(l, qr, oraw, a.Rw2c, has_n ? a.aux[i] : (uint8_t)0, has_s, ds, has_q, dq_up, has_o, dop_up, has_n, dn, ex,
-                     gs, gq, go);
+                     gs, gq, go, a.normals_world != 0);
     // ---- densification statistics (scene/gaussian_model.py:669-671, trainer.py:345)
     if (REGS ? a.accum != nullptr : a.grad2d != nullptr) {
         const int r = REGS ? t.radius : a.radii[i];
@@ -169,7 +174,7 @@ __device__ __forceinline__ void geometry_step_one(const VcrGeometryStep& a, cons
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             float m = a.m_xyz[i3 + k], v = a.v_xyz[i3 + k];
-            adam_one(p[k], m, v, REGS ? t.dp[k] : a.d_means3D[i3 + k], b1, b2, eps, st_xyz, gb.bc2[0]);
+            adam_one(p[k], m, v, gsc * (REGS ? t.dp[k] : a.d_means3D[i3 + k]), b1, b2, eps, st_xyz, gb.bc2[0]);
             a.m_xyz[i3 + k] = m; a.v_xyz[i3 + k] = v; a.xyz[i3 + k] = p[k];
         }
     }

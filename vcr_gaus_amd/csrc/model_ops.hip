@@ -424,6 +424,7 @@ extern "C" int vcr_geometry_step(const VcrGeometryStep* args, void* stream) {
         (a.next_scales && (!a.next_rots || !a.next_opac || (a.next_normals && (!a.next_campos || !a.next_Rw2c || !a.next_aux))))) {
         vcr_set_error("vcr_geometry_step: inconsistent arguments"); return 1;
     }
+    if (!(a.grad_scale > 0.f)) { vcr_set_error("vcr_geometry_step: grad_scale must be > 0 (1 on one GPU, 1 / world after a sum all-reduce)"); return 1; }
     if ((((uintptr_t)a.rotation) | ((uintptr_t)a.m_rotation) | ((uintptr_t)a.v_rotation) | ((uintptr_t)a.d_rots) | ((uintptr_t)a.next_rots)) & 15) {
         vcr_set_error("vcr_geometry_step: quaternion arrays must be 16-byte aligned"); return 1;
     }

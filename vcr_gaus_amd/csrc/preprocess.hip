@@ -368,7 +368,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const
 template <bool STAGE, bool COLOUR, bool QL>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, GeomState g, int32_t* __restrict__ radii,
                                                              uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
-                                                             uint32_t* __restrict__ vis_slots) {
+                                                             uint32_t* __restrict__ vis_slots, VcrPublished* host, uint32_t seq) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];
     if (STAGE) {
         const int base = blockIdx.x * 256;
@@ -382,6 +382,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
         atomicOr(vis_slots + VCR_FAR_FLAG_WORD, 1u);
     if (vis_slots) {
         __shared__ uint32_t s_cnt[3][4];
+        __shared__ bool s_last;
         uint32_t c = nt != 0 ? 1u : 0u, r = nt;
         for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); r += __shfl_xor(r, o); em += __shfl_xor(em, o); }
         if ((threadIdx.x & 63) == 0) { s_cnt[0][threadIdx.x >> 6] = c; s_cnt[1][threadIdx.x >> 6] = r; s_cnt[2][threadIdx.x >> 6] = em; }
@@ -389,6 +390,53 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
         if (threadIdx.x < 3) {
             const uint32_t t = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
             if (t) atomicAdd(vis_slots + threadIdx.x * VCR_VIS_SLOTS + blockIdx.x % VCR_VIS_SLOTS, t);
+        }
+        if (!host) return;
+        // Epilogue of the LAST workgroup to arrive (round 5, was publish_counts_kernel + a memset in front of every call): every
+        // workgroup orders its counter atomics before its ticket; the one that draws the last ticket therefore sees all of them,
+        // folds the slots, hands the totals to the spinning host and leaves the counter block zero for the next call.
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // two-level ticket (vcr_common.h): the last arrival of group b % 64 resets the group word and draws the top ticket
+            const uint32_t grp = blockIdx.x % VCR_DONE_GROUPS;
+            const uint32_t in_grp = (gridDim.x - grp + VCR_DONE_GROUPS - 1) / VCR_DONE_GROUPS;
+            const uint32_t groups = gridDim.x < VCR_DONE_GROUPS ? gridDim.x : VCR_DONE_GROUPS;
+            bool last = false;
+            if (atomicAdd(vis_slots + VCR_DONE_GROUP_WORD + grp, 1u) == in_grp - 1) {
+                __hip_atomic_store(vis_slots + VCR_DONE_GROUP_WORD + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence();
+                last = atomicAdd(vis_slots + VCR_DONE_WORD, 1u) == groups - 1;
+            }
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();
+        __shared__ unsigned long long s_r[4], s_e[4];
+        __shared__ uint32_t s_v[4];
+        unsigned long long rr = 0, ee = 0; uint32_t vv = 0;
+        for (int k = threadIdx.x; k < VCR_VIS_SLOTS; k += 256) {
+            vv += __hip_atomic_load(vis_slots + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            rr += __hip_atomic_load(vis_slots + VCR_VIS_SLOTS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ee += __hip_atomic_load(vis_slots + 2 * VCR_VIS_SLOTS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(vis_slots + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(vis_slots + VCR_VIS_SLOTS + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(vis_slots + 2 * VCR_VIS_SLOTS + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (int o = 32; o > 0; o >>= 1) { vv += __shfl_xor(vv, o); rr += __shfl_xor(rr, o); ee += __shfl_xor(ee, o); }
+        if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = vv; s_r[threadIdx.x >> 6] = rr; s_e[threadIdx.x >> 6] = ee; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t farw = __hip_atomic_load(vis_slots + VCR_FAR_FLAG_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(vis_slots + VCR_FAR_FLAG_WORD, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(vis_slots + VCR_DONE_WORD, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host->R = s_r[0] + s_r[1] + s_r[2] + s_r[3];
+            host->E = s_e[0] + s_e[1] + s_e[2] + s_e[3];
+            host->V = s_v[0] + s_v[1] + s_v[2] + s_v[3];
+            host->far = farw;
+            __threadfence_system();
+            host->seq = seq;
         }
     }
 }
@@ -436,8 +484,8 @@ struct TailArgs { VcrGeometryStep t; GeomBias gb; };
 
 template <bool STAGE, bool TAIL>
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, GeomState g, const int32_t* __restrict__ radii,
-                                                             const GradRec* __restrict__ sgrad,
-                                                             const float* __restrict__ sgrad_sem, VcrBackwardIO io, TailArgs ta) {
+                                                             GradRec* __restrict__ sgrad,
+                                                             float* __restrict__ sgrad_sem, VcrBackwardIO io, TailArgs ta) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int blk_base = blockIdx.x * 256, blk_cnt = min(256, a.N - blk_base);
@@ -456,12 +504,22 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
     float R[9], s[3], S[6];
     float dsc[3] = {0.f, 0.f, 0.f};
     float dq[4] = {0.f, 0.f, 0.f, 0.f};
+    float dsem[VCR_MAX_SEM] = {0.f, 0.f, 0.f, 0.f};
 
     if (vis) {
         const Cam cam = load_cam(a);
         const float* V = cam.V;
         const float* P = cam.P;
         GradRec gr = sgrad[i];
+        // The accumulators are library-owned and zero between calls (round 5: no 64 B x N memset in front of every backward):
+        // this kernel is their only reader, so it clears each record behind its own read.  Records of culled Gaussians were
+        // never written (they are in no list).
+        {
+            const float4 z4 = {0.f, 0.f, 0.f, 0.f};
+            float4* zr = reinterpret_cast<float4*>(sgrad + i);
+            zr[0] = z4; zr[1] = z4; zr[2] = z4; zr[3] = z4;
+            for (int k = 0; k < a.S; ++k) { dsem[k] = sgrad_sem[(size_t)i * a.S + k]; sgrad_sem[(size_t)i * a.S + k] = 0.f; }
+        }
         gr.finish(a.opacities[i]);
         const float p[3] = {a.means3D[i3], a.means3D[i3 + 1], a.means3D[i3 + 2]};
         Proj pr;
@@ -514,6 +572,14 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
             const float n[3] = {a.normals_precomp[i3], a.normals_precomp[i3 + 1], a.normals_precomp[i3 + 2]};
             dt[0] += n[0] * gr.plane; dt[1] += n[1] * gr.plane; dt[2] += n[2] * gr.plane;
             dn[0] = gr.nx + pr.t[0] * gr.plane; dn[1] = gr.ny + pr.t[1] * gr.plane; dn[2] = gr.nz + pr.t[2] * gr.plane;
+            if (!TAIL && io.normals_Rw2c) {        // data parallel: as the gradient w.r.t. the world-space axis column (vcr_raster.h)
+                const float* Rw = io.normals_Rw2c;
+                const float sg = (io.normals_aux[i] & 4) ? -1.f : 1.f;
+                const float w0 = sg * (Rw[0] * dn[0] + Rw[3] * dn[1] + Rw[6] * dn[2]);
+                const float w1 = sg * (Rw[1] * dn[0] + Rw[4] * dn[1] + Rw[7] * dn[2]);
+                const float w2 = sg * (Rw[2] * dn[0] + Rw[5] * dn[1] + Rw[8] * dn[2]);
+                dn[0] = w0; dn[1] = w1; dn[2] = w2;
+            }
         }
         // t = p Rv^T + tv  ->  dp_k += sum_c dt_c V[k*4+c]
 #pragma unroll
@@ -601,7 +667,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
         if (io.dL_dcolors) { io.dL_dcolors[i3] = dcol[0]; io.dL_dcolors[i3 + 1] = dcol[1]; io.dL_dcolors[i3 + 2] = dcol[2]; }
         if (io.dL_drgb) { io.dL_drgb[i3] = dcol[0]; io.dL_drgb[i3 + 1] = dcol[1]; io.dL_drgb[i3 + 2] = dcol[2]; }
         if (io.dL_dsemantics)
-            for (int k = 0; k < a.S; ++k) io.dL_dsemantics[(size_t)i * a.S + k] = vis ? sgrad_sem[(size_t)i * a.S + k] : 0.f;
+            for (int k = 0; k < a.S; ++k) io.dL_dsemantics[(size_t)i * a.S + k] = dsem[k];
         TailGrads tg;
         tg.dp[0] = dp[0]; tg.dp[1] = dp[1]; tg.dp[2] = dp[2];
         tg.ds[0] = dsc[0]; tg.ds[1] = dsc[1]; tg.ds[2] = dsc[2];
@@ -626,7 +692,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
     if (io.dL_drgb) { io.dL_drgb[i3] = dcol[0]; io.dL_drgb[i3 + 1] = dcol[1]; io.dL_drgb[i3 + 2] = dcol[2]; }
     if (io.dL_dnormals) { io.dL_dnormals[i3] = dn[0]; io.dL_dnormals[i3 + 1] = dn[1]; io.dL_dnormals[i3 + 2] = dn[2]; }
     if (io.dL_dsemantics)
-        for (int k = 0; k < a.S; ++k) io.dL_dsemantics[(size_t)i * a.S + k] = vis ? sgrad_sem[(size_t)i * a.S + k] : 0.f;
+        for (int k = 0; k < a.S; ++k) io.dL_dsemantics[(size_t)i * a.S + k] = dsem[k];
     if (io.dL_dscales) {
         io.dL_dscales[i3] = dsc[0]; io.dL_dscales[i3 + 1] = dsc[1]; io.dL_dscales[i3 + 2] = dsc[2];
         reinterpret_cast<float4*>(io.dL_drotations)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
@@ -958,17 +1024,17 @@ int vcr_launch_depth_keys(const VcrRasterArgs& a, uint32_t* depth_key, hipStream
 }
 
 int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key, uint32_t* ids,
-                          uint32_t* vis_slots, bool colour, hipStream_t st) {
+                          uint32_t* vis_slots, bool colour, hipStream_t st, VcrPublished* host, uint32_t seq) {
     if (a.N == 0) return 0;
     const int blocks = (a.N + 255) / 256;
 #define VCR_PRE(STAGE, COLOUR, SMEM)                                                                                          \
     do {                                                                                                                       \
         if (a.quad_lists)                                                                                                      \
             hipLaunchKernelGGL((preprocess_fwd_kernel<STAGE, COLOUR, true>), dim3(blocks), dim3(256), SMEM, st, a, g, radii,   \
-                               depth_key, ids, vis_slots);                                                                     \
+                               depth_key, ids, vis_slots, host, seq);                                                          \
         else                                                                                                                   \
             hipLaunchKernelGGL((preprocess_fwd_kernel<STAGE, COLOUR, false>), dim3(blocks), dim3(256), SMEM, st, a, g, radii,  \
-                               depth_key, ids, vis_slots);                                                                     \
+                               depth_key, ids, vis_slots, host, seq);                                                          \
     } while (0)
     if (!colour) VCR_PRE(false, false, 0);
     else if (a.shs && a.K == SH_K) VCR_PRE(true, true, 256 * SH_ROW * sizeof(float));
@@ -983,10 +1049,8 @@ int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, u
 // workgroups per CU up to 3 M Gaussians (round 4, profiles/r4_side_grid.txt: 256 / 320 / 384 / 512 / 768 workgroups -> step 1.355 /
 // 1.374 / 1.345 / 1.356 / 1.367 ms at 1 M, 2.54 / 2.50 / 2.45 / 2.53 / 2.54 at 2 M: more of them slow the chain down by more
 // than the update gains) and four per CU above (5 M, profiles/r4_side_grid_c5.txt: 512 / 640 / 768 / 1024 -> 3.79 / 3.92 / 3.78 / 3.735
-// ms/step).  VCR_SIDE_GRID overrides.
+// ms/step).
 int vcr_side_grid(int N) {
-    static const int g = [] { const char* e = getenv("VCR_SIDE_GRID"); return e ? atoi(e) : 0; }();
-    if (g > 0) return g;
     return N > 3000000 ? 1024 : 384;
 }
 
@@ -1015,8 +1079,8 @@ int vcr_launch_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st) {
     return 0;
 }
 
-int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const GradRec* sgrad,
-                                   const float* sgrad_sem, VcrBackwardIO& io, hipStream_t st) {
+int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const int32_t* radii, GradRec* sgrad,
+                                   float* sgrad_sem, VcrBackwardIO& io, hipStream_t st) {
     if (a.N == 0) return 0;
     const int blocks = (a.N + 255) / 256;
     const TailArgs none = {};
@@ -1032,8 +1096,8 @@ int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const in
 
 // projection backward + the static tail of the iteration in one kernel (vcr_rasterize_backward_tail).  `io.dL_dmeans2D_densify`
 // non-NULL only says WHICH screen gradient the densification statistics take (nothing is written through it).
-int vcr_launch_preprocess_backward_tail(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const GradRec* sgrad,
-                                        const float* sgrad_sem, VcrBackwardIO& io, const VcrGeometryStep& t, hipStream_t st) {
+int vcr_launch_preprocess_backward_tail(const VcrRasterArgs& a, GeomState g, const int32_t* radii, GradRec* sgrad,
+                                        float* sgrad_sem, VcrBackwardIO& io, const VcrGeometryStep& t, hipStream_t st) {
     if (a.N == 0) return 0;
     TailArgs ta;
     ta.t = t;

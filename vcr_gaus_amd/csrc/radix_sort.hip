@@ -386,13 +386,13 @@ size_t vcr_sort_scratch_bytes(int64_t n) {
 
 // Pass plan for `bits` key bits -> number of passes, bits of every pass in `out`.  Digits of at most 9 bits by default (round 4:
 // the depth keys are 27 bits wide, vcr_depth_sort -> 3 x 9; 16-17 tile / cell bits -> 2 passes instead of 3; every plan of at
-// most 8 bits per pass is unchanged).  VCR_SORT_DIGIT_BITS = 8 ... 11 overrides (11: 3 passes over 32-bit keys).  Measured at 1 M keys
+// most 8 bits per pass is unchanged; the A/B against 8 and 11 bits: profiles/r4_sort_digits.txt).  Measured at 1 M keys
 // (profiles/r3_sort_ab.txt): 3 x 11 bits 88 us stand-alone / 146 us inside the step against 4 x 8 bits 79 / 137 us -- with
 // 2048 digits and 4096 items per workgroup a run of equal digits is 2 items long, so the scatter of the first passes
 // degenerates to single stores, and the scan kernel works on 8 KB rows; the wide digits lose more per pass than the
 // saved pass returns.
 static int rs_plan(int bits, int out[4]) {
-    static const int max_digit = [] { const char* e = getenv("VCR_SORT_DIGIT_BITS"); const int v = e ? atoi(e) : 9; return v < 8 ? 8 : (v > 11 ? 11 : v); }();
+    constexpr int max_digit = 9;
     int passes = bits <= 8 ? 1 : (bits <= 16 ? 2 : (bits <= 2 * max_digit ? 2 : (bits <= 3 * max_digit ? 3 : 4)));
     for (int p = 0, left = bits; p < passes; ++p) {
         out[p] = (left + (passes - p) - 1) / (passes - p);
@@ -439,11 +439,8 @@ int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, 
 
 int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, uint32_t* meta, int64_t instances, bool lpt, bool snake,
                           hipStream_t st, int gxc) {
-    // workgroup slots of the compositing kernels on the chip: 5 resident 256-thread workgroups per CU (VCR_SPLIT_SLOTS overrides;
-    // 0 disables the split work items)
+    // workgroup slots of the compositing kernels on the chip: 5 resident 256-thread workgroups per CU
     static const int slots = [] {
-        const char* e = getenv("VCR_SPLIT_SLOTS");
-        if (e) return atoi(e);
         int dev = 0, cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)

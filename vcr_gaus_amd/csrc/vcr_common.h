@@ -100,10 +100,15 @@ struct BinState {
     uint32_t* meta;        // [VCR_BIN_META_WORDS] written by tile_order: [0] number S of heaviest tiles launched as split work
                            //     items (composite.hip), [1] non-empty tiles, [2] longest tile list
     uint32_t* point_list;  // [R'] Gaussian ids, (tile, depth, id)-ordered; LAST, so that the views above do not depend on R'
-    static size_t bytes(int64_t R, int T) {
+    // `ckpt`: with the transmittance checkpoints of a training forward behind the lists (composite.hip: ckpt_base) --
+    // (R' / 64 + T + 1) records of 256 floats cover both list forms
+    static size_t ckpt_floats(int64_t R, int T) { return ((size_t)(R > 0 ? R : 0) / 64 + (size_t)T + 1) * 256; }
+    static size_t bytes(int64_t R, int T, bool ckpt = false) {
         return vcr_align(sizeof(uint2) * 4 * (size_t)T) + vcr_align(sizeof(uint32_t) * (size_t)T) +
-               vcr_align(sizeof(uint32_t) * VCR_BIN_META_WORDS) + vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1));
+               vcr_align(sizeof(uint32_t) * VCR_BIN_META_WORDS) + vcr_align(sizeof(uint32_t) * (size_t)(R > 0 ? R : 1)) +
+               (ckpt ? vcr_align(sizeof(float) * ckpt_floats(R, T)) : 0);
     }
+    static float* ckpt_of(void* p, int64_t R, int T) { return (float*)((char*)p + bytes(R, T, false)); }
     static BinState view(void* p, int T) {
         BinState b;
         char* c = (char*)p;
@@ -119,6 +124,7 @@ struct ImageState {
     float* final_T;        // [H*W]
     uint32_t* n_contrib;   // [H*W] index (1-based, within the tile list) of the last contributor
     float* moments;        // [2,H*W] sum w m, sum w m^2 of the mapped depth m (distortion channel, num_dist == 1)
+    float* t_ckpt = nullptr;   // per-chunk transmittance checkpoints; lives behind the lists of the BINNING buffer (its size follows R')
     static size_t bytes(int P) {
         return vcr_align(sizeof(float) * (size_t)P) + vcr_align(sizeof(uint32_t) * (size_t)P) +
                vcr_align(2 * sizeof(float) * (size_t)P);
@@ -162,19 +168,36 @@ void vcr_set_error(const char* fmt, ...);
 // ---- stage launchers (defined in the .hip files) ----------------------------------------------
 #define VCR_VIS_SLOTS 1024                    // counter slots for visible Gaussians / 3-sigma tile instances / emitted tile instances
 #define VCR_FAR_FLAG_WORD (3 * VCR_VIS_SLOTS)  // behind the three slot arrays: != 0 when a visible depth key needs more than 27 bits
+#define VCR_DONE_WORD (VCR_FAR_FLAG_WORD + 1)  // groups of projection workgroups that have all added their counts (the last one publishes)
+#define VCR_DUP_TICKET_WORD (VCR_FAR_FLAG_WORD + 2)   // logical block index of the emission kernel (its last block resets it)
+// "last workgroup" detection in TWO levels: thousands of atomics on ONE address serialise at ~190 ns each (measured: a single
+// ticket word made the 38 us projection of 1 M Gaussians take 730 us), so workgroup b first draws a ticket from group word
+// b % VCR_DONE_GROUPS (<= ~60 arrivals per address, spread over the kernel's run time), and only the last arrival of a group
+// draws from VCR_DONE_WORD
+#define VCR_DONE_GROUPS 64
+#define VCR_DONE_GROUP_WORD (VCR_FAR_FLAG_WORD + 64)
+#define VCR_CTR_WORDS (3 * VCR_VIS_SLOTS + 64 + VCR_DONE_GROUPS)
+// What the host polls after the projection: totals + a sequence number published by the device AFTER the totals (system-scope
+// fence).  R: tile instances of the 3-sigma rectangles (what the reference counts), E: instances really emitted (exact rejection).
+struct VcrPublished { unsigned long long R, E; uint32_t V; uint32_t far; volatile uint32_t seq; };
+// The counter block is LIBRARY-OWNED and zero between calls (round 5): the projection's last workgroup -- an atomic ticket on
+// VCR_DONE_WORD tells which one that is -- folds the slots, publishes the totals to `host` (pinned, coherent) and re-zeroes every
+// word it read, so neither a memset in front of the projection nor a publish kernel behind it is launched.
 int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key,
-                          uint32_t* ids, uint32_t* vis_slots, bool colour, hipStream_t st);
+                          uint32_t* ids, uint32_t* vis_slots, bool colour, hipStream_t st,
+                          VcrPublished* host = nullptr, uint32_t seq = 0);
 int vcr_launch_depth_keys(const VcrRasterArgs& a, uint32_t* depth_key, hipStream_t st);
 int vcr_launch_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st);
 int vcr_launch_sh_update_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st);   // a.sh_update + colour in one pass
 int vcr_side_grid(int N);     // workgroups of a side-stream kernel (one per CU up to 3 M Gaussians, two above; VCR_SIDE_GRID)
+// (`sgrad` / `sgrad_sem` are library-owned accumulators, zero between calls: the kernel clears every record behind its own read)
 int vcr_launch_preprocess_backward(const VcrRasterArgs& a, GeomState g, const int32_t* radii,
-                                   const GradRec* sgrad, const float* sgrad_sem, VcrBackwardIO& io,
+                                   GradRec* sgrad, float* sgrad_sem, VcrBackwardIO& io,
                                    hipStream_t st);
-int vcr_launch_preprocess_backward_tail(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const GradRec* sgrad,
-                                        const float* sgrad_sem, VcrBackwardIO& io, const VcrGeometryStep& t, hipStream_t st);
+int vcr_launch_preprocess_backward_tail(const VcrRasterArgs& a, GeomState g, const int32_t* radii, GradRec* sgrad,
+                                        float* sgrad_sem, VcrBackwardIO& io, const VcrGeometryStep& t, hipStream_t st);
 size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits);
-size_t vcr_duplicate_status_bytes(int N);
+size_t vcr_duplicate_status_words(int N);       // look-back words of the emission kernel (library-owned, tagged with the call number)
 // Depth keys (round 4): key = bits(z) - bits(VCR_NEAR) of the view-space depth z > VCR_NEAR -- monotone in z, and below
 // z = 13 107.2 it fits VCR_DEPTH_KEY_BITS = 27 bits, so the depth order takes THREE 9-bit passes instead of four 8-bit ones
 // (culled Gaussians carry 0xFFFFFFFF: last).  A visible Gaussian beyond that depth raises the `far` flag of the projection's
@@ -186,7 +209,7 @@ int vcr_depth_sort(int N, const uint32_t* depth_key, uint2* pair_a, uint2* pair_
                    void* temp, hipStream_t st);
 int vcr_depth_sort_far(int N, uint2* pair_a, uint32_t* ids_sorted, uint32_t* totals, void* temp, hipStream_t st);
 int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* radii, const uint32_t* ids_sorted,
-                           unsigned long long* status, int64_t R /* emitted instances */, int tile_bits, uint2* inst, uint2* pair_a,
+                           unsigned long long* status, uint32_t* ticket, uint32_t seq, int64_t R /* emitted instances */, int tile_bits, uint2* inst, uint2* pair_a,
                            uint2* pair_b, uint32_t* keys_b, uint32_t* point_list, uint2* ranges, uint32_t* tile_order,
                            uint32_t* meta, int num_tiles, uint32_t* totals, void* temp, size_t temp_bytes, hipStream_t st);
 // radix_sort.hip: hand-written stable radix sort of (u32 key, u32 value) pairs and the block-scheduling order

@@ -36,15 +36,21 @@ class GeometrySink:
       * `tail` / `done`: the same tail INSIDE the rasterizer's backward (`vcr_rasterize_backward_tail`): `tail()` -> the
         argument block + commit of `FusedAdam.prepare_geometry_step(in_registers=True)`; the rasterizer node (which holds this
         sink through its `RasterOptions`) calls it, sets `done`, and returns no gradient for means / scales / rotations /
-        opacities / normals, so the activation backward has nothing left to do;
+        opacities / normals, so the activation backward has nothing left to do.  NOT atomic with the rest of the step: Adam on
+        xyz / scaling / rotation / opacity is applied in the middle of `loss.backward()`; if anything raises later in the same
+        backward or in the gradient exchange, the geometry has been stepped and the SH coefficients have not -- `started` is
+        set before the launch and the trainer then reports `last_tail = "raster-partial"`: such a step must not be retried;
       * `sums`: the trainer's cache of the loss node's fp64 reduction buffer, {device: [buffer, in use]} (re-zeroed by the
         finalize kernel, so it can be re-used from step to step instead of being allocated and cleared)."""
-    __slots__ = ("armed", "grads", "saved", "scale_reg", "defer_scale_grad", "scale_grad", "sums", "tail", "done", "want_normal")
+    __slots__ = ("armed", "grads", "saved", "scale_reg", "defer_scale_grad", "scale_grad", "sums", "tail", "done", "want_normal",
+                 "started", "exchange")
 
     def __init__(self, armed=True, defer_scale_grad=False, sums=None, tail=None):
         self.armed, self.grads, self.saved, self.scale_reg = armed, None, None, None
         self.defer_scale_grad, self.scale_grad, self.sums = defer_scale_grad, None, sums
         self.tail, self.done, self.want_normal = tail, False, None
+        self.exchange = False         # data parallel: the rasterizer's backward writes dL/dnormals in world space (see Trainer)
+        self.started = False          # set right before the tail's launch inside the rasterizer's backward (see `Trainer.last_tail`)
 
 
 class _FusedActivate(torch.autograd.Function):
@@ -85,7 +91,18 @@ class _FusedActivate(torch.autograd.Function):
             return (None,) * 9                   # (e.g. the rasterizer's backward has applied the static tail itself)
         sr, rr, orr, Rw, aux = ctx.saved_tensors
         N = sr.shape[0]
+        if ctx.sink is not None and ctx.sink.done:
+            # the rasterizer's backward has already applied Adam to these parameters from ITS gradients; one that arrives here
+            # now came by another path (a loss on the activated scales / opacities / normals that bypasses the rasterizer) and
+            # would be dropped silently
+            raise RuntimeError("fused geometry tail: a gradient reached the activated scales / rotations / opacities / normals "
+                               "outside the rasterizer after the tail had run inside its backward; set "
+                               "Trainer.fuse_geometry = False for such losses")
         keep = [None if t is None else t.contiguous().float() for t in (d_scales, d_rots, d_opac, d_nrm)]
+        if ctx.sink is not None and ctx.sink.exchange and not (ctx.sink.armed and ctx.sink.grads is None):
+            # (the rasterizer wrote dL/dnormals in the world-space form of the data-parallel exchange: only the one-kernel tail
+            #  understands it)
+            raise RuntimeError("fused geometry tail: the data-parallel exchange form was requested but the sink is not armed")
         if ctx.sink is not None and ctx.sink.armed and ctx.sink.grads is None:
             # fused static tail: `FusedAdam.geometry_step` applies this adjoint together with Adam in one pass
             ctx.sink.grads, ctx.sink.saved = keep, (sr, rr, orr, Rw, aux)
@@ -108,7 +125,7 @@ class ActivationCache:
     for the camera of this one (`VcrGeometryStep.next_*`: the parameters are in registers there anyway).  One-shot: the next
     `fused_activate` on the model takes it if -- and only if -- it asks for the same camera tensors, the same `want_normal`
     and the raw parameters are the tensors (storage and version counter) the tail updated; anything else drops it."""
-    __slots__ = ("campos", "R", "want_normal", "tensors", "stamp")
+    __slots__ = ("campos", "R", "want_normal", "tensors", "stamp", "params")
 
     @staticmethod
     def stamp_of(pc):
@@ -117,10 +134,14 @@ class ActivationCache:
     def __init__(self, pc, campos, R, want_normal, tensors):
         self.campos, self.R, self.want_normal, self.tensors = campos, R, want_normal, tensors
         self.stamp = self.stamp_of(pc)
+        # the parameter OBJECTS the tail updated: the kernels write through raw pointers (the version counter stays 0), so a
+        # rebuilt parameter that the caching allocator put at the same address would carry the same stamp
+        self.params = (pc._scaling, pc._rotation, pc._opacity, pc._xyz)
 
     def matches(self, pc, campos, R, want_normal):
         return (campos is self.campos or campos.data_ptr() == self.campos.data_ptr()) and \
             (R is self.R or R.data_ptr() == self.R.data_ptr()) and bool(want_normal) == bool(self.want_normal) and \
+            all(a is b for a, b in zip(self.params, (pc._scaling, pc._rotation, pc._opacity, pc._xyz))) and \
             self.stamp == self.stamp_of(pc)
 
 
@@ -191,11 +212,14 @@ class FusedAdam:
                 g["params"][0].grad = None
 
     @torch.no_grad()
-    def prepare_geometry_step(self, model, sink, grad2d=None, radii=None, in_registers=False, stats=False, next_cam=None):
+    def prepare_geometry_step(self, model, sink, grad2d=None, radii=None, in_registers=False, stats=False, next_cam=None,
+                              normals_world=False):
         """-> (VcrGeometryStep, commit): the argument block of the static tail and the host bookkeeping to run once the launch
         has been accepted (Adam step counters, `_xyz.grad`).  `in_registers`: the form `vcr_rasterize_backward_tail` takes
         -- no upstream gradient arrays (they stay inside the projection-backward kernel), `stats` instead of `grad2d` /
-        `radii`, and xyz always stepped."""
+        `radii`, and xyz always stepped.  `normals_world`: the data-parallel form -- `sink.grads` / `_xyz.grad` hold the
+        all-reduced activated-space gradients, the normal gradient w.r.t. the world-space axis column
+        (`RasterOptions.world_normals`); `self.grad_scale` (1 / world) is applied inside the kernel."""
         groups = {g["name"]: g for g in self.param_groups}
         sr, rr, orr, Rw, aux = sink.saved
         if in_registers:
@@ -216,7 +240,8 @@ class FusedAdam:
         sreg = sink.scale_reg
         want_stats = stats if in_registers else grad2d is not None
         a = _lib.VcrGeometryStep(
-            N=N, step_xyz=nxt["xyz"] if step_xyz else 0, step_scaling=nxt["scaling"],
+            N=N, normals_world=int(bool(normals_world)), grad_scale=float(self.grad_scale),
+            step_xyz=nxt["xyz"] if step_xyz else 0, step_scaling=nxt["scaling"],
             step_rotation=nxt["rotation"], step_opacity=nxt["opacity"],
             xyz=model._xyz.data_ptr(), scaling=sr.data_ptr(), rotation=rr.data_ptr(), opacity=orr.data_ptr(),
             d_means3D=ptr(gxc), d_scales=ptr(d_scales), d_rots=ptr(d_rots), d_opac=ptr(d_opac), d_normals=ptr(d_nrm),
@@ -256,14 +281,14 @@ class FusedAdam:
         return a, commit
 
     @torch.no_grad()
-    def geometry_step(self, model, sink, grad2d=None, radii=None, next_cam=None):
+    def geometry_step(self, model, sink, grad2d=None, radii=None, next_cam=None, normals_world=False):
         """The static tail of an iteration in ONE launch (`vcr_geometry_step`): adjoint of the fused activation + l1_scale
         gradient (from `sink`) -> densification statistics (`grad2d` [N,3] = `means2D_densify.grad`, `radii`; None = skip)
         -> Adam on xyz / scaling / rotation / opacity.  Same arithmetic as activate-backward + `add_densification_stats` +
         `step()` on those groups; their `.grad` must not be set elsewhere (`_xyz.grad` is consumed and cleared here)."""
         if model._xyz.shape[0] == 0:
             return
-        a, commit = self.prepare_geometry_step(model, sink, grad2d, radii, next_cam=next_cam)
+        a, commit = self.prepare_geometry_step(model, sink, grad2d, radii, next_cam=next_cam, normals_world=normals_world)
         _lib.check(_lib.load().vcr_geometry_step(C.byref(a), _lib.stream_of(model._xyz)))
         commit()
 

@@ -94,16 +94,21 @@ class RasterOptions:
       tail             an object with `.armed`, `.done` and `.tail()` -> (_lib.VcrGeometryStep, commit) or None (the trainer's
                        `GeometrySink`): when armed, the BACKWARD of this call applies the static tail of the training
                        iteration inside its projection-backward kernel (`vcr_rasterize_backward_tail`), calls `commit()`,
-                       sets `.done` and returns no gradient for means3D / means2D / opacities / scales / rotations / normals."""
-    __slots__ = ("sh_grad", "colour_stream", "colour_hook", "colour_sh_update", "sort_stream", "quad_lists", "tail")
+                       sets `.done` and returns no gradient for means3D / means2D / opacities / scales / rotations / normals.
+      world_normals    an object whose `.saved[3]` / `.saved[4]` are the camera rotation [3,3] and the aux bytes of this
+                       render's fused activation (the trainer's `GeometrySink`): the backward then returns dL/dnormals as the
+                       gradient w.r.t. the WORLD-space axis column (`VcrBackwardIO.normals_Rw2c`) -- the form the ranks of a
+                       data-parallel step can sum before the one-kernel tail."""
+    __slots__ = ("sh_grad", "colour_stream", "colour_hook", "colour_sh_update", "sort_stream", "quad_lists", "tail", "world_normals")
 
     def __init__(self, sh_grad="full", colour_stream=None, colour_hook=None, colour_sh_update=None, sort_stream=None,
-                 quad_lists=False, tail=None):
+                 quad_lists=False, tail=None, world_normals=None):
         if sh_grad not in ("full", "rgb"):
             raise ValueError("sh_grad must be 'full' or 'rgb'")
         self.sh_grad, self.colour_stream, self.colour_hook = sh_grad, colour_stream, colour_hook
         self.colour_sh_update, self.sort_stream, self.quad_lists = colour_sh_update, sort_stream, bool(quad_lists)
         self.tail = tail
+        self.world_normals = world_normals
 
 
 DEFAULT_OPTIONS = RasterOptions()
@@ -210,9 +215,6 @@ class _RasterizeGaussians(torch.autograd.Function):
         out = torch.empty((C if fc == 0 else 3, H, W), dtype=torch.float32, device=dev) if fc not in (3, 4) else None
         radii = torch.empty(N, dtype=torch.int32, device=dev)      # fully written by the preprocess kernel
         count = torch.zeros(N, dtype=torch.int32, device=dev) if fc != 0 else None
-        if fc == 0 and _os.environ.get("VCR_TIMING"):       # experiment builds only (-DVCR_TIMING)
-            count = torch.zeros(((H + 15) // 16) * ((W + 15) // 16) * 32, dtype=torch.int32, device=dev)
-            rec.timing = count
         score = torch.zeros(N, dtype=torch.float32, device=dev) if fc in (1, 2) else None
         fo = _lib.VcrForwardOut(out=_ptr(out), radii=_ptr(radii), count=_ptr(count), score=_ptr(score))
         al = _Allocator(dev)
@@ -227,11 +229,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         if fc == 0:
             ctx.rs, ctx.args_t, ctx.state, ctx.rec = rs, t, al.bufs, rec
             ctx.num_rendered = int(fo.num_rendered)
+            ctx.num_emitted = int(fo.num_emitted)
             ctx.has = (means2D_densify is not None)
             ctx.num_dist = int(num_dist)
             ctx.quad_lists = int(a.quad_lists)
             ctx.rgb_mode = opts.sh_grad == "rgb" and t["shs"] is not None
             ctx.tail = opts.tail
+            ctx.world_normals = opts.world_normals
             ctx.save_for_backward(radii)
             ctx.mark_non_differentiable(radii)
             return out, radii
@@ -289,18 +293,24 @@ class _RasterizeGaussians(torch.autograd.Function):
         d_cov = new(N, 6) if t["cov"] is not None else None
         io = _lib.VcrBackwardIO(dL_dout=_ptr(g), geom=_ptr(ctx.state[_lib.BUF_GEOM]),
                                 binning=_ptr(ctx.state[_lib.BUF_BINNING]), image=_ptr(ctx.state[_lib.BUF_IMAGE]),
-                                radii=_ptr(radii), num_rendered=ctx.num_rendered, dL_dmeans3D=_ptr(d_means3D),
+                                radii=_ptr(radii), num_rendered=ctx.num_rendered, num_emitted=ctx.num_emitted, dL_dmeans3D=_ptr(d_means3D),
                                 dL_dmeans2D=_ptr(d_means2D),
                                 dL_dmeans2D_densify=_ptr(d_dens) if tail is None else (_ptr(radii) if ctx.has else None),   # (tail: a flag)
                                 dL_dshs=_ptr(d_shs),
                                 dL_dshs_rest=_ptr(d_shr), dL_drgb=_ptr(d_rgb), view_dirs=_ptr(v_dirs), dL_dcolors=_ptr(d_col), dL_dnormals=_ptr(d_nrm), dL_dsemantics=_ptr(d_sem),
                                 dL_dopacities=_ptr(d_opac), dL_dscales=_ptr(d_sc), dL_drotations=_ptr(d_rot),
                                 dL_dcov3D=_ptr(d_cov))
+        wn = ctx.world_normals
+        if wn is not None and tail is None and d_nrm is not None:
+            if wn.saved is None:
+                raise RuntimeError("vcr_raster: world_normals was requested but the fused activation left nothing in the sink")
+            io.normals_Rw2c, io.normals_aux = _ptr(wn.saved[3]), _ptr(wn.saved[4])
         al = _Allocator(dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         try:
             with torch.cuda.device(dev):
                 if tail is not None:
+                    sink.started = True             # (from here on the geometry groups may have been stepped: GeometrySink)
                     _check(lib.vcr_rasterize_backward_tail(a, io, tail[0], al.cb, None, stream))
                     tail[1]()
                     sink.done = True

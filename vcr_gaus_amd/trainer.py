@@ -12,7 +12,6 @@ gradients are summed across ranks and scaled by 1/world inside the fused Adam ke
 statistics accumulate per rank and are reduced where they are read (`sync_densify_stats`).  All schedule
 decisions depend only on reduced quantities, so replicas stay in lock-step without broadcasts.
 """
-import os
 import random
 
 import torch
@@ -30,7 +29,13 @@ def load_capture(path):
     reconstructor and dtype classes are allow-listed -- data only, no code."""
     import numpy as np
     from torch.serialization import safe_globals
-    allow = [np._core.multiarray.scalar, np.dtype] + [type(np.dtype(t)) for t in (np.float64, np.float32, np.int64, np.int32)]
+    # torch's weights-only unpickler matches a global by the "module.name" STRING in the file.  numpy >= 2 pickles its scalar
+    # reconstructor as `numpy._core.multiarray.scalar`, numpy 1.x (what the reference's pytorch-2.0.1 environment has) as
+    # `numpy.core.multiarray.scalar`: both spellings are allow-listed for the one function this numpy provides.
+    core = getattr(np, "_core", None) or np.core
+    scalar = core.multiarray.scalar
+    allow = [(scalar, "numpy.core.multiarray.scalar"), (scalar, "numpy._core.multiarray.scalar"), np.dtype]
+    allow += [type(np.dtype(t)) for t in (np.float64, np.float32, np.int64, np.int32)]
     with safe_globals(allow):
         return torch.load(path, map_location="cpu", weights_only=True)
 
@@ -76,7 +81,7 @@ class Trainer:
         # larger of the two: 12 B/Gaussian/view) and the SH update run beside the next iteration's geometry all-reduce
         # wait, geometry Adam, projection and sort chain instead of in front of them.
         if overlap_sh is None:
-            overlap_sh = not force_factorised and str(device).startswith("cuda") and not os.environ.get("VCR_NO_OVERLAP")
+            overlap_sh = not force_factorised and str(device).startswith("cuda")
         self.overlap_sh = bool(overlap_sh)
         # below ~400 k Gaussians the step is launch-bound and the second stream's events / extra launches cost more than
         # the overlap returns (100 k Gaussians at 400x300: 580 vs 810 it/s): the two-stream form is used per step, by size
@@ -87,11 +92,13 @@ class Trainer:
         self._zero_campos = None
         # Fused static tail (round 3): on iterations without densify / prune / reset surgery a single process runs the adjoint
         # of the fused activation, the l1_scale gradient, the densification statistics and Adam on xyz / scaling / rotation /
-        # opacity as ONE kernel (`FusedAdam.geometry_step`) instead of five.  VCR_NO_FUSED_GEOMETRY=1 keeps the modular form.
-        self.fuse_geometry = not os.environ.get("VCR_NO_FUSED_GEOMETRY")
-        self.fuse_raster_tail = not os.environ.get("VCR_NO_RASTER_TAIL")       # (the tail inside the rasterizer's backward)
+        # opacity as ONE kernel (`FusedAdam.geometry_step`) instead of five.  `fuse_geometry = False` keeps the modular form (for
+        # losses built on the plain getters); the three attributes are settings of the object, not of the environment -- each
+        # combination the tests switch to is checked against the oracle as a whole step (tests/test_train_step_gpu.py).
+        self.fuse_geometry = True
+        self.fuse_raster_tail = True       # (the tail inside the rasterizer's backward)
         # ... which also evaluates the activations for the NEXT iteration's camera while the updated parameters are in registers
-        self.prefetch_activation = not os.environ.get("VCR_NO_ACT_PREFETCH")
+        self.prefetch_activation = True
         self._prefetched = None          # cameras of the next iteration, drawn ahead by `_peek_next_camera`
         # third stream: depth keys + depth sort beside the projection (two-stream form only).  Measured: neutral at 1-2 M
         # Gaussians (1.61 vs 1.61, 2.50-2.58 vs 2.49-2.58 ms/step), -4 % at 5 M (4.53 vs 4.74), where the 8 sort launches
@@ -115,8 +122,7 @@ class Trainer:
                 self.side = _lib.cu_masked_stream(int(side_cus), device)
             else:
                 self.side = torch.cuda.Stream(device=device)
-            if not os.environ.get("VCR_NO_SORT_STREAM"):
-                self.sort_stream = torch.cuda.Stream(device=device)
+            self.sort_stream = torch.cuda.Stream(device=device)
 
     def reserve_arena(self, factor=8.0, min_gb=4.0, max_fraction=0.25):
         """Take ONE large block from the device through torch's caching allocator and hand it straight back to the cache:
@@ -143,9 +149,8 @@ class Trainer:
         return want
 
     def _launch_pending_sh(self):
-        """Enqueue the deferred SH Adam update on the side stream.  Called from the rasterizer's colour-stream hook, i.e.
-        after the side stream was made to wait for this iteration's projection (hence for the backward that produced
-        the gradients) and before the SH -> RGB evaluation: the update runs beside the latency-bound sort chain."""
+        """Enqueue the deferred SH Adam update on the side stream as its own kernel (`join_side`: a pending update that no
+        forward is going to consume -- before evaluation renders, checkpoints, row surgery)."""
         if self._pending_sh is None:
             return
         pend, self._pending_sh = self._pending_sh, None
@@ -307,12 +312,16 @@ class Trainer:
         return self._wvec
 
     # ---- gradient exchange ------------------------------------------------------------------------------------
-    def _allreduce_grads(self, early_feature_step=False, defer_sh=False, rec=None):
+    def _allreduce_grads(self, early_feature_step=False, defer_sh=False, rec=None, sink=None):
         """Sum the per-Gaussian gradients of all ranks (RCCL over xGMI).  One collective per parameter
         tensor, all in flight together; the 1/world scale is folded into the Adam kernel.  With the factorised SH
         exchange the all-gather of dL/drgb is awaited first, the SH gradients are rebuilt and (on iterations without
         densify / prune / opacity-reset surgery) their Adam update runs while the all-reduce of the remaining
-        44 B/Gaussian is still in flight.  `rec`: the `RasterRecord` of THIS step's render (its backward left dL/drgb there)."""
+        44 B/Gaussian is still in flight.  `rec`: the `RasterRecord` of THIS step's render (its backward left dL/drgb there).
+        `sink` (round 5, the one-kernel tail under data parallelism): the bucket then carries the gradients of the four geometry
+        groups in ACTIVATED space -- dL/d(mean, activated scales, unit quaternion, opacity, world-space axis column), 56 B per
+        Gaussian, what the rasterizer's backward returned -- instead of the 44 B of raw-parameter gradients: the activation
+        adjoint is linear in them and the parameters are replicated, so the tail can run ONCE on the sum."""
         if self.world == 1 and not self.factorised_sh:
             self.model.optimizer.grad_scale = 1.0
             return
@@ -338,18 +347,28 @@ class Trainer:
             drgb_all = flat.view(self.world, drgb.shape[0], 3)
         # ONE bucket for the remaining gradients (xyz, opacity, scaling, rotation, ...): a ring all-reduce pays 2(n-1) link
         # latencies per call, so four small collectives cost four times the latency of one (xGMI is point-to-point)
+        geo = ("xyz", "scaling", "rotation", "opacity")
         params = [g["params"][0] for g in self.model.optimizer.param_groups
-                  if not (self.factorised_sh and g["name"] in ("f_dc", "f_rest"))]
-        sizes = [(p.numel() + 3) // 4 * 4 for p in params]                    # 16-byte aligned segments for the Adam kernel
-        ref = params[0]
-        if all(p.grad is not None and n == p.numel() for p, n in zip(params, sizes)):
-            flat = torch.cat([p.grad.reshape(-1) for p in params])            # one kernel
+                  if not (self.factorised_sh and g["name"] in ("f_dc", "f_rest")) and not (sink is not None and g["name"] in geo)]
+        grads = [p.grad for p in params]
+        if sink is not None:          # activated-space gradients first: [d mean | d scales | d quaternion | d opacity | d axis column]
+            act = [self.model._xyz.grad] + list(sink.grads)
+            keep = [k for k, t in enumerate(act) if t is not None]
+            grads = [act[k] for k in keep] + grads
+        else:
+            act = keep = None
+        shapes = [None if t is None else t.shape for t in grads]
+        numels = [p.numel() for p in params] if sink is None else [act[k].numel() for k in keep] + [p.numel() for p in params]
+        sizes = [(n + 3) // 4 * 4 for n in numels]                            # 16-byte aligned segments for the Adam kernel
+        ref = params[0] if params else self.model._xyz
+        if all(t is not None and n == t.numel() for t, n in zip(grads, sizes)):
+            flat = torch.cat([t.reshape(-1) for t in grads])                  # one kernel
         else:
             flat = torch.zeros(sum(sizes), dtype=ref.dtype, device=ref.device)
             off = 0
-            for p, n in zip(params, sizes):
-                if p.grad is not None:
-                    flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            for t, n in zip(grads, sizes):
+                if t is not None:
+                    flat[off:off + t.numel()].copy_(t.reshape(-1))
                 off += n
         if self.exchange_algo == "rs_ag" and self.world > 1:
             # reduce-scatter + all-gather on the bucket padded to a multiple of the ranks: rank r sums slice r of every
@@ -365,9 +384,14 @@ class Trainer:
             self._rs_ag_keep = shard                                          # (alive until the waits below)
         else:
             works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-        off = 0
-        for p, n in zip(params, sizes):
-            p.grad = flat[off:off + p.numel()].view_as(p)                       # views of the bucket: no copy back
+        off = 0                                                                 # views of the bucket: no copy back
+        if sink is not None:
+            for j, k in enumerate(keep):
+                act[k] = flat[off:off + numels[j]].view(shapes[j])
+                off += sizes[j]
+            self.model._xyz.grad, sink.grads = act[0], act[1:]
+        for p, n in zip(params, sizes[(len(keep) if sink is not None else 0):]):
+            p.grad = flat[off:off + p.numel()].view_as(p)
             off += n
         if gather is not None:
             campos_all = torch.stack([self.cameras[i].camera_center for i in self._picked]).float().contiguous()
@@ -385,7 +409,7 @@ class Trainer:
         for w in works:
             w.wait()
 
-    def _exchange_grads(self, overlap, surgery, rec=None):
+    def _exchange_grads(self, overlap, surgery, rec=None, sink=None):
         """What happens between backward and the optimizer step.  Two-stream form (`overlap`, no surgery this iteration):
         single GPU -> the SH update is only stashed (applied from the next forward's colour stream); data parallel -> the
         geometry bucket is all-reduced now, dL/drgb is all-gathered asynchronously and the SH update of ALL views is left
@@ -396,7 +420,7 @@ class Trainer:
                 if g["name"] in ("f_dc", "f_rest"):    # the projection the side stream will wait for
                     m.optimizer._state(g)
             if self.world > 1 or getattr(self, "force_collectives", False):
-                self._allreduce_grads(defer_sh=True, rec=rec)
+                self._allreduce_grads(defer_sh=True, rec=rec, sink=sink)
                 self.last_exchange = "factorised-deferred"      # bucket all-reduce now, all-view SH update on the side stream
                 if self.exchange_algo == "rs_ag" and self.world > 1:
                     self.last_exchange += "+rs_ag"
@@ -406,7 +430,7 @@ class Trainer:
                 self._pending_sh = rec.take_sh_factors() + (int(m.active_sh_degree),)
         else:
             self.join_side()
-            self._allreduce_grads(early_feature_step=not surgery, rec=rec)
+            self._allreduce_grads(early_feature_step=not surgery, rec=rec, sink=sink)
             collectives = self.world > 1 or getattr(self, "force_collectives", False)
             self.last_exchange = ("factorised" if self.factorised_sh else "dense") if collectives else "none"
             if collectives and self.exchange_algo == "rs_ag" and self.world > 1:
@@ -450,6 +474,28 @@ class Trainer:
             cl = data["countlist"]
             self._visi_delta = cl.clone() if self._visi_delta is None else self._visi_delta + cl
         self._stats_dirty = True
+
+    def _stats_target(self, deltas):
+        """Context: with `deltas`, the model's statistic accumulators are swapped for this rank's deltas (see `_densify_stats`)
+        while a kernel that writes them runs -- the one-kernel tail under data parallelism."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def swap():
+            m = self.model
+            N = m._xyz.shape[0]
+            if self._stats_delta is None or self._stats_delta[0].shape[0] != N:
+                assert self._stats_delta is None or not self._stats_dirty, "densification statistics not synchronised before row surgery"
+                self._stats_delta = (torch.zeros(N, 1, device=self.device), torch.zeros(N, 1, device=self.device))
+            keep = (m.xyz_gradient_accum, m.denom)
+            m.xyz_gradient_accum, m.denom = self._stats_delta
+            try:
+                yield
+            finally:
+                m.xyz_gradient_accum, m.denom = keep
+            self._stats_dirty = True
+
+        return swap() if deltas else contextlib.nullcontext()
 
     def sync_densify_stats(self):
         """Data parallel: sum the rank-local statistic deltas (and maximise `max_radii2D`) over the ranks.  `train_step`
@@ -502,6 +548,8 @@ class Trainer:
         self.current_iteration = int(first_iter)
         self._stats_delta, self._visi_delta, self._stats_dirty = None, None, False
         self._pending_sh, self.visi_list = None, None
+        # the camera drawn ahead for the activation prefetch belongs to the run that was interrupted by this load
+        self._prefetched = None
         self.model._act_cache = None
 
     # ---- visibility / importance passes (`tools/prune.py:6-69`, `trainer.py:688-702`), camera-sharded ------------
@@ -568,7 +616,6 @@ class Trainer:
         self.factorised_sh = self._factorised_base or overlap
         if not overlap and self._pending_sh is not None:
             self.join_side()
-        fuse = overlap and not os.environ.get("VCR_NO_FUSED_SH_COLOUR")
         surgery = (it < cfg.optim.densify_until_iter and it > cfg.optim.densify_from_iter
                    and it % cfg.optim.densification_interval == 0) \
             or it % cfg.optim.opacity_reset_interval == 0 or it in cfg.optim.prune.iterations \
@@ -576,15 +623,19 @@ class Trainer:
         from . import fused_losses, gaussian_model
         # the fused static tail needs every gradient path into scaling / rotation / opacity to pass through the fused
         # activation node (the fused loss node guarantees that), un-reduced gradients (one process) and unchanged rows
-        armed = bool(self.fuse_geometry and fused and not surgery and self.world == 1
-                     and not getattr(self, "force_collectives", False) and m._xyz.is_cuda and m._xyz.shape[0] > 0
+        dp = self.world > 1 or getattr(self, "force_collectives", False)
+        armed = bool(self.fuse_geometry and fused and not surgery and m._xyz.is_cuda and m._xyz.shape[0] > 0
                      and not cfg.pipline.compute_cov3D_python)
         # the iteration's side channel (see GeometrySink): armed = the one-kernel static tail; the l1_scale gradient joins the
         # activation backward's kernel; the loss node's reduction buffer is this trainer's
         sink = gaussian_model.GeometrySink(armed=armed, defer_scale_grad=True, sums=self._loss_sums)
-        # ... and, with the factorised SH gradient, the tail runs INSIDE the rasterizer's backward (projection backward +
-        # activation adjoint + statistics + Adam in one kernel): the geometry gradients never reach memory
-        raster_tail = armed and self.fuse_raster_tail and self.factorised_sh
+        # Data parallel (round 5): the same one-kernel tail, on the SUM over the ranks -- the rasterizer's backward returns the
+        # activated-space gradients (the normal's in the world-space form, `RasterOptions.world_normals`), the exchange sums
+        # those 56 B per Gaussian, and `geometry_step` applies adjoint + l1_scale (once) + Adam with grad_scale = 1 / world.
+        sink.exchange = armed and dp
+        # ... and, on ONE process with the factorised SH gradient, the tail runs INSIDE the rasterizer's backward (projection
+        # backward + activation adjoint + statistics + Adam in one kernel): the geometry gradients never reach memory
+        raster_tail = armed and not dp and self.fuse_raster_tail and self.factorised_sh
         def next_cam():            # (evaluated when the tail is prepared: the sink then knows this render's `want_normal`)
             nc = self._peek_next_camera() if sink.want_normal is not None else None
             return None if nc is None else nc + (sink.want_normal,)
@@ -592,11 +643,12 @@ class Trainer:
         if raster_tail:
             stats_on = it < cfg.optim.densify_until_iter
             sink.tail = lambda: m.optimizer.prepare_geometry_step(m, sink, in_registers=True, stats=stats_on, next_cam=next_cam())
-        opts = RasterOptions("rgb" if self.factorised_sh else "full", self.side if overlap else None,
-                             self._launch_pending_sh if (overlap and not fuse) else None,
-                             self._pending_sh_update if fuse else None,
+        # two-stream form: the deferred SH update is applied on the second stream in ONE pass with the SH -> RGB evaluation
+        opts = RasterOptions("rgb" if self.factorised_sh else "full", self.side if overlap else None, None,
+                             self._pending_sh_update if overlap else None,
                              self.sort_stream if (overlap and m._xyz.shape[0] >= self.sort_stream_min_gaussians) else None,
-                             quad_lists=self._quad_on, tail=sink if raster_tail else None)
+                             quad_lists=self._quad_on, tail=sink if raster_tail else None,
+                             world_normals=sink if sink.exchange else None)
         m._geom_sink = sink
         ok, left = False, None
         try:
@@ -616,6 +668,8 @@ class Trainer:
             loss.backward(fused_losses.unit_seed(loss.device))
             ok = True
         finally:
+            if not ok and sink.started:
+                self.last_tail = "raster-partial"               # geometry stepped inside the failed backward, SH not: do not retry
             m._geom_sink = None
             sink.armed = False
             sink.tail = None                                     # (its closure refers to the sink: no cycle left behind)
@@ -627,14 +681,16 @@ class Trainer:
         geom = armed and (sink.done or sink.grads is not None)
         self.last_tail = "raster" if sink.done else ("kernel" if geom else "modular")     # (which form of the tail ran)
         with torch.no_grad():
-            self._exchange_grads(overlap, surgery, data["raster"])
+            self._exchange_grads(overlap, surgery, data["raster"], sink=sink if (geom and sink.exchange) else None)
             if geom:
                 # activation adjoint + l1_scale gradient + densification statistics + Adam on the four geometry groups
                 stats = it < cfg.optim.densify_until_iter
                 if not sink.done:                  # (done: the rasterizer's backward has applied the tail itself)
                     vp = data["viewspace_points_densify"]
-                    m.optimizer.geometry_step(m, sink, grad2d=vp.grad.contiguous() if (stats and vp.grad is not None) else None,
-                                              radii=data["radii"] if stats else None, next_cam=next_cam())
+                    with self._stats_target(dp and stats):           # (data parallel: statistics into the rank-local deltas)
+                        m.optimizer.geometry_step(m, sink, grad2d=vp.grad.contiguous() if (stats and vp.grad is not None) else None,
+                                                  radii=data["radii"] if stats else None, next_cam=next_cam(),
+                                                  normals_world=sink.exchange)
                 # the one-kernel tail has applied Adam to these groups; a gradient that reached them by another path (a loss
                 # built on the plain getters) would be applied a SECOND time by optimizer.step() below
                 stray = [k for k in ("_scaling", "_rotation", "_opacity") if getattr(m, k).grad is not None]
@@ -643,7 +699,10 @@ class Trainer:
                                        "set Trainer.fuse_geometry = False for losses on the plain getters")
                 if stats and it > cfg.optim.densify_from_iter and "countlist" in data:                  # `trainer.py:350-356`
                     cl = data["countlist"]
-                    self.visi_list = cl if self.visi_list is None else self.visi_list + cl
+                    if dp:
+                        self._visi_delta = cl.clone() if self._visi_delta is None else self._visi_delta + cl
+                    else:
+                        self.visi_list = cl if self.visi_list is None else self.visi_list + cl
             if it < cfg.optim.densify_until_iter and not geom:
                 self._densify_stats(data)
                 if it > cfg.optim.densify_from_iter and "countlist" in data and not self._stats_dirty:        # `trainer.py:350-356`
