@@ -413,7 +413,7 @@ int  vcr_profile_read(float* ms, int32_t* launches, int n);
  * surviving (quad, Gaussian) pair really hits.  out[0..64]: forward, out[65..129]: backward; accumulated over all launches
  * since the last reset.  Returns 1 in ordinary builds. */
 int  vcr_debug_hit_histogram(uint32_t out[130], int reset);
-/* Diagnostics: with `on`, every vcr_rasterize_backward of this host thread keeps a copy of its screen-space accumulators
+/* Diagnostics (not thread-safe): with `on`, every vcr_rasterize_backward of the process keeps a copy of its screen-space accumulators
  * (GradRec [N] = 16 floats per Gaussian, raw sums as the compositing backward left them, see csrc/vcr_common.h) before the
  * projection backward consumes them; vcr_debug_read_sgrad copies the last one to HOST memory (synchronises the device).
  * Used by profiles/grad_stage_errors.py to tell the error of the compositing backward from that of the projection backward. */

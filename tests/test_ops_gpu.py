@@ -325,7 +325,7 @@ def test_two_stream_sh_path_trains_like_the_serial_loop(device):
         tr.model.active_sh_degree = 2
         real_exchange = tr._exchange_grads
 
-        def exchange_after_an_eval_render(ov, surgery, rec, tr=tr, cams=cams):
+        def exchange_after_an_eval_render(ov, surgery, rec, tr=tr, cams=cams, **kw):
             # an evaluation render (with its own backward, in "rgb" mode) between this step's backward and its gradient
             # exchange: dL/drgb travels on the record of the render that produced it, so the step is unaffected
             from vcr_gaus_amd.rasterizer import RasterOptions
@@ -340,7 +340,7 @@ def test_two_stream_sh_path_trains_like_the_serial_loop(device):
                 assert pkg["raster"].drgb is not None and pkg["raster"] is not rec
                 for g in tr.model.optimizer.param_groups:
                     g["params"][0].grad = keep[g["name"]]
-            return real_exchange(ov, surgery, rec)
+            return real_exchange(ov, surgery, rec, **kw)
 
         tr._exchange_grads = exchange_after_an_eval_render
         for it in range(14):

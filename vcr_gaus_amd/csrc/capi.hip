@@ -59,7 +59,8 @@ Published* pinned_published() {
 
 // ---- library-owned device scratch (round 5) ------------------------------------------------------------------------------
 // Small state that used to be carved out of the caller's per-call scratch and cleared by a memset launch in front of every call:
-//   * `ctr`: the projection's counter block (vcr_common.h) -- zero between calls, the kernels clean up after themselves;
+//   * `ctr`: ticket / flag words (vcr_common.h) -- zero between calls, the kernels clean up after themselves; `blk`: the
+//     per-workgroup count rows of the projection (every row of a launch is written before it is read);
 //   * `status`: look-back words of the emission kernel, tagged with `seq` instead of being cleared;
 //   * `grad`: the backward's per-Gaussian accumulators (GradRec [N] + semantic gradients) -- zero between calls, the projection
 //     backward clears every record behind its own read (was a 64 B x N memset per backward).
@@ -68,6 +69,7 @@ Published* pinned_published() {
 // flags make the next call clear a block that a failed call may have left half-used.
 struct StreamScratch {
     uint32_t* ctr = nullptr; bool ctr_dirty = true;
+    uint32_t* blk = nullptr; size_t blk_rows = 0;        // three count words per workgroup of the projection (never cleared)
     unsigned long long* status = nullptr; size_t status_words = 0;
     uint32_t seq = 0;
     char* grad = nullptr; size_t grad_bytes = 0; bool grad_dirty = true;
@@ -83,7 +85,7 @@ StreamScratch* stream_scratch(hipStream_t st) {
     static thread_local ScratchMap m;
     for (auto& kv : m.sets) if (kv.first == st) return kv.second;
     if (m.sets.size() >= 64) {       // a caller cycling through streams: start over (hipFree synchronises the device)
-        for (auto& kv : m.sets) { (void)hipFree(kv.second->ctr); (void)hipFree(kv.second->status); (void)hipFree(kv.second->grad); delete kv.second; }
+        for (auto& kv : m.sets) { (void)hipFree(kv.second->ctr); (void)hipFree(kv.second->blk); (void)hipFree(kv.second->status); (void)hipFree(kv.second->grad); delete kv.second; }
         m.sets.clear();
     }
     StreamScratch* sc = new StreamScratch();
@@ -93,9 +95,17 @@ StreamScratch* stream_scratch(hipStream_t st) {
 }
 
 // counter block ready (zero) + status words for `words` look-back entries; advances the call number.  Stream-ordered.
-int scratch_begin_forward(StreamScratch* sc, size_t words, hipStream_t st) {
+int scratch_begin_forward(StreamScratch* sc, size_t words, int N, hipStream_t st) {
     if (sc->ctr_dirty) { VCR_HIP_CHECK(hipMemsetAsync(sc->ctr, 0, sizeof(uint32_t) * VCR_CTR_WORDS, st)); }
     sc->ctr_dirty = true;            // until this call's projection has published (it then left the block zero)
+    const size_t rows = (size_t)(N + 255) / 256 + 1;
+    if (rows > sc->blk_rows) {
+        if (sc->blk) VCR_HIP_CHECK(hipFree(sc->blk));
+        sc->blk = nullptr; sc->blk_rows = 0;
+        const size_t cap = rows + rows / 4 + 64;
+        VCR_HIP_CHECK(hipMalloc((void**)&sc->blk, sizeof(uint32_t) * 3 * cap));
+        sc->blk_rows = cap;
+    }
     if (words > sc->status_words) {
         if (sc->status) VCR_HIP_CHECK(hipFree(sc->status));
         sc->status = nullptr; sc->status_words = 0;
@@ -256,7 +266,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         if (!s1) { vcr_set_error("allocator returned NULL"); return 1; }
         StreamScratch* sc = stream_scratch(st);          // counters + look-back words: library-owned, no memset launch (round 5)
         if (!sc) { vcr_set_error("hipMalloc for the counter block failed"); return 1; }
-        if (scratch_begin_forward(sc, vcr_duplicate_status_words(N), st)) return 1;
+        if (scratch_begin_forward(sc, vcr_duplicate_status_words(N), N, st)) return 1;
         uint32_t* depth_key = (uint32_t*)s1;
         uint32_t* ids_sorted = (uint32_t*)(s1 + nb);
         uint2* pair_a = (uint2*)(s1 + 2 * nb);
@@ -321,7 +331,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
             StageTimer tm(ST_PREPROCESS, st);
             // (count-only modes 3 / 4 never read a colour: geometry-only projection, 36 against 105 us at 1 M Gaussians)
             const bool colour_here = !split_colour && a.f_count != 3 && a.f_count != 4;
-            if (vcr_launch_preprocess(a, g, out->radii, split_sort ? nullptr : depth_key, ids, vis_counter, colour_here, st, pub, seq))
+            if (vcr_launch_preprocess(a, g, out->radii, split_sort ? nullptr : depth_key, ids, vis_counter, colour_here, st, sc->blk, pub, seq))
                 return join_streams();
         }
         if (split_colour) {
@@ -404,10 +414,10 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         }
         out->num_rendered = R;
         if (a.debug) {                       // diagnostics only: longest per-tile list (one extra sync)
-            VCR_HIP_CHECK_JOIN(hipMemsetAsync(vis_counter, 0, sizeof(uint32_t), st));
-            hipLaunchKernelGGL(max_tile_len_kernel, dim3(32), dim3(256), 0, st, a.quad_lists ? 4 * T : T, b.ranges, vis_counter);
-            VCR_HIP_CHECK_JOIN(hipMemcpyAsync(&rb->R[0], vis_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            VCR_HIP_CHECK_JOIN(hipMemsetAsync(vis_counter, 0, sizeof(uint32_t), st));          // (the block stays zero between calls)
+            uint32_t* mx = sc->blk;                  // (the projection has published: its count rows are free)
+            VCR_HIP_CHECK_JOIN(hipMemsetAsync(mx, 0, sizeof(uint32_t), st));
+            hipLaunchKernelGGL(max_tile_len_kernel, dim3(32), dim3(256), 0, st, a.quad_lists ? 4 * T : T, b.ranges, mx);
+            VCR_HIP_CHECK_JOIN(hipMemcpyAsync(&rb->R[0], mx, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             VCR_HIP_CHECK_JOIN(hipStreamSynchronize(st));
             out->max_tile_len = (int32_t)rb->R[0];
         }
@@ -565,10 +575,10 @@ extern "C" int vcr_visibility_batch(const VcrVisibilityBatch* vb, vcr_alloc_fn a
             StreamScratch& sc = pool->sc[c - c0];
             uint32_t* totals_depth = (uint32_t*)(v.s1 + 7 * nb);
             void* temp1 = v.s1 + 7 * nb + tot_bytes;
-            if (scratch_begin_forward(&sc, vcr_duplicate_status_words(N), cs)) { rc = 1; break; }
+            if (scratch_begin_forward(&sc, vcr_duplicate_status_words(N), N, cs)) { rc = 1; break; }
             v.dseq = sc.seq;
             v.seq = ++seq_counter ? seq_counter : ++seq_counter;
-            if (vcr_launch_preprocess(a, g, v.radii, depth_key, nullptr, sc.ctr, false, cs, pool->pub + (c - c0), v.seq)) { rc = 1; break; }
+            if (vcr_launch_preprocess(a, g, v.radii, depth_key, nullptr, sc.ctr, false, cs, sc.blk, pool->pub + (c - c0), v.seq)) { rc = 1; break; }
             if (vcr_depth_sort(N, depth_key, (uint2*)(v.s1 + 2 * nb), (uint2*)(v.s1 + 4 * nb), ids_sorted, totals_depth, temp1, cs)) { rc = 1; break; }
         }
         // back half: the host sizes the instance buffers of camera c while the later cameras' front halves run
@@ -624,9 +634,10 @@ int vcr_dbg_acc64_begin(int N, hipStream_t st);
 int vcr_dbg_acc64_end(int N, GradRec* sgrad, hipStream_t st);
 #endif
 namespace {
-thread_local bool g_keep_sgrad = false;
-thread_local float* g_sgrad_copy = nullptr;
-thread_local int g_sgrad_copy_n = 0;
+// (process-wide, not per thread: autograd runs the backward on its own host thread)
+bool g_keep_sgrad = false;
+float* g_sgrad_copy = nullptr;
+int g_sgrad_copy_n = 0;
 // vcr_rasterize_backward (tail == nullptr) and vcr_rasterize_backward_tail
 int backward_impl(const VcrRasterArgs* args, VcrBackwardIO* io, const VcrGeometryStep* tail, vcr_alloc_fn alloc, void* user,
                   void* stream) {

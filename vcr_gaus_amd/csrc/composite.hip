@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
     while (pos < range.y) {
         uint32_t nnid; float4 nq0, nq1, nq2 = zero4, nq3 = zero4, nqs = zero4; bool nnvalid;
         const uint32_t npos = pos + 64;
-        if (FC == 0 && pos != range.x && pm.inside) ck[(size_t)((pos - range.x) >> 6) * VCR_CKPT_STRIDE] = T;
+        if (VCR_T_ANCHOR && FC == 0 && pos != range.x && pm.inside) ck[(size_t)((pos - range.x) >> 6) * VCR_CKPT_STRIDE] = T;
         VCR_GATHER_FWD(nid, nq0, nq1, nq2, nq3);                     // records of the next chunk
         if (!SEM_IN_REC) VCR_GATHER_SEM(nid, nqs);
         VCR_LOAD_ID(npos + 64 + lane, range.y, nnid, nnvalid);       // ids of the chunk after that
@@ -656,7 +656,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_RO
         VCR_GATHER_REC(nid, nq0, nq1, nq2, nq3);
         VCR_GATHER_SEM(nid, nqs);
         VCR_LOAD_ID(chunk > 1 ? range.x + (uint32_t)(chunk - 2) * 64u + lane : lim, lim, nnid, nnvalid);
-        const float ckT = (chunk > 0 && pm.inside) ? ck[(size_t)chunk * VCR_CKPT_STRIDE] : 1.f;      // (see the v2 kernel)
+        const float ckT = (VCR_T_ANCHOR && chunk > 0 && pm.inside) ? ck[(size_t)chunk * VCR_CKPT_STRIDE] : 1.f;      // (see the v2 kernel)
         // cull against the live box of each 4x4 sub-block; one survivor mask per row
         const unsigned long long live = __builtin_amdgcn_ballot_w64(lastc > (uint32_t)chunk * 64u);
         unsigned long long mr[4];

@@ -375,16 +375,18 @@ __global__ void __launch_bounds__(256) normal_losses_bwd_kernel(int H, int W, In
 // ---------------- fused L1 + SSIM ------------------------------------------------------------------
 #define SSIM_R 5
 #define SSIM_TX 32
-#define SSIM_TY 16
-#define SSIM_VO (SSIM_TY / 8)                 // output rows per lane in the vertical pass
+// Rows per workgroup (round 5, profiles/r5_ssim_tiles.txt + kernel traces): 32 rows make the halo 1.72x instead of 2.13x on the
+// loads and 1.31x instead of 1.63x on the horizontal pass -- the BACKWARD gains (64 -> 58 us at 1080p), the FORWARD, whose five
+// row-sum planes then take 42 KB of LDS (3 instead of 6 workgroups per CU), loses (64 -> 75 us): 16 rows forward, 32 backward.
+#define SSIM_TY_FWD 16
+#define SSIM_TY_BWD 32
 #define SSIM_HW (SSIM_TX + 2 * SSIM_R)        // 42: tile + halo, x
-#define SSIM_HH (SSIM_TY + 2 * SSIM_R)        // 26: tile + halo, y
 #define SSIM_HS (SSIM_HW + 2)                 // 44: halo row stride
 struct GaussWin { float w[11]; };
 
-// One workgroup = 32x16 output pixels of one channel.  The (32+10)x(16+10) halo of both images is staged in LDS and the 11x11
+// One workgroup = 32 x TY output pixels of one channel.  The (32+10) x (TY+10) halo of both images is staged in LDS and the 11x11
 // window is evaluated separably with REGISTER sliding windows: every lane produces 4 adjacent outputs in the horizontal pass (14
-// loaded values feed 4 x 11 taps) and 2 in the vertical pass, ~3x fewer LDS reads per output pixel than the one-output-per-
+// loaded values feed 4 x 11 taps) and TY / 8 in the vertical pass, ~3x fewer LDS reads per output pixel than the one-output-per-
 // lane form (LDS-bound: 84 us at 1080p).  The five window sums travel in natural pairs -- (a, b), (a^2, b^2) and a b alone --
 // on packed fp32 (v_pk_fma_f32: 3 instructions per tap instead of 5; the kernel is VALU-bound).  Zero padding as
 // F.conv2d(padding=5).
@@ -392,25 +394,27 @@ struct GaussWin { float w[11]; };
 typedef float lf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ lf2 lpk_fma(lf2 a, lf2 b, lf2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+template <int TY>
 __global__ void __launch_bounds__(256) l1_ssim_fwd_kernel(int H, int W, GaussWin gw, const float* __restrict__ img1,
                                                           const float* __restrict__ img2, double* __restrict__ sums,
                                                           float* __restrict__ part) {
-    __shared__ lf2 s_ab[SSIM_HH][SSIM_HS];                 // (a, b)
-    __shared__ lf2 s_hm[SSIM_HH][SSIM_TX + 1];             // row sums of (a, b)
-    __shared__ lf2 s_hq[SSIM_HH][SSIM_TX + 1];             // row sums of (a^2, b^2)
-    __shared__ float s_hx[SSIM_HH][SSIM_TX + 1];           // row sums of a b
-    const int c = blockIdx.z, x0 = blockIdx.x * SSIM_TX, y0 = blockIdx.y * SSIM_TY;
+    constexpr int HH = TY + 2 * SSIM_R, VO = TY / 8;      // halo rows; output rows per lane in the vertical pass
+    __shared__ lf2 s_ab[HH][SSIM_HS];                 // (a, b)
+    __shared__ lf2 s_hm[HH][SSIM_TX + 1];             // row sums of (a, b)
+    __shared__ lf2 s_hq[HH][SSIM_TX + 1];             // row sums of (a^2, b^2)
+    __shared__ float s_hx[HH][SSIM_TX + 1];           // row sums of a b
+    const int c = blockIdx.z, x0 = blockIdx.x * SSIM_TX, y0 = blockIdx.y * TY;
     const size_t P = (size_t)H * W;
     const float* A = img1 + c * P;
     const float* B = img2 + c * P;
-    for (int t = threadIdx.x; t < SSIM_HW * SSIM_HH; t += 256) {
+    for (int t = threadIdx.x; t < SSIM_HW * HH; t += 256) {
         const int ly = t / SSIM_HW, lx = t % SSIM_HW, gx = x0 + lx - SSIM_R, gy = y0 + ly - SSIM_R;
         const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
         s_ab[ly][lx] = in ? lf2{A[(size_t)gy * W + gx], B[(size_t)gy * W + gx]} : lf2{0.f, 0.f};
     }
     __syncthreads();
     // horizontal pass: item = (halo row, group of 4 output columns)
-    for (int it = threadIdx.x; it < SSIM_HH * (SSIM_TX / 4); it += 256) {
+    for (int it = threadIdx.x; it < HH * (SSIM_TX / 4); it += 256) {
         const int ly = it / (SSIM_TX / 4), lx0 = (it % (SSIM_TX / 4)) * 4;
         lf2 m[4], q[4];
         float x[4];
@@ -433,17 +437,17 @@ __global__ void __launch_bounds__(256) l1_ssim_fwd_kernel(int H, int W, GaussWin
         for (int o = 0; o < 4; ++o) { s_hm[ly][lx0 + o] = m[o]; s_hq[ly][lx0 + o] = q[o]; s_hx[ly][lx0 + o] = x[o]; }
     }
     __syncthreads();
-    // vertical pass: lane = (column, group of SSIM_VO output rows)
-    const int lx = threadIdx.x & 31, ly0 = (threadIdx.x >> 5) * SSIM_VO;
-    lf2 rm[SSIM_VO], rq[SSIM_VO];
-    float rx[SSIM_VO];
+    // vertical pass: lane = (column, group of VO output rows)
+    const int lx = threadIdx.x & 31, ly0 = (threadIdx.x >> 5) * VO;
+    lf2 rm[VO], rq[VO];
+    float rx[VO];
     {
-        lf2 cm[10 + SSIM_VO], cq[10 + SSIM_VO];
-        float cx[10 + SSIM_VO];
+        lf2 cm[10 + VO], cq[10 + VO];
+        float cx[10 + VO];
 #pragma unroll
-        for (int k = 0; k < 10 + SSIM_VO; ++k) { cm[k] = s_hm[ly0 + k][lx]; cq[k] = s_hq[ly0 + k][lx]; cx[k] = s_hx[ly0 + k][lx]; }
+        for (int k = 0; k < 10 + VO; ++k) { cm[k] = s_hm[ly0 + k][lx]; cq[k] = s_hq[ly0 + k][lx]; cx[k] = s_hx[ly0 + k][lx]; }
 #pragma unroll
-        for (int o = 0; o < SSIM_VO; ++o) {
+        for (int o = 0; o < VO; ++o) {
             lf2 tm = {0.f, 0.f}, tq = {0.f, 0.f};
             float tx = 0.f;
 #pragma unroll
@@ -457,7 +461,7 @@ __global__ void __launch_bounds__(256) l1_ssim_fwd_kernel(int H, int W, GaussWin
     float l1 = 0.f, sv_sum = 0.f;
     const int gx = x0 + lx;
 #pragma unroll
-    for (int o = 0; o < SSIM_VO; ++o) {
+    for (int o = 0; o < VO; ++o) {
         const int gy = y0 + ly0 + o;
         if (gx < W && gy < H) {
             const float m1 = rm[o].x, m2 = rm[o].y, q11 = rq[o].x, q22 = rq[o].y, q12 = rx[o];
@@ -487,17 +491,19 @@ __global__ void __launch_bounds__(256) l1_ssim_fwd_kernel(int H, int W, GaussWin
 
 // dimg1(p) = gl1 * sign(a-b) + gss * sum_q w(q-p) [ dm1(q) + 2 a(p) dq11(q) + b(p) dq12(q) ]      (same tiling; the three
 // planes as one packed pair + one scalar)
+template <int TY>
 __global__ void __launch_bounds__(256) l1_ssim_bwd_kernel(int H, int W, GaussWin gw, const float* __restrict__ img1,
                                                           const float* __restrict__ img2, const float* __restrict__ part,
                                                           const float* __restrict__ g_l1, const float* __restrict__ g_ssim,
                                                           float wl1, float wss, float* __restrict__ dimg1) {
-    __shared__ lf2 s_p01[SSIM_HH][SSIM_HS];
-    __shared__ float s_p2[SSIM_HH][SSIM_HS];
-    __shared__ lf2 s_h01[SSIM_HH][SSIM_TX + 1];
-    __shared__ float s_h2[SSIM_HH][SSIM_TX + 1];
-    const int c = blockIdx.z, x0 = blockIdx.x * SSIM_TX, y0 = blockIdx.y * SSIM_TY;
+    constexpr int HH = TY + 2 * SSIM_R, VO = TY / 8;      // halo rows; output rows per lane in the vertical pass
+    __shared__ lf2 s_p01[HH][SSIM_HS];
+    __shared__ float s_p2[HH][SSIM_HS];
+    __shared__ lf2 s_h01[HH][SSIM_TX + 1];
+    __shared__ float s_h2[HH][SSIM_TX + 1];
+    const int c = blockIdx.z, x0 = blockIdx.x * SSIM_TX, y0 = blockIdx.y * TY;
     const size_t P = (size_t)H * W;
-    for (int t = threadIdx.x; t < SSIM_HW * SSIM_HH; t += 256) {
+    for (int t = threadIdx.x; t < SSIM_HW * HH; t += 256) {
         const int ly = t / SSIM_HW, lx = t % SSIM_HW, gx = x0 + lx - SSIM_R, gy = y0 + ly - SSIM_R;
         const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
         const size_t o = c * P + (size_t)gy * W + gx;
@@ -505,7 +511,7 @@ __global__ void __launch_bounds__(256) l1_ssim_bwd_kernel(int H, int W, GaussWin
         s_p2[ly][lx] = in ? part[6 * P + o] : 0.f;
     }
     __syncthreads();
-    for (int it = threadIdx.x; it < SSIM_HH * (SSIM_TX / 4); it += 256) {
+    for (int it = threadIdx.x; it < HH * (SSIM_TX / 4); it += 256) {
         const int ly = it / (SSIM_TX / 4), lx0 = (it % (SSIM_TX / 4)) * 4;
         lf2 p01[14];
         float p2[14];
@@ -521,16 +527,16 @@ __global__ void __launch_bounds__(256) l1_ssim_bwd_kernel(int H, int W, GaussWin
         }
     }
     __syncthreads();
-    const int lx = threadIdx.x & 31, ly0 = (threadIdx.x >> 5) * SSIM_VO;
-    lf2 r01[SSIM_VO];
-    float r2[SSIM_VO];
+    const int lx = threadIdx.x & 31, ly0 = (threadIdx.x >> 5) * VO;
+    lf2 r01[VO];
+    float r2[VO];
     {
-        lf2 c01[10 + SSIM_VO];
-        float c2[10 + SSIM_VO];
+        lf2 c01[10 + VO];
+        float c2[10 + VO];
 #pragma unroll
-        for (int k = 0; k < 10 + SSIM_VO; ++k) { c01[k] = s_h01[ly0 + k][lx]; c2[k] = s_h2[ly0 + k][lx]; }
+        for (int k = 0; k < 10 + VO; ++k) { c01[k] = s_h01[ly0 + k][lx]; c2[k] = s_h2[ly0 + k][lx]; }
 #pragma unroll
-        for (int o = 0; o < SSIM_VO; ++o) {
+        for (int o = 0; o < VO; ++o) {
             lf2 t01 = {0.f, 0.f};
             float t2 = 0.f;
 #pragma unroll
@@ -542,7 +548,7 @@ __global__ void __launch_bounds__(256) l1_ssim_bwd_kernel(int H, int W, GaussWin
     const float n = 1.f / (3.f * (float)P);
     const float kl1 = wl1 * g_l1[0] * n, kss = wss * g_ssim[0] * n;
 #pragma unroll
-    for (int o = 0; o < SSIM_VO; ++o) {
+    for (int o = 0; o < VO; ++o) {
         const int gy = y0 + ly0 + o;
         if (gx < W && gy < H) {
             const size_t oo = c * P + (size_t)gy * W + gx;
@@ -652,8 +658,8 @@ extern "C" int vcr_normal_losses_backward(int H, int W, float fx, float fy, floa
 extern "C" int vcr_l1_ssim_forward(int H, int W, const float* img1, const float* img2, double* sums2, float* means2,
                                    float* partials9, int sums_prezeroed, void* stream) {
     if (!(sums_prezeroed & 1)) VCR_HIP_CHECK(hipMemsetAsync(sums2, 0, 2 * (1 + VCR_NSLOT) * sizeof(double), (hipStream_t)stream));
-    const dim3 grid((W + SSIM_TX - 1) / SSIM_TX, (H + SSIM_TY - 1) / SSIM_TY, 3);
-    hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, make_window(), img1, img2, sums2,
+    const dim3 grid((W + SSIM_TX - 1) / SSIM_TX, (H + SSIM_TY_FWD - 1) / SSIM_TY_FWD, 3);
+    hipLaunchKernelGGL(l1_ssim_fwd_kernel<SSIM_TY_FWD>, grid, dim3(256), 0, (hipStream_t)stream, H, W, make_window(), img1, img2, sums2,
                        partials9);
     if (!(sums_prezeroed & 2))
         hipLaunchKernelGGL(finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, 2, sums2, 0,
@@ -664,8 +670,8 @@ extern "C" int vcr_l1_ssim_forward(int H, int W, const float* img1, const float*
 
 extern "C" int vcr_l1_ssim_backward(int H, int W, const float* img1, const float* img2, const float* partials9,
                                     const float* g_l1, const float* g_ssim, float* dimg1, void* stream) {
-    const dim3 grid((W + SSIM_TX - 1) / SSIM_TX, (H + SSIM_TY - 1) / SSIM_TY, 3);
-    hipLaunchKernelGGL(l1_ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, make_window(), img1, img2, partials9,
+    const dim3 grid((W + SSIM_TX - 1) / SSIM_TX, (H + SSIM_TY_BWD - 1) / SSIM_TY_BWD, 3);
+    hipLaunchKernelGGL(l1_ssim_bwd_kernel<SSIM_TY_BWD>, grid, dim3(256), 0, (hipStream_t)stream, H, W, make_window(), img1, img2, partials9,
                        g_l1, g_ssim, 1.f, 1.f, dimg1);
     VCR_HIP_CHECK(hipGetLastError());
     return 0;

@@ -22,26 +22,29 @@ __device__ __forceinline__ Cam load_cam(const VcrRasterArgs& a) {
     return cam;
 }
 
-__device__ __forceinline__ void quat_to_R(const float4 q, float R[9]) {
-    const float r = q.x, x = q.y, y = q.z, z = q.w;
-    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z); R[2] = 2.f * (x * z + r * y);
-    R[3] = 2.f * (x * y + r * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
-    R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
+// (T = float: the forward; T = double: the backward, see preprocess_bwd_kernel)
+template <typename T>
+__device__ __forceinline__ void quat_to_R(const float4 q, T R[9]) {
+    const T r = q.x, x = q.y, y = q.z, z = q.w;
+    R[0] = T(1) - T(2) * (y * y + z * z); R[1] = T(2) * (x * y - r * z); R[2] = T(2) * (x * z + r * y);
+    R[3] = T(2) * (x * y + r * z); R[4] = T(1) - T(2) * (x * x + z * z); R[5] = T(2) * (y * z - r * x);
+    R[6] = T(2) * (x * z - r * y); R[7] = T(2) * (y * z + r * x); R[8] = T(1) - T(2) * (x * x + y * y);
 }
 
 // Sigma (xx,xy,xz,yy,yz,zz)
-__device__ __forceinline__ void load_cov3d(const VcrRasterArgs& a, int i, float S[6], float R[9], float s[3]) {
+template <typename T>
+__device__ __forceinline__ void load_cov3d(const VcrRasterArgs& a, int i, T S[6], T R[9], T s[3]) {
     if (a.cov3D_precomp) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) S[k] = a.cov3D_precomp[6 * (size_t)i + k];
         return;
     }
     const float4 q = reinterpret_cast<const float4*>(a.rotations)[i];
-    quat_to_R(q, R);
-    s[0] = a.scales[3 * (size_t)i + 0] * a.scale_modifier;
-    s[1] = a.scales[3 * (size_t)i + 1] * a.scale_modifier;
-    s[2] = a.scales[3 * (size_t)i + 2] * a.scale_modifier;
-    const float s0 = s[0] * s[0], s1 = s[1] * s[1], s2 = s[2] * s[2];
+    quat_to_R<T>(q, R);
+    s[0] = (T)a.scales[3 * (size_t)i + 0] * (T)a.scale_modifier;
+    s[1] = (T)a.scales[3 * (size_t)i + 1] * (T)a.scale_modifier;
+    s[2] = (T)a.scales[3 * (size_t)i + 2] * (T)a.scale_modifier;
+    const T s0 = s[0] * s[0], s1 = s[1] * s[1], s2 = s[2] * s[2];
     S[0] = R[0] * R[0] * s0 + R[1] * R[1] * s1 + R[2] * R[2] * s2;
     S[1] = R[0] * R[3] * s0 + R[1] * R[4] * s1 + R[2] * R[5] * s2;
     S[2] = R[0] * R[6] * s0 + R[1] * R[7] * s1 + R[2] * R[8] * s2;
@@ -50,42 +53,47 @@ __device__ __forceinline__ void load_cov3d(const VcrRasterArgs& a, int i, float 
     S[5] = R[6] * R[6] * s0 + R[7] * R[7] * s1 + R[8] * R[8] * s2;
 }
 
-struct Proj {
-    float t[3];          // view-space position
-    float u, v;          // clamped tx/tz, ty/tz
+template <typename T>
+struct ProjT {
+    T t[3];              // view-space position
+    T u, v;              // clamped tx/tz, ty/tz
     bool uc, vc;         // clamp active
-    float M0[3], M1[3];  // rows of J * Rv
-    float fx, fy;
+    T M0[3], M1[3];      // rows of J * Rv
+    T fx, fy;
 };
+typedef ProjT<float> Proj;
 
-__device__ __forceinline__ void project(const VcrRasterArgs& a, const Cam& cam, const float p[3], Proj& pr) {
+template <typename T>
+__device__ __forceinline__ void project(const VcrRasterArgs& a, const Cam& cam, const T p[3], ProjT<T>& pr) {
     const float* V = cam.V;
-    pr.t[0] = p[0] * V[0] + p[1] * V[4] + p[2] * V[8] + V[12];
-    pr.t[1] = p[0] * V[1] + p[1] * V[5] + p[2] * V[9] + V[13];
-    pr.t[2] = p[0] * V[2] + p[1] * V[6] + p[2] * V[10] + V[14];
-    pr.fx = a.W / (2.f * a.tanfovx);
-    pr.fy = a.H / (2.f * a.tanfovy);
+    pr.t[0] = p[0] * (T)V[0] + p[1] * (T)V[4] + p[2] * (T)V[8] + (T)V[12];
+    pr.t[1] = p[0] * (T)V[1] + p[1] * (T)V[5] + p[2] * (T)V[9] + (T)V[13];
+    pr.t[2] = p[0] * (T)V[2] + p[1] * (T)V[6] + p[2] * (T)V[10] + (T)V[14];
+    pr.fx = (T)a.W / (T(2) * (T)a.tanfovx);
+    pr.fy = (T)a.H / (T(2) * (T)a.tanfovy);
 }
 
-__device__ __forceinline__ void jacobian_rows(const VcrRasterArgs& a, const Cam& cam, Proj& pr) {
+template <typename T>
+__device__ __forceinline__ void jacobian_rows(const VcrRasterArgs& a, const Cam& cam, ProjT<T>& pr) {
     const float* V = cam.V;
-    const float tz = pr.t[2], itz = 1.f / tz;
-    const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
-    const float ru = pr.t[0] * itz, rv = pr.t[1] * itz;
+    const T tz = pr.t[2], itz = T(1) / tz;
+    const T limx = (T)1.3f * (T)a.tanfovx, limy = (T)1.3f * (T)a.tanfovy;
+    const T ru = pr.t[0] * itz, rv = pr.t[1] * itz;
     pr.uc = (ru < -limx) || (ru > limx);
     pr.vc = (rv < -limy) || (rv > limy);
-    pr.u = fminf(limx, fmaxf(-limx, ru));
-    pr.v = fminf(limy, fmaxf(-limy, rv));
-    const float J00 = pr.fx * itz, J02 = -pr.fx * pr.u * itz;
-    const float J11 = pr.fy * itz, J12 = -pr.fy * pr.v * itz;
+    pr.u = ru < -limx ? -limx : (ru > limx ? limx : ru);
+    pr.v = rv < -limy ? -limy : (rv > limy ? limy : rv);
+    const T J00 = pr.fx * itz, J02 = -pr.fx * pr.u * itz;
+    const T J11 = pr.fy * itz, J12 = -pr.fy * pr.v * itz;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {           // Rv[c][k] = V[k*4+c]
-        pr.M0[k] = J00 * V[k * 4 + 0] + J02 * V[k * 4 + 2];
-        pr.M1[k] = J11 * V[k * 4 + 1] + J12 * V[k * 4 + 2];
+        pr.M0[k] = J00 * (T)V[k * 4 + 0] + J02 * (T)V[k * 4 + 2];
+        pr.M1[k] = J11 * (T)V[k * 4 + 1] + J12 * (T)V[k * 4 + 2];
     }
 }
 
-__device__ __forceinline__ void sym_mul(const float S[6], const float m[3], float o[3]) {
+template <typename T>
+__device__ __forceinline__ void sym_mul(const T S[6], const T m[3], T o[3]) {
     o[0] = S[0] * m[0] + S[1] * m[1] + S[2] * m[2];
     o[1] = S[1] * m[0] + S[3] * m[1] + S[4] * m[2];
     o[2] = S[2] * m[0] + S[4] * m[1] + S[5] * m[2];
@@ -363,12 +371,13 @@ __device__ __forceinline__ uint32_t preprocess_one(const VcrRasterArgs& a, const
     return (uint32_t)ntiles;
 }
 
-// vis_slots (optional): 3 x VCR_VIS_SLOTS counters, [visible Gaussians | tile instances of the 3-sigma rectangles | tile
-// instances emitted], three atomics per block spread over many addresses (same-address L2 atomics serialise at ~200 ns each)
+// vis_slots (optional; then blk_counts and host too): the library-owned ticket / flag words (vcr_common.h); blk_counts: three words
+// per workgroup, [visible Gaussians | tile instances of the 3-sigma rectangles | tile instances emitted]
 template <bool STAGE, bool COLOUR, bool QL>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, GeomState g, int32_t* __restrict__ radii,
                                                              uint32_t* __restrict__ depth_key, uint32_t* __restrict__ ids,
-                                                             uint32_t* __restrict__ vis_slots, VcrPublished* host, uint32_t seq) {
+                                                             uint32_t* __restrict__ vis_slots, uint32_t* __restrict__ blk_counts,
+                                                             VcrPublished* host, uint32_t seq) {
     extern __shared__ __attribute__((aligned(16))) float s_sh[];
     if (STAGE) {
         const int base = blockIdx.x * 256;
@@ -378,51 +387,53 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
     uint32_t em;
     bool far;
     const uint32_t nt = preprocess_one<STAGE, COLOUR, QL>(a, g, radii, depth_key, ids, s_sh, blockIdx.x * 256 + threadIdx.x, em, far);
-    if (vis_slots && __builtin_amdgcn_ballot_w64(far) != 0 && (threadIdx.x & 63) == 0)      // (a visible depth beyond 27 key bits: rare)
-        atomicOr(vis_slots + VCR_FAR_FLAG_WORD, 1u);
     if (vis_slots) {
-        __shared__ uint32_t s_cnt[3][4];
+        __shared__ uint32_t s_cnt[4][4];
         __shared__ bool s_last;
         uint32_t c = nt != 0 ? 1u : 0u, r = nt;
         for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); r += __shfl_xor(r, o); em += __shfl_xor(em, o); }
-        if ((threadIdx.x & 63) == 0) { s_cnt[0][threadIdx.x >> 6] = c; s_cnt[1][threadIdx.x >> 6] = r; s_cnt[2][threadIdx.x >> 6] = em; }
-        __syncthreads();
-        if (threadIdx.x < 3) {
-            const uint32_t t = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
-            if (t) atomicAdd(vis_slots + threadIdx.x * VCR_VIS_SLOTS + blockIdx.x % VCR_VIS_SLOTS, t);
+        const uint32_t anyfar = __builtin_amdgcn_ballot_w64(far) != 0 ? 1u : 0u;       // (a visible depth beyond 27 key bits: rare)
+        if ((threadIdx.x & 63) == 0) {
+            s_cnt[0][threadIdx.x >> 6] = c; s_cnt[1][threadIdx.x >> 6] = r; s_cnt[2][threadIdx.x >> 6] = em; s_cnt[3][threadIdx.x >> 6] = anyfar;
         }
-        if (!host) return;
-        // Epilogue of the LAST workgroup to arrive (round 5, was publish_counts_kernel + a memset in front of every call): every
-        // workgroup orders its counter atomics before its ticket; the one that draws the last ticket therefore sees all of them,
-        // folds the slots, hands the totals to the spinning host and leaves the counter block zero for the next call.
-        __threadfence();
         __syncthreads();
+        // Round 5 (was: three contended slot atomics per workgroup, a memset in front of every call and publish_counts_kernel
+        // behind it): thread 0 STORES the workgroup's three counts into the workgroup's own words of `blk_counts` (device-scope
+        // stores: write-through), waits for them to complete and draws the done-ticket; the workgroup that draws the last
+        // ticket sums all rows, hands the totals to the spinning host and leaves the ticket words zero for the next call.
+        // No fence anywhere: a __threadfence() here writes back and invalidates the XCD's whole L2, and 3907 of them made this
+        // 38 us kernel take 730 us; the ordering that is needed -- counts before ticket -- is the s_waitcnt between them.
         if (threadIdx.x == 0) {
-            // two-level ticket (vcr_common.h): the last arrival of group b % 64 resets the group word and draws the top ticket
+            uint32_t* row = blk_counts + 3 * (size_t)blockIdx.x;
+            __hip_atomic_store(row + 0, s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(row + 1, s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(row + 2, s_cnt[2][0] + s_cnt[2][1] + s_cnt[2][2] + s_cnt[2][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s_cnt[3][0] | s_cnt[3][1] | s_cnt[3][2] | s_cnt[3][3]) {
+                uint32_t was = atomicOr(vis_slots + VCR_FAR_FLAG_WORD, 1u);
+                asm volatile("" : "+v"(was));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // two-level ticket (vcr_common.h)
             const uint32_t grp = blockIdx.x % VCR_DONE_GROUPS;
             const uint32_t in_grp = (gridDim.x - grp + VCR_DONE_GROUPS - 1) / VCR_DONE_GROUPS;
             const uint32_t groups = gridDim.x < VCR_DONE_GROUPS ? gridDim.x : VCR_DONE_GROUPS;
             bool last = false;
             if (atomicAdd(vis_slots + VCR_DONE_GROUP_WORD + grp, 1u) == in_grp - 1) {
-                __hip_atomic_store(vis_slots + VCR_DONE_GROUP_WORD + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __threadfence();
+                uint32_t was = atomicExch(vis_slots + VCR_DONE_GROUP_WORD + grp, 0u);    // (reset for the next call, performed ...
+                asm volatile("" : "+v"(was));                                            //  ... before the top ticket is drawn)
                 last = atomicAdd(vis_slots + VCR_DONE_WORD, 1u) == groups - 1;
             }
             s_last = last;
         }
         __syncthreads();
         if (!s_last) return;
-        __threadfence();
         __shared__ unsigned long long s_r[4], s_e[4];
         __shared__ uint32_t s_v[4];
         unsigned long long rr = 0, ee = 0; uint32_t vv = 0;
-        for (int k = threadIdx.x; k < VCR_VIS_SLOTS; k += 256) {
-            vv += __hip_atomic_load(vis_slots + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            rr += __hip_atomic_load(vis_slots + VCR_VIS_SLOTS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ee += __hip_atomic_load(vis_slots + 2 * VCR_VIS_SLOTS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(vis_slots + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(vis_slots + VCR_VIS_SLOTS + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(vis_slots + 2 * VCR_VIS_SLOTS + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t k = threadIdx.x; k < gridDim.x; k += 256) {
+            vv += __hip_atomic_load(blk_counts + 3 * (size_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            rr += __hip_atomic_load(blk_counts + 3 * (size_t)k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ee += __hip_atomic_load(blk_counts + 3 * (size_t)k + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         for (int o = 32; o > 0; o >>= 1) { vv += __shfl_xor(vv, o); rr += __shfl_xor(rr, o); ee += __shfl_xor(ee, o); }
         if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = vv; s_r[threadIdx.x >> 6] = rr; s_e[threadIdx.x >> 6] = ee; }
@@ -495,15 +506,25 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
     if (!STAGE && !live) return;
     const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
 
-    float dp[3] = {0.f, 0.f, 0.f};                 // dL/dmeans3D
+    // Arithmetic of the adjoint chain below: fp64 (round 5).  profiles/r5_grad_stage_errors.txt separated the stages: the
+    // screen-space sums the compositing backward leaves in the GradRec are as accurate as an fp32 evaluation of the oracle
+    // (error ratio ~1.0), the PARAMETER gradients were 2-5x worse -- the excess was made HERE: conic -> Sigma2D -> Sigma3D ->
+    // (scale, quaternion) and the Jacobian's dependence on the mean are sums of products that cancel for flat / needle-shaped
+    // Gaussians.  One lane handles one Gaussian and the kernel streams ~300 B for it: ~400 fp64 operations per Gaussian are
+    // free next to that (VCR_BWD_REAL=float: the round-1-4 arithmetic, for the A/B).
+#ifndef VCR_BWD_REAL
+#define VCR_BWD_REAL double
+#endif
+    typedef VCR_BWD_REAL BR;
+    BR dp[3] = {0, 0, 0};                          // dL/dmeans3D
     float dm2[2] = {0.f, 0.f}, dm2a[2] = {0.f, 0.f};
     float dn[3] = {0.f, 0.f, 0.f};
     float dop = 0.f;
-    float dS[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // dL/dSigma (symmetric, full-matrix entries)
+    BR dS[6] = {0, 0, 0, 0, 0, 0};                 // dL/dSigma (symmetric, full-matrix entries)
     float dcol[3] = {0.f, 0.f, 0.f};
-    float R[9], s[3], S[6];
-    float dsc[3] = {0.f, 0.f, 0.f};
-    float dq[4] = {0.f, 0.f, 0.f, 0.f};
+    BR R[9], s[3], S[6];
+    BR dsc[3] = {0, 0, 0};
+    BR dq[4] = {0, 0, 0, 0};
     float dsem[VCR_MAX_SEM] = {0.f, 0.f, 0.f, 0.f};
 
     if (vis) {
@@ -521,27 +542,27 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
             for (int k = 0; k < a.S; ++k) { dsem[k] = sgrad_sem[(size_t)i * a.S + k]; sgrad_sem[(size_t)i * a.S + k] = 0.f; }
         }
         gr.finish(a.opacities[i]);
-        const float p[3] = {a.means3D[i3], a.means3D[i3 + 1], a.means3D[i3 + 2]};
-        Proj pr;
-        project(a, cam, p, pr);
-        load_cov3d(a, i, S, R, s);
-        jacobian_rows(a, cam, pr);
-        float SM0[3], SM1[3];
-        sym_mul(S, pr.M0, SM0);
-        sym_mul(S, pr.M1, SM1);
-        const float ca = pr.M0[0] * SM0[0] + pr.M0[1] * SM0[1] + pr.M0[2] * SM0[2] + VCR_LOWPASS;
-        const float cb = pr.M0[0] * SM1[0] + pr.M0[1] * SM1[1] + pr.M0[2] * SM1[2];
-        const float cc = pr.M1[0] * SM1[0] + pr.M1[1] * SM1[1] + pr.M1[2] * SM1[2] + VCR_LOWPASS;
-        const float det = ca * cc - cb * cb;
-        const float id2 = 1.f / (det * det);
+        const BR p[3] = {(BR)a.means3D[i3], (BR)a.means3D[i3 + 1], (BR)a.means3D[i3 + 2]};
+        ProjT<BR> pr;
+        project<BR>(a, cam, p, pr);
+        load_cov3d<BR>(a, i, S, R, s);
+        jacobian_rows<BR>(a, cam, pr);
+        BR SM0[3], SM1[3];
+        sym_mul<BR>(S, pr.M0, SM0);
+        sym_mul<BR>(S, pr.M1, SM1);
+        const BR ca = pr.M0[0] * SM0[0] + pr.M0[1] * SM0[1] + pr.M0[2] * SM0[2] + (BR)VCR_LOWPASS;
+        const BR cb = pr.M0[0] * SM1[0] + pr.M0[1] * SM1[1] + pr.M0[2] * SM1[2];
+        const BR cc = pr.M1[0] * SM1[0] + pr.M1[1] * SM1[1] + pr.M1[2] * SM1[2] + (BR)VCR_LOWPASS;
+        const BR det = ca * cc - cb * cb;
+        const BR id2 = BR(1) / (det * det);
         // conic (A,B,C) = (c,-b,a)/det  ->  cov2D (a,b,c)
-        const float gA = gr.ca, gB = gr.cb, gC = gr.cc;
-        const float ga = (-cc * cc * gA + cb * cc * gB - cb * cb * gC) * id2;
-        const float gc = (-ca * ca * gC + ca * cb * gB - cb * cb * gA) * id2;
-        const float gb = (2.f * cb * cc * gA - (ca * cc + cb * cb) * gB + 2.f * ca * cb * gC) * id2;
-        const float hb = 0.5f * gb;
+        const BR gA = gr.ca, gB = gr.cb, gC = gr.cc;
+        const BR ga = (-cc * cc * gA + cb * cc * gB - cb * cb * gC) * id2;
+        const BR gc = (-ca * ca * gC + ca * cb * gB - cb * cb * gA) * id2;
+        const BR gb = (BR(2) * cb * cc * gA - (ca * cc + cb * cb) * gB + BR(2) * ca * cb * gC) * id2;
+        const BR hb = BR(0.5) * gb;
         // dSigma = M^T G M
-        const float* M0 = pr.M0; const float* M1 = pr.M1;
+        const BR* M0 = pr.M0; const BR* M1 = pr.M1;
         dS[0] = ga * M0[0] * M0[0] + gb * M0[0] * M1[0] + gc * M1[0] * M1[0];
         dS[3] = ga * M0[1] * M0[1] + gb * M0[1] * M1[1] + gc * M1[1] * M1[1];
         dS[5] = ga * M0[2] * M0[2] + gb * M0[2] * M1[2] + gc * M1[2] * M1[2];
@@ -549,52 +570,54 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
         dS[2] = ga * M0[0] * M0[2] + hb * (M0[0] * M1[2] + M1[0] * M0[2]) + gc * M1[0] * M1[2];
         dS[4] = ga * M0[1] * M0[2] + hb * (M0[1] * M1[2] + M1[1] * M0[2]) + gc * M1[1] * M1[2];
         // dM = 2 G M Sigma
-        float dM0[3], dM1[3];
+        BR dM0[3], dM1[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            dM0[k] = 2.f * (ga * SM0[k] + hb * SM1[k]);
-            dM1[k] = 2.f * (hb * SM0[k] + gc * SM1[k]);
+            dM0[k] = BR(2) * (ga * SM0[k] + hb * SM1[k]);
+            dM1[k] = BR(2) * (hb * SM0[k] + gc * SM1[k]);
         }
         // dJ = dM Rv^T, Rv[c][k] = V[k*4+c]
-        const float dJ00 = dM0[0] * V[0] + dM0[1] * V[4] + dM0[2] * V[8];
-        const float dJ02 = dM0[0] * V[2] + dM0[1] * V[6] + dM0[2] * V[10];
-        const float dJ11 = dM1[0] * V[1] + dM1[1] * V[5] + dM1[2] * V[9];
-        const float dJ12 = dM1[0] * V[2] + dM1[1] * V[6] + dM1[2] * V[10];
-        const float tz = pr.t[2], itz = 1.f / tz, itz2 = itz * itz;
-        float dt[3] = {0.f, 0.f, 0.f};
+        const BR dJ00 = dM0[0] * (BR)V[0] + dM0[1] * (BR)V[4] + dM0[2] * (BR)V[8];
+        const BR dJ02 = dM0[0] * (BR)V[2] + dM0[1] * (BR)V[6] + dM0[2] * (BR)V[10];
+        const BR dJ11 = dM1[0] * (BR)V[1] + dM1[1] * (BR)V[5] + dM1[2] * (BR)V[9];
+        const BR dJ12 = dM1[0] * (BR)V[2] + dM1[1] * (BR)V[6] + dM1[2] * (BR)V[10];
+        const BR tz = pr.t[2], itz = BR(1) / tz, itz2 = itz * itz;
+        BR dt[3] = {0, 0, 0};
         dt[2] = (-dJ00 * pr.fx + dJ02 * pr.fx * pr.u - dJ11 * pr.fy + dJ12 * pr.fy * pr.v) * itz2;
-        const float du = -dJ02 * pr.fx * itz, dv = -dJ12 * pr.fy * itz;
+        const BR du = -dJ02 * pr.fx * itz, dv = -dJ12 * pr.fy * itz;
         if (!pr.uc) { dt[0] += du * itz; dt[2] -= du * pr.t[0] * itz2; }
         if (!pr.vc) { dt[1] += dv * itz; dt[2] -= dv * pr.t[1] * itz2; }
         // depth and plane offset
-        dt[2] += gr.z;
+        dt[2] += (BR)gr.z;
         if (a.normals_precomp) {
-            const float n[3] = {a.normals_precomp[i3], a.normals_precomp[i3 + 1], a.normals_precomp[i3 + 2]};
-            dt[0] += n[0] * gr.plane; dt[1] += n[1] * gr.plane; dt[2] += n[2] * gr.plane;
-            dn[0] = gr.nx + pr.t[0] * gr.plane; dn[1] = gr.ny + pr.t[1] * gr.plane; dn[2] = gr.nz + pr.t[2] * gr.plane;
+            const BR n[3] = {(BR)a.normals_precomp[i3], (BR)a.normals_precomp[i3 + 1], (BR)a.normals_precomp[i3 + 2]};
+            dt[0] += n[0] * (BR)gr.plane; dt[1] += n[1] * (BR)gr.plane; dt[2] += n[2] * (BR)gr.plane;
+            BR dnr[3] = {(BR)gr.nx + pr.t[0] * (BR)gr.plane, (BR)gr.ny + pr.t[1] * (BR)gr.plane, (BR)gr.nz + pr.t[2] * (BR)gr.plane};
             if (!TAIL && io.normals_Rw2c) {        // data parallel: as the gradient w.r.t. the world-space axis column (vcr_raster.h)
                 const float* Rw = io.normals_Rw2c;
-                const float sg = (io.normals_aux[i] & 4) ? -1.f : 1.f;
-                const float w0 = sg * (Rw[0] * dn[0] + Rw[3] * dn[1] + Rw[6] * dn[2]);
-                const float w1 = sg * (Rw[1] * dn[0] + Rw[4] * dn[1] + Rw[7] * dn[2]);
-                const float w2 = sg * (Rw[2] * dn[0] + Rw[5] * dn[1] + Rw[8] * dn[2]);
-                dn[0] = w0; dn[1] = w1; dn[2] = w2;
+                const BR sg = (io.normals_aux[i] & 4) ? BR(-1) : BR(1);
+                const BR w0 = sg * ((BR)Rw[0] * dnr[0] + (BR)Rw[3] * dnr[1] + (BR)Rw[6] * dnr[2]);
+                const BR w1 = sg * ((BR)Rw[1] * dnr[0] + (BR)Rw[4] * dnr[1] + (BR)Rw[7] * dnr[2]);
+                const BR w2 = sg * ((BR)Rw[2] * dnr[0] + (BR)Rw[5] * dnr[1] + (BR)Rw[8] * dnr[2]);
+                dnr[0] = w0; dnr[1] = w1; dnr[2] = w2;
             }
+            dn[0] = (float)dnr[0]; dn[1] = (float)dnr[1]; dn[2] = (float)dnr[2];
         }
         // t = p Rv^T + tv  ->  dp_k += sum_c dt_c V[k*4+c]
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dp[k] += dt[0] * V[k * 4 + 0] + dt[1] * V[k * 4 + 1] + dt[2] * V[k * 4 + 2];
+        for (int k = 0; k < 3; ++k) dp[k] += dt[0] * (BR)V[k * 4 + 0] + dt[1] * (BR)V[k * 4 + 1] + dt[2] * (BR)V[k * 4 + 2];
         // pixel position through the full projection
-        const float hx = p[0] * P[0] + p[1] * P[4] + p[2] * P[8] + P[12];
-        const float hy = p[0] * P[1] + p[1] * P[5] + p[2] * P[9] + P[13];
-        const float hw = p[0] * P[3] + p[1] * P[7] + p[2] * P[11] + P[15];
-        const float pw = 1.f / (hw + 1e-7f);
+        const BR hx = p[0] * (BR)P[0] + p[1] * (BR)P[4] + p[2] * (BR)P[8] + (BR)P[12];
+        const BR hy = p[0] * (BR)P[1] + p[1] * (BR)P[5] + p[2] * (BR)P[9] + (BR)P[13];
+        const BR hw = p[0] * (BR)P[3] + p[1] * (BR)P[7] + p[2] * (BR)P[11] + (BR)P[15];
+        const BR pw = BR(1) / (hw + (BR)1e-7f);
         dm2[0] = gr.gx * 0.5f * a.W; dm2[1] = gr.gy * 0.5f * a.H;
         dm2a[0] = gr.agx * 0.5f * a.W; dm2a[1] = gr.agy * 0.5f * a.H;
-        const float dhx = dm2[0] * pw, dhy = dm2[1] * pw;
-        const float dhw = -(hx * dm2[0] + hy * dm2[1]) * pw * pw;
+        const BR g2x = (BR)gr.gx * BR(0.5) * (BR)a.W, g2y = (BR)gr.gy * BR(0.5) * (BR)a.H;
+        const BR dhx = g2x * pw, dhy = g2y * pw;
+        const BR dhw = -(hx * g2x + hy * g2y) * pw * pw;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dp[k] += P[k * 4 + 0] * dhx + P[k * 4 + 1] * dhy + P[k * 4 + 3] * dhw;
+        for (int k = 0; k < 3; ++k) dp[k] += (BR)P[k * 4 + 0] * dhx + (BR)P[k * 4 + 1] * dhy + (BR)P[k * 4 + 3] * dhw;
         dop = gr.opacity;
         // colour
         dcol[0] = gr.r; dcol[1] = gr.g; dcol[2] = gr.b;
@@ -603,7 +626,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
             if (cl & 1) dcol[0] = 0.f;
             if (cl & 2) dcol[1] = 0.f;
             if (cl & 4) dcol[2] = 0.f;
-            float dx = p[0] - cam.c[0], dy = p[1] - cam.c[1], dz = p[2] - cam.c[2];
+            const float pf[3] = {a.means3D[i3], a.means3D[i3 + 1], a.means3D[i3 + 2]};
+            float dx = pf[0] - cam.c[0], dy = pf[1] - cam.c[1], dz = pf[2] - cam.c[2];
             const float il = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
             dx *= il; dy *= il; dz *= il;
             // colour -> mean through the view direction: M was stored with the colour (GeomState::cjac), so the 192 B of SH
@@ -620,33 +644,33 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
             }
             if (io.view_dirs) { io.view_dirs[i3] = dx; io.view_dirs[i3 + 1] = dy; io.view_dirs[i3 + 2] = dz; }
             const float4 m0 = g.cjac[3 * (size_t)i], m1 = g.cjac[3 * (size_t)i + 1], m2 = g.cjac[3 * (size_t)i + 2];
-            dp[0] += dcol[0] * m0.x + dcol[1] * m1.x + dcol[2] * m2.x;
-            dp[1] += dcol[0] * m0.y + dcol[1] * m1.y + dcol[2] * m2.y;
-            dp[2] += dcol[0] * m0.z + dcol[1] * m1.z + dcol[2] * m2.z;
+            dp[0] += (BR)dcol[0] * (BR)m0.x + (BR)dcol[1] * (BR)m1.x + (BR)dcol[2] * (BR)m2.x;
+            dp[1] += (BR)dcol[0] * (BR)m0.y + (BR)dcol[1] * (BR)m1.y + (BR)dcol[2] * (BR)m2.y;
+            dp[2] += (BR)dcol[0] * (BR)m0.z + (BR)dcol[1] * (BR)m1.z + (BR)dcol[2] * (BR)m2.z;
         }
         // Sigma = (R s)(R s)^T
         if (!a.cov3D_precomp) {
-            float dR[9];
+            BR dR[9];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const float d0 = (r == 0 ? dS[0] : (r == 1 ? dS[1] : dS[2]));
-                const float d1 = (r == 0 ? dS[1] : (r == 1 ? dS[3] : dS[4]));
-                const float d2 = (r == 0 ? dS[2] : (r == 1 ? dS[4] : dS[5]));
+                const BR d0 = (r == 0 ? dS[0] : (r == 1 ? dS[1] : dS[2]));
+                const BR d1 = (r == 0 ? dS[1] : (r == 1 ? dS[3] : dS[4]));
+                const BR d2 = (r == 0 ? dS[2] : (r == 1 ? dS[4] : dS[5]));
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     // dL_rk = 2 * sum_j dSigma[r][j] L[j][k], L[j][k] = R[j][k] s_k
-                    const float dL = 2.f * (d0 * R[0 * 3 + k] + d1 * R[1 * 3 + k] + d2 * R[2 * 3 + k]) * s[k];
+                    const BR dL = BR(2) * (d0 * R[0 * 3 + k] + d1 * R[1 * 3 + k] + d2 * R[2 * 3 + k]) * s[k];
                     dsc[k] += dL * R[r * 3 + k];
                     dR[r * 3 + k] = dL * s[k];
                 }
             }
-            const float4 q = reinterpret_cast<const float4*>(a.rotations)[i];
-            const float r = q.x, x = q.y, y = q.z, z = q.w;
-            dq[0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
-            dq[1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
-            dq[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
-            dq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
-            dsc[0] *= a.scale_modifier; dsc[1] *= a.scale_modifier; dsc[2] *= a.scale_modifier;
+            const float4 qf = reinterpret_cast<const float4*>(a.rotations)[i];
+            const BR r = qf.x, x = qf.y, y = qf.z, z = qf.w;
+            dq[0] = BR(2) * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+            dq[1] = BR(2) * (y * dR[1] + z * dR[2] + y * dR[3] - BR(2) * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - BR(2) * x * dR[8]);
+            dq[2] = BR(2) * (-BR(2) * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - BR(2) * y * dR[8]);
+            dq[3] = BR(2) * (-BR(2) * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - BR(2) * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+            dsc[0] *= (BR)a.scale_modifier; dsc[1] *= (BR)a.scale_modifier; dsc[2] *= (BR)a.scale_modifier;
         }
     } else if (io.dL_dshs && (STAGE || live)) {
         float* dsh = STAGE ? (s_sh + threadIdx.x * SH_ROW) : (io.dL_dshs + (size_t)i * a.K * 3);
@@ -669,19 +693,19 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
         if (io.dL_dsemantics)
             for (int k = 0; k < a.S; ++k) io.dL_dsemantics[(size_t)i * a.S + k] = dsem[k];
         TailGrads tg;
-        tg.dp[0] = dp[0]; tg.dp[1] = dp[1]; tg.dp[2] = dp[2];
-        tg.ds[0] = dsc[0]; tg.ds[1] = dsc[1]; tg.ds[2] = dsc[2];
+        tg.dp[0] = (float)dp[0]; tg.dp[1] = (float)dp[1]; tg.dp[2] = (float)dp[2];
+        tg.ds[0] = (float)dsc[0]; tg.ds[1] = (float)dsc[1]; tg.ds[2] = (float)dsc[2];
         tg.dn[0] = dn[0]; tg.dn[1] = dn[1]; tg.dn[2] = dn[2];
         const bool dens = io.dL_dmeans2D_densify != nullptr;         // (which screen gradient feeds the statistics: a flag here)
         tg.dm2[0] = dens ? dm2a[0] : dm2[0]; tg.dm2[1] = dens ? dm2a[1] : dm2[1];
-        tg.dq = make_float4(dq[0], dq[1], dq[2], dq[3]);
+        tg.dq = make_float4((float)dq[0], (float)dq[1], (float)dq[2], (float)dq[3]);
         tg.dop = dop;
         tg.radius = radii[i];
         tg.has_n = a.normals_precomp != nullptr;
         geometry_step_one<true>(ta.t, ta.gb, i, tg);
         return;
     }
-    io.dL_dmeans3D[i3] = dp[0]; io.dL_dmeans3D[i3 + 1] = dp[1]; io.dL_dmeans3D[i3 + 2] = dp[2];
+    io.dL_dmeans3D[i3] = (float)dp[0]; io.dL_dmeans3D[i3 + 1] = (float)dp[1]; io.dL_dmeans3D[i3 + 2] = (float)dp[2];
     io.dL_dmeans2D[i3] = dm2[0]; io.dL_dmeans2D[i3 + 1] = dm2[1]; io.dL_dmeans2D[i3 + 2] = 0.f;
     if (io.dL_dmeans2D_densify) {
         io.dL_dmeans2D_densify[i3] = dm2a[0]; io.dL_dmeans2D_densify[i3 + 1] = dm2a[1];
@@ -694,12 +718,13 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
     if (io.dL_dsemantics)
         for (int k = 0; k < a.S; ++k) io.dL_dsemantics[(size_t)i * a.S + k] = dsem[k];
     if (io.dL_dscales) {
-        io.dL_dscales[i3] = dsc[0]; io.dL_dscales[i3 + 1] = dsc[1]; io.dL_dscales[i3 + 2] = dsc[2];
-        reinterpret_cast<float4*>(io.dL_drotations)[i] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+        io.dL_dscales[i3] = (float)dsc[0]; io.dL_dscales[i3 + 1] = (float)dsc[1]; io.dL_dscales[i3 + 2] = (float)dsc[2];
+        reinterpret_cast<float4*>(io.dL_drotations)[i] = make_float4((float)dq[0], (float)dq[1], (float)dq[2], (float)dq[3]);
     }
     if (io.dL_dcov3D) {
         float* d = io.dL_dcov3D + 6 * (size_t)i;
-        d[0] = dS[0]; d[1] = 2.f * dS[1]; d[2] = 2.f * dS[2]; d[3] = dS[3]; d[4] = 2.f * dS[4]; d[5] = dS[5];
+        d[0] = (float)dS[0]; d[1] = (float)(BR(2) * dS[1]); d[2] = (float)(BR(2) * dS[2]); d[3] = (float)dS[3];
+        d[4] = (float)(BR(2) * dS[4]); d[5] = (float)dS[5];
     }
 }
 
@@ -1024,17 +1049,18 @@ int vcr_launch_depth_keys(const VcrRasterArgs& a, uint32_t* depth_key, hipStream
 }
 
 int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key, uint32_t* ids,
-                          uint32_t* vis_slots, bool colour, hipStream_t st, VcrPublished* host, uint32_t seq) {
+                          uint32_t* vis_slots, bool colour, hipStream_t st, uint32_t* blk_counts, VcrPublished* host, uint32_t seq) {
+    if (vis_slots && (!blk_counts || !host)) { vcr_set_error("vcr_launch_preprocess: counters without rows / host record"); return 1; }
     if (a.N == 0) return 0;
     const int blocks = (a.N + 255) / 256;
 #define VCR_PRE(STAGE, COLOUR, SMEM)                                                                                          \
     do {                                                                                                                       \
         if (a.quad_lists)                                                                                                      \
             hipLaunchKernelGGL((preprocess_fwd_kernel<STAGE, COLOUR, true>), dim3(blocks), dim3(256), SMEM, st, a, g, radii,   \
-                               depth_key, ids, vis_slots, host, seq);                                                          \
+                               depth_key, ids, vis_slots, blk_counts, host, seq);                                                          \
         else                                                                                                                   \
             hipLaunchKernelGGL((preprocess_fwd_kernel<STAGE, COLOUR, false>), dim3(blocks), dim3(256), SMEM, st, a, g, radii,  \
-                               depth_key, ids, vis_slots, host, seq);                                                          \
+                               depth_key, ids, vis_slots, blk_counts, host, seq);                                                          \
     } while (0)
     if (!colour) VCR_PRE(false, false, 0);
     else if (a.shs && a.K == SH_K) VCR_PRE(true, true, 256 * SH_ROW * sizeof(float));

@@ -166,26 +166,26 @@ void vcr_set_error(const char* fmt, ...);
     } while (0)
 
 // ---- stage launchers (defined in the .hip files) ----------------------------------------------
-#define VCR_VIS_SLOTS 1024                    // counter slots for visible Gaussians / 3-sigma tile instances / emitted tile instances
-#define VCR_FAR_FLAG_WORD (3 * VCR_VIS_SLOTS)  // behind the three slot arrays: != 0 when a visible depth key needs more than 27 bits
-#define VCR_DONE_WORD (VCR_FAR_FLAG_WORD + 1)  // groups of projection workgroups that have all added their counts (the last one publishes)
-#define VCR_DUP_TICKET_WORD (VCR_FAR_FLAG_WORD + 2)   // logical block index of the emission kernel (its last block resets it)
-// "last workgroup" detection in TWO levels: thousands of atomics on ONE address serialise at ~190 ns each (measured: a single
-// ticket word made the 38 us projection of 1 M Gaussians take 730 us), so workgroup b first draws a ticket from group word
-// b % VCR_DONE_GROUPS (<= ~60 arrivals per address, spread over the kernel's run time), and only the last arrival of a group
-// draws from VCR_DONE_WORD
+// Counter words of one forward call (LIBRARY-OWNED, zero between calls: the kernels clean up after themselves, no memset launch)
+#define VCR_FAR_FLAG_WORD 0        // != 0 when a visible depth key needs more than 27 bits
+#define VCR_DONE_WORD 1            // groups of projection workgroups that have all stored their counts (the last one publishes)
+#define VCR_DUP_TICKET_WORD 2      // logical block index of the emission kernel (its last block resets it)
+// "last workgroup" detection in TWO levels: workgroup b first draws a ticket from group word b % VCR_DONE_GROUPS (<= ~60
+// arrivals per address, spread over the kernel's run time), and only the last arrival of a group draws from VCR_DONE_WORD
+// (profiles/microbench/ticket_rates.hip: back-to-back atomics on one address cost ~10 ns each)
 #define VCR_DONE_GROUPS 64
-#define VCR_DONE_GROUP_WORD (VCR_FAR_FLAG_WORD + 64)
-#define VCR_CTR_WORDS (3 * VCR_VIS_SLOTS + 64 + VCR_DONE_GROUPS)
+#define VCR_DONE_GROUP_WORD 64
+#define VCR_CTR_WORDS (64 + VCR_DONE_GROUPS)
+#define VCR_VIS_SLOTS 1024         // (Readback layout of the debug path)
 // What the host polls after the projection: totals + a sequence number published by the device AFTER the totals (system-scope
 // fence).  R: tile instances of the 3-sigma rectangles (what the reference counts), E: instances really emitted (exact rejection).
 struct VcrPublished { unsigned long long R, E; uint32_t V; uint32_t far; volatile uint32_t seq; };
-// The counter block is LIBRARY-OWNED and zero between calls (round 5): the projection's last workgroup -- an atomic ticket on
-// VCR_DONE_WORD tells which one that is -- folds the slots, publishes the totals to `host` (pinned, coherent) and re-zeroes every
-// word it read, so neither a memset in front of the projection nor a publish kernel behind it is launched.
+// `vis_slots`: the counter words above; `blk_counts`: 3 words per workgroup of the projection ((N + 255) / 256 rows, library-owned,
+// need not be cleared); `host`: pinned, coherent.  The projection's last workgroup sums the rows and publishes (round 5: neither a
+// memset in front of the projection nor a publish kernel behind it).
 int vcr_launch_preprocess(const VcrRasterArgs& a, GeomState g, int32_t* radii, uint32_t* depth_key,
                           uint32_t* ids, uint32_t* vis_slots, bool colour, hipStream_t st,
-                          VcrPublished* host = nullptr, uint32_t seq = 0);
+                          uint32_t* blk_counts = nullptr, VcrPublished* host = nullptr, uint32_t seq = 0);
 int vcr_launch_depth_keys(const VcrRasterArgs& a, uint32_t* depth_key, hipStream_t st);
 int vcr_launch_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st);
 int vcr_launch_sh_update_colour(const VcrRasterArgs& a, GeomState g, hipStream_t st);   // a.sh_update + colour in one pass
