@@ -224,8 +224,51 @@ def bin_and_sort(pre):
     return owner, beg, end, R
 
 
-def composite_tile(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem, num_dist=0):
-    """K6 for one 16x16 tile, vectorised over [pixels, list]."""
+FRAGILE_K = 16.0          # multiples of the fp32 unit roundoff (2^-24) x the magnitude of what is being rounded, see _mark_fragile
+
+
+@torch.no_grad()
+def _mark_fragile(fragile, idx, con, dx, dy, power, opac, alpha, valid, a_eff, T_incl, stopped, contrib, z):
+    """Which Gaussians of this tile sit on a DISCONTINUITY of the algorithm that an fp32 evaluation may resolve the other way?
+    The rasterizer decides per (pixel, entry) -- power <= 0, alpha >= 1/255, T' < 1e-4 (stop) -- and per pair of list neighbours
+    (depth order); each decision moves the result by a finite amount, so two correct fp32 implementations that round
+    differently agree only up to those flips, however accurate their arithmetic is.  A decision is FRAGILE when its test
+    quantity lies within the rounding-error bound of an fp32 evaluation of it:
+        exponent   |ln(alpha / (1/255))| or |power| <  K u (|A dx^2|/2 + |C dy^2|/2 + |B dx dy| + |ln o| + 1)
+        stop       |ln(T' / 1e-4)|                  <  K u sum_{j<=k} 1 / (1 - alpha_j)          (u = 2^-24)
+        order      |z_k+1 - z_k|                    <  K u |z|
+    A fragile alpha / power test at (pixel, k) marks k and everything that contributes behind it at that pixel (their
+    transmittance changes by the factor 1 - alpha_k); a fragile stop marks the entry it decides about; a fragile order marks
+    both neighbours.  `fragile` [N] bool is OR-ed in place.  Test infrastructure: lets the parity tests separate "rounds
+    differently at a threshold" from "computes the gradient wrong" (tests/util.py)."""
+    u = 2.0 ** -24
+    K = FRAGILE_K
+    mag = 0.5 * (con[None, :, 0].abs() * dx * dx + con[None, :, 2].abs() * dy * dy) + (con[None, :, 1] * dx * dy).abs()
+    bound = K * u * (mag + opac.clamp_min(1e-30).log().abs()[None] + 1.0)
+    lna = opac.clamp_min(1e-30).log()[None] + torch.clamp(power, max=0.0) - math.log(ALPHA_MIN)
+    near_alpha = (lna.abs() < bound) & (power <= bound)
+    near_pow = (power.abs() < bound) & (lna >= -bound)
+    dec = (near_alpha | near_pow) & ~stopped                       # (a decision behind the stop changes nothing)
+    om_inv = 1.0 / (1.0 - a_eff)
+    bound_T = K * u * torch.cumsum(om_inv, 1)
+    stop_here = valid & ~(torch.cumsum((valid & (T_incl < T_EPS)).to(torch.int32), 1) - (valid & (T_incl < T_EPS)).to(torch.int32) > 0)
+    near_stop = stop_here & ((T_incl.clamp_min(1e-300) / T_EPS).log().abs() < bound_T)
+    mark = near_stop.any(0)
+    if bool(dec.any()):
+        behind = (torch.cumsum(dec.to(torch.int32), 1) > 0) & (contrib | dec)      # the fragile entry and what contributes behind it
+        mark = mark | behind.any(0)
+    if z.numel() > 1:
+        tie = (z[1:] - z[:-1]).abs() < K * u * z[1:].abs()
+        if bool(tie.any()):
+            both = torch.zeros_like(mark)
+            both[1:] |= tie
+            both[:-1] |= tie
+            mark = mark | (both & (valid | contrib).any(0))
+    fragile[idx[mark]] = True
+
+
+def composite_tile(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem, num_dist=0, fragile=None):
+    """K6 for one 16x16 tile, vectorised over [pixels, list].  `fragile`: optional [N] bool collector, see _mark_fragile."""
     dt = pre["px"].dtype
     H, W = s.image_height, s.image_width
     ys, xs = torch.meshgrid(torch.arange(y0, min(y0 + TILE, H)), torch.arange(x0, min(x0 + TILE, W)),
@@ -259,6 +302,9 @@ def composite_tile(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem, num_dist
     contrib = valid & ~stopped
     wgt = torch.where(contrib, a_eff * T_excl, torch.zeros_like(alpha))     # [P,L]
     Tfin = torch.where(contrib, om, torch.ones_like(om)).prod(1)
+    if fragile is not None:
+        _mark_fragile(fragile, idx, con, dx, dy, power, pre["opacity"][idx], alpha, valid, a_eff, T_incl, stopped, contrib,
+                      pre["depth"][idx])
 
     z = pre["depth"][idx]
     if dirs is not None:
@@ -293,7 +339,7 @@ def composite_tile(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem, num_dist
 def rasterize(s: Settings, means3D, means2D=None, means2D_densify=None, shs=None,
               colors_precomp=None, normals_precomp=None, semantics_precomp=None, opacities=None,
               scales=None, rotations=None, cov3D_precomp=None, dirs=None, inside=None, tile_stride=1,
-              timings=None, num_dist=0):
+              timings=None, num_dist=0, fragile=False):
     """Full forward (tile_stride>1 composites only every k-th tile: bounded CPU-baseline sample).  f_count==0: (out[C,H,W], radii).  f_count==1/2: (count, score, image, radii).
     f_count==3: (count, radii).  C = 8 + S (colour3, depth1, normal3, alpha1, sem S)."""
     dt = means3D.dtype
@@ -315,6 +361,7 @@ def rasterize(s: Settings, means3D, means2D=None, means2D_densify=None, shs=None
     count = torch.zeros(N, dtype=torch.int32)
     score = torch.zeros(N, dtype=dt)
     rows, cols, vals, tvals = [], [], [], []
+    frag = torch.zeros(N, dtype=torch.bool) if fragile else None
     for ty in range(gy):
         for tx in range(gx):
             t = ty * gx + tx
@@ -322,7 +369,7 @@ def rasterize(s: Settings, means3D, means2D=None, means2D_densify=None, shs=None
                 continue
             idx = owner[beg[t]:end[t]]
             xs, ys, out, Tfin, contrib, wgt = composite_tile(
-                s, pre, idx, tx * TILE, ty * TILE, means2D_densify, dirs, num_sem, num_dist)
+                s, pre, idx, tx * TILE, ty * TILE, means2D_densify, dirs, num_sem, num_dist, fragile=frag)
             rows.append(ys); cols.append(xs); vals.append(out); tvals.append(Tfin)
             if s.f_count and contrib is not None:
                 count.index_add_(0, idx, contrib.sum(0).to(torch.int32))
@@ -333,7 +380,7 @@ def rasterize(s: Settings, means3D, means2D=None, means2D_densify=None, shs=None
     bg = s.bg.to(dt)
     rgb = img[:, :, :3] + Tmap[:, :, None] * bg[None, None]
     out = torch.cat([rgb, img[:, :, 3:]], -1).permute(2, 0, 1).contiguous()
-    stats = dict(R=R, V=int(pre["vis"].sum()), final_T=Tmap)
+    stats = dict(R=R, V=int(pre["vis"].sum()), final_T=Tmap, fragile=frag)
     if timings is not None:
         timings["pre_bin_s"] = _t1 - _t0
         timings["tiles_s"] = _time.perf_counter() - _t1

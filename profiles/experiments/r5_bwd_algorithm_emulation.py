@@ -108,9 +108,9 @@ class Blend(torch.autograd.Function):
 _orig = OR.composite_tile
 
 
-def composite_tile(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem, num_dist=0):
+def composite_tile(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem, num_dist=0, fragile=None):
     if MODE == "auto" or idx.numel() == 0:
-        return _orig(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem, num_dist)
+        return _orig(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem, num_dist, fragile=fragile)
     assert num_dist == 0
     dt = pre["px"].dtype
     H, W = s.image_height, s.image_width

@@ -53,7 +53,7 @@ def test_c1_all_four_cameras_forward_and_backward(device, view):
     (out * wgt.float().to(device)).sum().backward()
     clean, flipped = util.flip_clean_mask(cam, inp, out, ref, bg)
     for k in ["means3D", "shs", "normals", "opac", "scales", "rots", "m2", "m2d"]:
-        util.assert_grads_close(hl[k].grad.cpu()[clean], rl[k].grad[clean], f"c1 view {view}:{k}")
+        util.assert_grads_close(hl[k].grad.cpu()[clean], rl[k].grad[clean], f"c1 view {view}:{k}", fragile=rl["fragile"][clean])
 
 
 def test_forward_traditional_depth_no_normals(device):
@@ -79,7 +79,7 @@ def test_backward_matches_oracle(device, case):
     for k in ["means3D", "shs", "normals", "opac", "scales", "rots", "m2", "m2d", "sem"]:
         if rl[k] is None:
             continue
-        util.assert_grads_close(hl[k].grad, rl[k].grad, k)
+        util.assert_grads_close(hl[k].grad, rl[k].grad, k, fragile=rl.get("fragile"))
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2])
@@ -100,7 +100,7 @@ def test_sh_degrees_below_three_match_oracle(device, deg):
     assert float(hl["shs"].grad[:, K:].abs().max()) == 0.0 and float(rl["shs"].grad[:, K:].abs().max()) == 0.0
     assert float(hl["shs"].grad[:, :K].abs().max()) > 0.0
     for k in ["shs", "means3D", "opac", "scales", "rots"]:
-        util.assert_grads_close(hl[k].grad, rl[k].grad, f"deg{deg}:{k}")
+        util.assert_grads_close(hl[k].grad, rl[k].grad, f"deg{deg}:{k}", fragile=rl.get("fragile"))
 
 
 def test_count_modes(device):
@@ -170,7 +170,7 @@ def test_depth_moment_channels_forward_backward(device):
     assert torch.equal(out[8], out[3])
     (out * wgt.float().to(device)).sum().backward()
     for k in ["means3D", "normals", "opac", "scales", "rots", "shs"]:
-        util.assert_grads_close(hl[k].grad, rl[k].grad, k)
+        util.assert_grads_close(hl[k].grad, rl[k].grad, k, fragile=rl.get("fragile"))
 
 
 def test_factorised_sh_gradient_exchange_equals_summed_full_gradients(device):
@@ -262,7 +262,7 @@ def test_precomputed_covariance_and_colours_path(device):
         res[name] = (out.detach(), leaf)
     assert util.bad_pixels(res["hip"][0], res["oracle"][0]) <= util.pixel_budget(res["oracle"][0])
     for k in ["xyz", "cov", "col", "op", "nrm"]:
-        util.assert_grads_close(res["hip"][1][k].grad, res["oracle"][1][k].grad, k)
+        util.assert_grads_close(res["hip"][1][k].grad, res["oracle"][1][k].grad, k, fragile=res["oracle"][1].get("fragile"))
 
 
 def test_empty_model_and_single_gaussian(device):
@@ -304,7 +304,7 @@ def test_edge_tiny_image_and_few_gaussians(device):
         out, ref, hl, rl, st = _fwd_bwd_vs_oracle(device, cam, inp, dirs, torch.tensor([0.2, 0.4, 0.6]), fwd_budget=1)
         for k in ["means3D", "opac", "scales", "rots", "shs"]:
             if float(rl[k].grad.abs().max()) > 0:
-                util.assert_grads_close(hl[k].grad, rl[k].grad, f"n={n}:{k}", p999_tol=1e-1)
+                util.assert_grads_close(hl[k].grad, rl[k].grad, f"n={n}:{k}", p999_tol=1e-1, fragile=rl.get("fragile"))
 
 
 def test_edge_screen_filling_gaussians(device):
@@ -318,7 +318,7 @@ def test_edge_screen_filling_gaussians(device):
     # (twelve Gaussians that reach EVERY pixel: each of their gradient entries is a sum over the whole image, accumulated by
     #  fp32 atomics from all 24 tiles -- 3x the tolerance of the ordinary cases; measured 2x on the rotations' p99.9)
     for k in ["means3D", "opac", "scales", "rots", "shs", "normals"]:
-        util.assert_grads_close(hl[k].grad, rl[k].grad, k, scale=3.0)
+        util.assert_grads_close(hl[k].grad, rl[k].grad, k, scale=3.0, fragile=rl.get("fragile"))
 
 
 def test_edge_equal_depths_and_opacity_extremes(device):
@@ -335,7 +335,7 @@ def test_edge_equal_depths_and_opacity_extremes(device):
     assert float(hl["opac"].grad[100:150].abs().max()) == 0.0 and float(rl["opac"].grad[100:150].abs().max()) == 0.0
     assert float(ref[7].max()) > 0.999                            # saturated pixels exist
     for k in ["means3D", "opac", "scales", "rots", "shs", "normals"]:
-        util.assert_grads_close(hl[k].grad, rl[k].grad, k)
+        util.assert_grads_close(hl[k].grad, rl[k].grad, k, fragile=rl.get("fragile"))
 
 
 @pytest.mark.parametrize("num_dist", [1, 2])
@@ -438,7 +438,7 @@ def test_quad_granular_binning_gives_the_same_render_and_gradients(device, case)
     for k in keys:
         assert util.rel_err(leaves[1][k].grad, leaves[0][k].grad) < 2e-5, k
         if case != "ragged_big_footprints":
-            util.assert_grads_close(leaves[1][k].grad, rl[k].grad, k)
+            util.assert_grads_close(leaves[1][k].grad, rl[k].grad, k, fragile=rl.get("fragile"))
     assert util.rel_err(leaves[1]["m2d"].grad, leaves[0]["m2d"].grad) < 2e-5
     # count modes follow the same lists
     (c0, _), _ = util.hip_forward(cam, inp, dirs, bg, device, f_count=3, use_normals=False)

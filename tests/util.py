@@ -33,7 +33,7 @@ def settings_for(cam, bg, cls, sh_degree=3, f_count=0, device=None):
 
 
 def oracle_forward(cam, inp, dirs, bg, dtype=torch.float64, requires_grad=False, sh_degree=3, f_count=0,
-                   use_normals=True, num_dist=0, tile_stride=1):
+                   use_normals=True, num_dist=0, tile_stride=1, fragile=False):
     s = settings_for(cam, bg, OR.Settings, sh_degree=sh_degree, f_count=f_count)
     leaf = {}
     for k, v in inp.items():
@@ -44,9 +44,13 @@ def oracle_forward(cam, inp, dirs, bg, dtype=torch.float64, requires_grad=False,
     N = inp["means3D"].shape[0]
     leaf["m2"] = torch.zeros(N, 3, dtype=dtype, requires_grad=requires_grad)
     leaf["m2d"] = torch.zeros(N, 3, dtype=dtype, requires_grad=requires_grad)
+    fragile = fragile or (dtype == torch.float64 and requires_grad and f_count == 0)    # (every fp64 gradient reference carries it)
     res = OR.rasterize(s, leaf["means3D"], leaf["m2"], leaf["m2d"], leaf["shs"], None,
                        leaf["normals"] if use_normals else None, leaf["sem"], leaf["opac"], leaf["scales"],
-                       leaf["rots"], None, dirs if use_normals else None, num_dist=num_dist, tile_stride=tile_stride)
+                       leaf["rots"], None, dirs if use_normals else None, num_dist=num_dist, tile_stride=tile_stride,
+                       fragile=fragile)
+    if fragile and f_count == 0:
+        leaf["fragile"] = res[2]["fragile"]
     return res, leaf
 
 
@@ -113,34 +117,37 @@ def grad_stats(a, b):
     return dict(maxnorm=rel_err(a, b), med=float(q[0]), p99=float(q[1]), p999=float(q[2]), max=float(e.max()) if e.numel() else 0.0)
 
 
-# Gradient acceptance used by every parity test, PER TENSOR and PER REGIME: (max-norm relative error, element-wise p99,
-# element-wise p99.9; see elem_err) must stay below FACTOR x the error of the ORACLE ITSELF run in fp32 against its fp64 self
-# in the same regime -- tests/golden/grad_yardstick.json, produced on the CPU by profiles/grad_yardstick.py:
-#   "small"  the parity cases (<= 10 000 Gaussians, <= 256 x 256),
-#   "full"   the full-size sampled-tile cases (every pixel sees ~10x more pairs: the yardstick itself is ~6x wider there),
-#   "step"   whole training iterations (the image losses add their own fp32 reductions).
-# i.e. the HIP path may be at most FACTOR times as noisy as a plain fp32 evaluation of the same algorithm.  FACTOR = 3,
-# with these measured exceptions (HIP / yardstick per case: profiles/r4_grad_ratio_table_default.txt, and -- the same figures
-# with every fp32 atomic of the backward issued in ONE fixed order -- profiles/r4_grad_ratio_table_det.txt):
-#   small: 5 for means3D / scales / rots (measured element-wise p99 / p99.9 up to 3.6 / 5.9x).  Round 4 built the
-#          deterministic-order backward to find out what this is made of, and the answer is NOT the order of the atomics:
-#          the deterministic build shows the same quantiles to within a few per cent (tests/test_deterministic_bwd_gpu.py).
-#          It is the backward ALGORITHM of the reference's rasterizer family -- transmittance recovered back to front by
-#          T_i = T_{i+1} / (1 - alpha_i), one division's rounding per list entry, amplified by the Sigma2D -> Sigma3D ->
-#          (s, q) and projection adjoints -- which the autograd oracle (it keeps every T_i from the forward) does not share;
-#   step:  8 on the quantiles: the whole-step scenes use 6x enlarged Gaussians (long per-pixel lists), where that recovery
-#          accumulates most (measured 3 - 6.7x).  The max-norm figure is the error of the single largest entry: there the step
-#          yardstick (5e-6 for the scales) is a lucky draw, and the bound is the small-regime max-norm tolerance of the same
-#          tensor; 12 for the densification statistic (sum over pixels of |dL/dxy|: measured 8.8 - 10.8x);
-#   full:  3 throughout (measured 0.7 - 1.6x).
-# Floors: 2e-5 / 2e-5 / 2e-4 (below that the figure is a handful of fp32 ulps of a sum of ~100 terms).
-# (A pixel whose alpha >= 1/255 or T < 1e-4 decision flips between fp32 and fp64 moves the gradients of the few
-# Gaussians under it discretely -- those are the tolerated 0.1 %.)
+# Gradient acceptance used by every parity test (round 5: rebuilt around FRAGILE DECISIONS).
+#
+# The rasterizer is piecewise smooth: per (pixel, entry) it decides power <= 0, alpha >= 1/255, T' < 1e-4, and per pair of list
+# neighbours the depth order.  Two correct fp32 evaluations that round differently resolve the decisions that sit within
+# rounding distance of their threshold differently, and each such flip moves the gradient of the Gaussians under it by a
+# FINITE amount -- without moving the image beyond the pixel tolerance.  Rounds 1-4 compared all gradients against multiples
+# of "the error of the oracle itself in fp32" and found the HIP path 2-6x noisier on geometry gradients, with exceptions of 5 /
+# 8 / 12 on the factor and a suite that flaked at its tightest entries.  Round 5 took that apart (profiles/r5_*):
+#   * the compositing backward's per-Gaussian sums are as accurate as the fp32 oracle's (r5_grad_stage_errors.txt), and neither
+#     its transmittance recovery nor its atomics matter (anchored / Newton / fp64-recurrence / fp64-accumulation builds:
+#     r5_ratio_*.txt): VERDICT r4's hypothesis is refuted by measurement;
+#   * the excess on scales / rotations / means came from the PROJECTION backward's fp32 adjoint chain -- now fp64;
+#   * what is left, in the HIP path AND in the fp32 oracle, is dominated by flips: leaving out the Gaussians under fragile
+#     decisions drops the fp32 oracle's own max-norm error 10-25x (r5_fragile_emulation.txt).
+# So the fp64 oracle now also reports which Gaussians sit under a fragile decision (oracle/raster_torch.py::_mark_fragile: test
+# quantity within K = 16 unit roundoffs x the magnitude of what an fp32 evaluation rounds), and a comparison has two parts:
+#   STRICT on the non-fragile Gaussians: max-norm relative error < 1e-4 (BASELINE.json's figure), element-wise p99 / p99.9
+#          below 3 x the committed fp32-oracle yardstick of that tensor and regime -- factor 3 EVERYWHERE, no exceptions;
+#   BOUNDED on all of them: a flip is a legitimate difference, not an unbounded one -- max-norm < 3e-3, p99 / p99.9 below
+#          10 x the yardstick.
+# Yardstick: tests/golden/grad_yardstick.json (profiles/grad_yardstick.py; regimes "small" / "full" / "step"), floors
+# 2e-5 / 2e-5 / 2e-4.  A comparison without a fragile mask (quantities that do not come out of the rasterizer's backward)
+# uses the strict p99 / p99.9 figures and the tensor's own max-norm yardstick.
 import json as _json
 
 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "grad_yardstick.json")) as _f:
     _YARDSTICK = _json.load(_f)
-_FACTOR = {"small": {"means3D": (5, 5, 5), "scales": (5, 5, 5), "rots": (5, 5, 5)}, "full": {}, "step": {None: (8, 8, 8), "means2D_densify": (12, 12, 12)}}
+_FACTOR = 3.0                      # everywhere
+_FACTOR_ALL = 10.0                 # quantile bounds with the fragile Gaussians included
+NONFRAGILE_MAXNORM_TOL = 1e-4      # BASELINE.json: "per-parameter gradients within 1e-4 rel"
+ALL_MAXNORM_TOL = 3e-3
 _FLOOR = (2e-5, 2e-5, 2e-4)
 # other names the tests use for the same tensors
 _ALIAS = {"xyz": "means3D", "f_dc": "shs", "f_rest": "shs", "opacity": "opac", "scaling": "scales", "rotation": "rots",
@@ -151,41 +158,58 @@ GRAD_ELEM_P99_TOL = 1e-3
 GRAD_ELEM_P999_TOL = 1e-2
 
 
-def grad_tolerance(name, regime="small"):
-    """-> (max-norm, p99, p99.9) tolerance for the tensor called `name` ("deg2:shs", "xyz", ... resolve to their row)."""
+def grad_tolerance(name, regime="small", factor=_FACTOR):
+    """-> (max-norm, p99, p99.9) tolerance for the tensor called `name` ("deg2:shs", "xyz", ... resolve to their row):
+    `factor` x its yardstick row, floored."""
     key = name.split(":")[-1]
     table = _YARDSTICK[regime]
     if key not in table:
         key = _ALIAS.get(key, key)
     if key not in table:
         return (GRAD_MAXNORM_TOL, GRAD_ELEM_P99_TOL, GRAD_ELEM_P999_TOL)
-    fac = _FACTOR[regime].get(key, _FACTOR[regime].get(None, (3, 3, 3)))
-    tol = [max(f * y, fl) for f, y, fl in zip(fac, table[key], _FLOOR)]
-    if regime == "step":
-        tol[0] = max(tol[0], grad_tolerance(_ALIAS.get(key, key), "small")[0])
-    return tuple(tol)
+    return tuple(max(factor * y, fl) for y, fl in zip(table[key], _FLOOR))
 
 
-def assert_grads_close(got, ref, name, maxnorm_tol=None, p999_tol=None, p99_tol=None, scale=1.0, regime="small"):
-    """`regime`: which yardstick applies; `scale`: documented per-test widening factor on the tensor's own tolerances;
-    explicit *_tol values replace them."""
-    st = grad_stats(got, ref)
+def _report(name, part, st, tols, n):
+    rep = os.environ.get("VCR_GRAD_REPORT")
+    ok = st["maxnorm"] < tols[0] and st["p99"] < tols[1] and st["p999"] < tols[2]
+    if rep:                   # calibration runs: log measured figure vs tolerance for every call instead of stopping at the first
+        with open(rep, "a") as f:
+            f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]} | {name} [{part}] | {'ok' if ok else 'FAIL'} | maxnorm {st['maxnorm']:.2e}/{tols[0]:.1e}"
+                    f" | p99 {st['p99']:.2e}/{tols[1]:.1e} | p999 {st['p999']:.2e}/{tols[2]:.1e} | n {n}\n")
+        return
+    assert st["maxnorm"] < tols[0], f"grad {name} [{part}]: max-norm rel err {st['maxnorm']:.2e} >= {tols[0]:.1e} (stats {st})"
+    assert st["p99"] < tols[1], f"grad {name} [{part}]: element-wise p99 err {st['p99']:.2e} >= {tols[1]:.1e} (stats {st})"
+    assert st["p999"] < tols[2], f"grad {name} [{part}]: element-wise p99.9 err {st['p999']:.2e} >= {tols[2]:.1e} (stats {st})"
+
+
+def assert_grads_close(got, ref, name, maxnorm_tol=None, p999_tol=None, p99_tol=None, scale=1.0, regime="small", fragile=None):
+    """`got` against the fp64 oracle's `ref` (rows = Gaussians).  `fragile`: bool [rows] from the oracle (see the comment block
+    above) -> STRICT comparison on the rest + BOUNDED comparison on everything; without it: one comparison with the strict
+    quantile figures.  `regime`: which yardstick applies; `scale`: documented per-test widening factor; explicit *_tol values
+    replace the strict figures (tests of quantities with their own measured bounds)."""
+    got, ref = torch.as_tensor(got).detach().cpu(), torch.as_tensor(ref).detach().cpu()
     t_max, t_p99, t_p999 = (scale * t for t in grad_tolerance(name, regime))
     if p999_tol is not None and p99_tol is None:
         p99_tol = GRAD_ELEM_P99_TOL * (p999_tol / GRAD_ELEM_P999_TOL)
-    maxnorm_tol = t_max if maxnorm_tol is None else maxnorm_tol
-    p99_tol = t_p99 if p99_tol is None else p99_tol
-    p999_tol = t_p999 if p999_tol is None else p999_tol
-    rep = os.environ.get("VCR_GRAD_REPORT")
-    if rep:               # calibration runs: log measured figure vs tolerance for every call instead of stopping at the first
-        ok = st["maxnorm"] < maxnorm_tol and st["p99"] < p99_tol and st["p999"] < p999_tol
-        with open(rep, "a") as f:
-            f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]} | {name} | {'ok' if ok else 'FAIL'} | maxnorm {st['maxnorm']:.2e}/{maxnorm_tol:.1e}"
-                    f" | p99 {st['p99']:.2e}/{p99_tol:.1e} | p999 {st['p999']:.2e}/{p999_tol:.1e} | n {int(torch.as_tensor(ref).numel())}\n")
+    strict = [t_max if maxnorm_tol is None else maxnorm_tol, t_p99 if p99_tol is None else p99_tol,
+              t_p999 if p999_tol is None else p999_tol]
+    if fragile is None:
+        st = grad_stats(got, ref)
+        _report(name, "all", st, strict, int(ref.numel()))
         return st
-    assert st["maxnorm"] < maxnorm_tol, f"grad {name}: max-norm rel err {st['maxnorm']:.2e} >= {maxnorm_tol:.1e} (stats {st})"
-    assert st["p99"] < p99_tol, f"grad {name}: element-wise p99 err {st['p99']:.2e} >= {p99_tol:.1e} (stats {st})"
-    assert st["p999"] < p999_tol, f"grad {name}: element-wise p99.9 err {st['p999']:.2e} >= {p999_tol:.1e} (stats {st})"
+    fragile = torch.as_tensor(fragile).cpu().bool()
+    assert fragile.shape[0] == ref.shape[0], (fragile.shape, ref.shape)
+    keep = ~fragile
+    st = grad_stats(got[keep], ref[keep])
+    if maxnorm_tol is None:
+        strict[0] = scale * NONFRAGILE_MAXNORM_TOL
+    _report(name, f"non-fragile {int(keep.sum())}/{keep.numel()}", st, strict, int(ref[keep].numel()))
+    st_all = grad_stats(got, ref)
+    loose = [scale * t for t in grad_tolerance(name, regime, _FACTOR_ALL)]
+    loose[0] = max(scale * ALL_MAXNORM_TOL, strict[0])
+    loose[1], loose[2] = max(loose[1], strict[1]), max(loose[2], strict[2])
+    _report(name, "all", st_all, loose, int(ref.numel()))
     return st
 
 
@@ -268,24 +292,28 @@ def sampled_tile_parity(device, cam, inp, dirs, bg, stride, min_inst, name, min_
     (ref * wgt).sum().backward()
     (out * wgt.float().to(device)).sum().backward()
 
+    fr = rl.get("fragile")
+    fr = torch.zeros(int(hit.sum()), dtype=torch.bool) if fr is None else fr
+
     def tol(k, a, b):
-        """own yardstick: every figure of the tensor's tolerance becomes max(table, 3 x the fp32 oracle's own error on this
-        subset) -- max-norm AND the element-wise quantiles (round 4 widened the max-norm only, and the trained scene's p99.9
-        sat within 4 % of a tolerance measured on synthetic blobs)"""
-        t = grad_tolerance(k, "full")
+        """own yardstick (scenes the tabulated "full" yardstick was not measured on): every STRICT figure of the tensor becomes
+        max(default, 3 x the fp32 oracle's own error on the same non-fragile rows)."""
         if l32 is None:
-            return dict(maxnorm_tol=t[0], p99_tol=t[1], p999_tol=t[2])
+            return {}
+        t = grad_tolerance(k, "full")
         own = grad_stats(a, b)
-        return dict(maxnorm_tol=max(t[0], 3.0 * own["maxnorm"]), p99_tol=max(t[1], 3.0 * own["p99"]),
+        return dict(maxnorm_tol=max(NONFRAGILE_MAXNORM_TOL, 3.0 * own["maxnorm"]), p99_tol=max(t[1], 3.0 * own["p99"]),
                     p999_tol=max(t[2], 3.0 * own["p999"]))
 
+    nf = clean & ~fr
     for k in ["means3D", "shs", "normals", "opac", "scales", "rots", "m2", "sem"]:
         if rl.get(k) is None or hl[k] is None:
             continue
         gfull = hl[k].grad.cpu()
         assert float(gfull[~hit].abs().max()) == 0.0 if (~hit).any() else True, f"{k}: gradient outside the sampled subset"
-        assert_grads_close(gfull[hit][clean], rl[k].grad[clean], f"{name}:{k}", regime="full",
-                           **tol(k, l32[k].grad[clean] if l32 is not None else None, rl[k].grad[clean]))
+        assert_grads_close(gfull[hit][clean], rl[k].grad[clean], f"{name}:{k}", regime="full", fragile=fr[clean],
+                           **tol(k, l32[k].grad[nf] if l32 is not None else None, rl[k].grad[nf]))
     assert_grads_close(hl["m2d"].grad.cpu()[hit][clean][:, :2], rl["m2d"].grad[clean][:, :2], f"{name}:m2d", regime="full",
-                       **tol("m2d", l32["m2d"].grad[clean][:, :2] if l32 is not None else None, rl["m2d"].grad[clean][:, :2]))
-    return dict(instances=inst, flipped=bad, sampled_pixels=int(o.shape[1]), subset=int(hit.sum()))
+                       fragile=fr[clean],
+                       **tol("m2d", l32["m2d"].grad[nf][:, :2] if l32 is not None else None, rl["m2d"].grad[nf][:, :2]))
+    return dict(instances=inst, flipped=bad, sampled_pixels=int(o.shape[1]), subset=int(hit.sum()), fragile=int(fr.sum()))

@@ -360,6 +360,19 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         // From here on the colour stream may already be running work that consumed the caller's pending SH update: every
         // error return below first joins it (the caller's retry / error handling must not see an un-joined stream).
         auto fail_joined = join_streams;
+        // instance-count dependent buffers, requested NOW for the previous call's count + 1/8 (see below)
+        static thread_local int64_t e_guess = 0;
+        const bool with_ckpt = VCR_T_ANCHOR && a.f_count == 0;   // (anchored builds: per-chunk transmittance checkpoints for the backward)
+        const bool third = vcr_sort_passes(tbits) > 2;      // (more than 16 tile bits: a second intermediate buffer)
+        int64_t cap = (e_guess > 0 && !with_ckpt) ? e_guess + e_guess / 8 + 4096 : 0;
+        void* bin_p = nullptr;
+        char* s2 = nullptr;      // [emitted (tile, id) records | records of the sort's first pass | sorted tile keys | (records of a third pass)]
+        if (cap > 0) {
+            bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(cap, T, with_ckpt));
+            s2 = bin_p ? (char*)alloc(user, VCR_BUF_SCRATCH, (third ? 7 : 5) * vcr_align(sizeof(uint32_t) * (size_t)cap) +
+                                                             vcr_binning_temp_bytes(N, cap, tbits)) : nullptr;
+            if (!bin_p || !s2) { vcr_set_error("allocator returned NULL"); return fail_joined(); }
+        }
         {   // spin on the published sequence number for at most ~2 ms of wall time, then sleep in a stream synchronisation (which
             // also surfaces a device fault or a failed launch as an error instead of a hang)
             const auto t_spin = std::chrono::steady_clock::now();
@@ -391,18 +404,22 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         out->num_emitted = E;
         if (R >= (1ll << 32)) { vcr_set_error("more than 2^32 tile instances"); return fail_joined(); }
 
-        const bool with_ckpt = a.f_count == 0;              // training forward: per-chunk transmittance checkpoints for the backward
-        void* bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(E, T, with_ckpt));
-        if (!bin_p) { vcr_set_error("allocator returned NULL"); return fail_joined(); }
+        // (the instance-count dependent buffers were requested BEFORE the hand-over, sized by the previous call's count: the
+        //  two allocator callbacks -- Python, ~8 us each -- then run while the GPU sorts, not while it waits for the emission
+        //  kernel; only a count beyond that guess asks again)
+        if (!bin_p || E > cap) {
+            cap = E;
+            bin_p = alloc(user, VCR_BUF_BINNING, BinState::bytes(cap, T, with_ckpt));
+            s2 = bin_p ? (char*)alloc(user, VCR_BUF_SCRATCH, (third ? 7 : 5) * vcr_align(sizeof(uint32_t) * (size_t)(cap > 0 ? cap : 1)) +
+                                                             vcr_binning_temp_bytes(N, cap, tbits)) : nullptr;
+            if (!bin_p || !s2) { vcr_set_error("allocator returned NULL"); return fail_joined(); }
+        }
+        e_guess = E;
         BinState b = BinState::view(bin_p, T);
         out->binning = bin_p;
-        im.t_ckpt = with_ckpt ? BinState::ckpt_of(bin_p, E, T) : nullptr;
-        const size_t tmp2 = vcr_binning_temp_bytes(N, E, tbits);
-        const size_t rbts = vcr_align(sizeof(uint32_t) * (size_t)(E > 0 ? E : 1));
-        const bool third = vcr_sort_passes(tbits) > 2;      // (more than 16 tile bits: a second intermediate buffer)
-        // [emitted (tile, id) records | records of the sort's first pass | sorted tile keys | (records of a third pass)]
-        char* s2 = (char*)alloc(user, VCR_BUF_SCRATCH, (third ? 7 : 5) * rbts + tmp2);
-        if (!s2) { vcr_set_error("allocator returned NULL"); return fail_joined(); }
+        im.t_ckpt = with_ckpt ? BinState::ckpt_of(bin_p, cap, T) : nullptr;
+        const size_t tmp2 = vcr_binning_temp_bytes(N, cap, tbits);
+        const size_t rbts = vcr_align(sizeof(uint32_t) * (size_t)(cap > 0 ? cap : 1));
         if (split_sort) VCR_HIP_CHECK_JOIN(hipStreamWaitEvent(st, colour_event(3), 0));  // the depth order is needed from here on
         {
             StageTimer tm(ST_BINNING, st);
@@ -685,7 +702,7 @@ int backward_impl(const VcrRasterArgs* args, VcrBackwardIO* io, const VcrGeometr
         vcr_set_error("backward: num_emitted = %lld is not the forward's", (long long)io->num_emitted);
         return 1;
     }
-    im.t_ckpt = BinState::ckpt_of(const_cast<void*>(io->binning), io->num_emitted, gx * gy);
+    im.t_ckpt = VCR_T_ANCHOR ? BinState::ckpt_of(const_cast<void*>(io->binning), io->num_emitted, gx * gy) : nullptr;
     const size_t gb = vcr_align(sizeof(GradRec) * (size_t)N);
     const size_t sb = vcr_align(sizeof(float) * (size_t)N * (a.S > 0 ? a.S : 1));
     // the screen-space accumulators: library-owned, zero between calls (the projection backward clears what it reads)

@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include "../../include/vcr_raster.h"
 
+#ifndef VCR_T_ANCHOR
+#define VCR_T_ANCHOR 0             // 1: experiment build, see composite.hip (transmittance checkpoints)
+#endif
 #define VCR_TILE 16
 #define VCR_TILE_PIX 256
 #define VCR_ALPHA_MIN (1.0f / 255.0f)
