@@ -71,7 +71,8 @@ def render(raw, cam, cfg, extent, bg, dirs, sh_degree, num_dist=0):
     m2d = torch.zeros(N, 3, dtype=dt, requires_grad=True)
     sem = raw["obj_dc"].squeeze(1) if "obj_dc" in raw and cfg.optim.loss_weight.semantic > 0 else None
     out, radii, st = OR.rasterize(s, act["xyz"], m2, m2d, act["shs"], None, ncam, sem, act["opacity"], act["scaling"],
-                                  act["rotation"], None, None if dirs is None else dirs.cpu(), num_dist=num_dist)
+                                  act["rotation"], None, None if dirs is None else dirs.cpu(), num_dist=num_dist,
+                                  fragile=dt == torch.float64)      # (the fp64 reference also reports its fragile decisions)
     image, depth, normal, alpha = out[:8].split([3, 1, 3, 1], dim=0)
     with torch.no_grad():
         mask = cam.mask.cpu().bool() if hasattr(cam, "mask") else torch.ones_like(depth, dtype=torch.bool).squeeze(0)
