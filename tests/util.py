@@ -139,7 +139,7 @@ def grad_stats(a, b):
 #          comparisons of the suite, worst 1.93e-4, see NONFRAGILE_MAXNORM_TOL), element-wise p99 / p99.9
 #          below 3 x the committed fp32-oracle yardstick of that tensor and regime -- factor 3 EVERYWHERE, no exceptions;
 #   BOUNDED on all of them: a flip is a legitimate difference, not an unbounded one -- max-norm < 3e-3, p99 / p99.9 below
-#          10 x the yardstick.
+#          max(10 x the yardstick, 1e-3 / 1e-2).
 # Yardstick: tests/golden/grad_yardstick.json (profiles/grad_yardstick.py; regimes "small" / "full" / "step"), floors
 # 2e-5 / 2e-5 / 2e-4.  A comparison without a fragile mask (quantities that do not come out of the rasterizer's backward)
 # uses the strict p99 / p99.9 figures and the tensor's own max-norm yardstick.
@@ -213,7 +213,7 @@ def assert_grads_close(got, ref, name, maxnorm_tol=None, p999_tol=None, p99_tol=
     st_all = grad_stats(got, ref)
     loose = [scale * t for t in grad_tolerance(name, regime, _FACTOR_ALL)]
     loose[0] = max(scale * ALL_MAXNORM_TOL, strict[0])
-    loose[1], loose[2] = max(loose[1], strict[1]), max(loose[2], strict[2])
+    loose[1], loose[2] = max(loose[1], strict[1], scale * GRAD_ELEM_P99_TOL), max(loose[2], strict[2], scale * GRAD_ELEM_P999_TOL)
     _report(name, "all", st_all, loose, int(ref.numel()))
     return st
 

@@ -84,28 +84,39 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
     uint32_t agg = 0;
 #pragma unroll
     for (int r = 0; r < DUP_ROUNDS; ++r) agg += s_wtot[r][0] + s_wtot[r][1] + s_wtot[r][2] + s_wtot[r][3];
-    if (wv == 0) {                                       // decoupled look-back by the first wave
+    // Decoupled look-back by the WHOLE block, 256 predecessors per step (round 5; was the first wave, 64 per step: with ~1000
+    // blocks in flight at once the last ones walked 15 dependent steps of agent-scope loads).
+    __shared__ unsigned long long s_pm[4];
+    __shared__ uint32_t s_part[4];
+    {
         uint32_t excl = 0;
-        if (bid > 0) {
-            if (lane == 0) __hip_atomic_store(status + bid, tag | ST_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bid > 0) {                                     // (block-uniform)
+            if (threadIdx.x == 0) __hip_atomic_store(status + bid, tag | ST_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int look = bid - 1;
             for (;;) {
-                const int b = look - lane;
+                const int b = look - (int)threadIdx.x;
                 unsigned long long sv = ST_PREFIX;        // lanes past block 0 count as a zero prefix
                 if (b >= 0) {
                     do { sv = __hip_atomic_load(status + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     while ((sv >> 34) != (unsigned long long)seq || ((sv >> 32) & 3ull) == 0);
                 }
                 const unsigned long long pm = __builtin_amdgcn_ballot_w64(((sv >> 32) & 3ull) == 2);
-                const int first = pm ? __builtin_ctzll(pm) : 64;                 // nearest block with a full prefix
-                uint32_t v = lane <= first ? (uint32_t)sv : 0u;
+                if (lane == 0) s_pm[wv] = pm;
+                __syncthreads();
+                int first = 256;                          // nearest block (smallest distance) that published a full prefix
+#pragma unroll
+                for (int w = 3; w >= 0; --w) if (s_pm[w]) first = 64 * w + __builtin_ctzll(s_pm[w]);
+                uint32_t v = (int)threadIdx.x <= first ? (uint32_t)sv : 0u;
                 for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-                excl += v;
-                if (pm) break;
-                look -= 64;
+                if (lane == 0) s_part[wv] = v;
+                __syncthreads();
+                excl += s_part[0] + s_part[1] + s_part[2] + s_part[3];
+                if (first < 256) break;
+                look -= 256;
+                __syncthreads();                           // (s_pm / s_part are rewritten by the next step)
             }
         }
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
             __hip_atomic_store(status + bid, tag | ST_PREFIX | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_prefix = excl;
         }

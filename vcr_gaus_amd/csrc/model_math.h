@@ -46,40 +46,46 @@ __device__ __forceinline__ ActOut activate_one(const float l[3], float4 qr, floa
 
 // adjoint of activate_one: gradients w.r.t. the raw scaling (gs), rotation (gq), opacity (go).  `has_*`: which upstream
 // gradients exist; ds / dq / dop / dn: upstream gradients; extra: second gradient path into the raw scaling (l1_scale).
+// Arithmetic in fp64 (round 5, like the projection backward in front of it: the quaternion adjoints project out the component
+// along q twice -- differences of nearly equal products -- and one lane does this once per Gaussian beside ~350 B of traffic).
 __device__ __forceinline__ void activate_bwd_one(const float l[3], float4 qr, float oraw, const float* __restrict__ Rw2c, uint8_t aux,
                                                  bool has_s, const float ds[3], bool has_q, float4 dq, bool has_o, float dop,
                                                  bool has_n, const float dn[3], const float extra[3], float gs[3], float4& gq,
                                                  float& go, bool n_world = false) {
+    typedef double D;
 #pragma unroll
     for (int k = 0; k < 3; ++k) gs[k] = (has_s ? ds[k] * expf(l[k]) : 0.f) + extra[k];
     const float o = 1.f / (1.f + expf(-oraw));
     go = has_o ? dop * o * (1.f - o) : 0.f;
-    const float inv = 1.f / fmaxf(sqrtf(qr.x * qr.x + qr.y * qr.y + qr.z * qr.z + qr.w * qr.w), 1e-12f);
-    const float r = qr.x * inv, x = qr.y * inv, y = qr.z * inv, z = qr.w * inv;
-    float g[4] = {0.f, 0.f, 0.f, 0.f};                 // gradient w.r.t. the unit quaternion
+    const D qx = qr.x, qy = qr.y, qz = qr.z, qw = qr.w;
+    const D nrm = sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+    const D inv = 1.0 / (nrm > 1e-12 ? nrm : 1e-12);
+    const D r = qx * inv, x = qy * inv, y = qz * inv, z = qw * inv;
+    D g[4] = {0, 0, 0, 0};                             // gradient w.r.t. the unit quaternion
     if (has_q) { g[0] = dq.x; g[1] = dq.y; g[2] = dq.z; g[3] = dq.w; }
     if (has_n) {
         const int axis = aux & 3;
-        const float sgn = (aux & 4) ? -1.f : 1.f;
-        const float c0 = dn[0], c1 = dn[1], c2 = dn[2];
+        const D sgn = (aux & 4) ? -1.0 : 1.0;
+        const D c0 = dn[0], c1 = dn[1], c2 = dn[2];
         // n_cam = Rw2c * (sgn * R[:,axis]); n_world: `dn` already is the gradient w.r.t. R[:,axis] (summed over the ranks' views)
-        const float w0 = n_world ? c0 : sgn * (Rw2c[0] * c0 + Rw2c[3] * c1 + Rw2c[6] * c2);
-        const float w1 = n_world ? c1 : sgn * (Rw2c[1] * c0 + Rw2c[4] * c1 + Rw2c[7] * c2);
-        const float w2 = n_world ? c2 : sgn * (Rw2c[2] * c0 + Rw2c[5] * c1 + Rw2c[8] * c2);
-        float dR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const D w0 = n_world ? c0 : sgn * ((D)Rw2c[0] * c0 + (D)Rw2c[3] * c1 + (D)Rw2c[6] * c2);
+        const D w1 = n_world ? c1 : sgn * ((D)Rw2c[1] * c0 + (D)Rw2c[4] * c1 + (D)Rw2c[7] * c2);
+        const D w2 = n_world ? c2 : sgn * ((D)Rw2c[2] * c0 + (D)Rw2c[5] * c1 + (D)Rw2c[8] * c2);
+        D dR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         dR[axis] = w0; dR[3 + axis] = w1; dR[6 + axis] = w2;
-        float h[4];
-        h[0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
-        h[1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
-        h[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
-        h[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+        D h[4];
+        h[0] = 2.0 * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+        h[1] = 2.0 * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0 * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0 * x * dR[8]);
+        h[2] = 2.0 * (-2.0 * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0 * y * dR[8]);
+        h[3] = 2.0 * (-2.0 * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0 * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
         // build_rotation re-normalises its (already unit) input: project onto the tangent space
-        const float hd = h[0] * r + h[1] * x + h[2] * y + h[3] * z;
+        const D hd = h[0] * r + h[1] * x + h[2] * y + h[3] * z;
         g[0] += h[0] - r * hd; g[1] += h[1] - x * hd; g[2] += h[2] - y * hd; g[3] += h[3] - z * hd;
     }
     // q = raw/|raw|
-    const float gd = g[0] * r + g[1] * x + g[2] * y + g[3] * z;
-    gq = make_float4((g[0] - r * gd) * inv, (g[1] - x * gd) * inv, (g[2] - y * gd) * inv, (g[3] - z * gd) * inv);
+    const D gd = g[0] * r + g[1] * x + g[2] * y + g[3] * z;
+    gq = make_float4((float)((g[0] - r * gd) * inv), (float)((g[1] - x * gd) * inv), (float)((g[2] - y * gd) * inv),
+                     (float)((g[3] - z * gd) * inv));
 }
 
 // one Adam update (torch.optim.Adam, eps outside the bias-corrected root): step = lr / bc1
