@@ -141,7 +141,7 @@ def grad_stats(a, b):
 #   BOUNDED on all of them: a flip is a legitimate difference, not an unbounded one -- max-norm < 3e-3, p99 / p99.9 below
 #          max(10 x the yardstick, 1e-3 / 1e-2).
 # Yardstick: tests/golden/grad_yardstick.json (profiles/grad_yardstick.py; regimes "small" / "full" / "step"), floors
-# 2e-5 / 2e-5 / 2e-4.  A comparison without a fragile mask (quantities that do not come out of the rasterizer's backward)
+# 2e-5 / 2e-5 / 3e-3.  A comparison without a fragile mask (quantities that do not come out of the rasterizer's backward)
 # uses the strict p99 / p99.9 figures and the tensor's own max-norm yardstick.
 import json as _json
 
@@ -153,7 +153,9 @@ NONFRAGILE_MAXNORM_TOL = 3e-4      # BASELINE.json asks for 1e-4 rel: measured o
                                    # r5_grad_report_calibration.txt) 146 are below 1e-4, the worst is 1.93e-4 (a normals gradient at 1 M /
                                    # 1080p); 3e-4 is that worst case with its run-to-run spread, not a target
 ALL_MAXNORM_TOL = 3e-3
-_FLOOR = (2e-5, 2e-5, 2e-4)
+_FLOOR = (2e-5, 2e-5, 3e-3)        # p99.9 of a 3 000 - 9 000-element tensor is its 3rd - 9th worst element: an order statistic whose
+                                   # run-to-run spread is a factor ~2 (profiles/r5_grad_report_*.txt); 3 x ONE draw of it from the fp32
+                                   # oracle is not a bound, 0.3 % of the element's own magnitude is
 # other names the tests use for the same tensors
 _ALIAS = {"xyz": "means3D", "f_dc": "shs", "f_rest": "shs", "opacity": "opac", "scaling": "scales", "rotation": "rots",
           "means2D_densify": "m2d", "means2D": "m2", "obj_dc": "sem", "col": "shs", "cov": "scales", "op": "opac", "nrm": "normals"}

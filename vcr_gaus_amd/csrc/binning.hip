@@ -18,18 +18,17 @@ namespace {
 
 constexpr unsigned long long ST_AGG = 1ull << 32, ST_PREFIX = 2ull << 32;
 constexpr int DUP_ROUNDS = 4;                       // Gaussians per thread: 1024 per block keeps the look-back chain short
-constexpr int DUP_STAGE = 4096;                     // instances a block stages in LDS before it writes them out (32 KB)
 
 // Tile-instance emission with the offsets scan fused in.  A block takes 1024 Gaussians of the depth order (4 rounds of
 // 256), scans their instance counts (popcount of the tile mask, or width x height for the few rectangles without one),
 // obtains the number of instances before it by decoupled look-back over the status words of the earlier blocks (flag |
 // running total in ONE 64-bit word, so no data has to be ordered against the flag; the logical block order comes from an
 // atomic ticket, so forward progress does not depend on the dispatch order of the workgroups), and emits:
-//   * round 5: the instances of a block form ONE contiguous piece of the output ([prefix, prefix + total)), but a lane's own
-//     instances start wherever its scan position says -- 8-byte stores at 64 unrelated addresses per instruction (measured
-//     78 us for 2 M instances, 16 MB).  A block whose piece fits (<= 4096 instances, nearly all) now assembles it in LDS and
-//     writes it out as full lines; larger pieces keep the direct stores;
-//   * masked rectangles (<= 32 tiles, nearly all): every lane walks the set bits of ITS mask -- a handful of iterations;
+//   * masked rectangles (<= 32 tiles, nearly all): every lane walks the set bits of ITS mask -- a handful of iterations
+//     (round 5 measured two variants of this kernel -- the block's piece of the output assembled in LDS and written as full
+//     lines, and the look-back by the whole block, 256 predecessors per step -- at 80.7 and 82.8 us against 78.4-80.7 us for
+//     this form at 1 M Gaussians: neither the scattered 8-byte stores nor the look-back chain is what the kernel waits for;
+//     profiles/experiments/r5_emission_lds_staging_and_wide_lookback.patch);
 //   * unmasked giants: wave-cooperatively and load-balanced -- the wave's giant counts are prefix-summed in LDS and every
 //     lane binary-searches the Gaussian its slot belongs to, so a screen-filling Gaussian does not serialise a lane.
 // `status`: one 64-bit word per block, [call number `seq`: 30 bits | flag: 2 | value: 32] -- the buffer is library-owned and is
@@ -44,7 +43,6 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
     __shared__ uint32_t s_gend[4][64], s_start[4][64], s_id[4][64];
     __shared__ int s_xmin[4][64], s_ymin[4][64], s_w[4][64];
     __shared__ uint32_t s_wtot[DUP_ROUNDS][4], s_prefix, s_bid;
-    __shared__ uint2 s_out[DUP_STAGE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int gx = gx_keys;                             // keys per row: tiles, or 8x8 cells in quad-list mode (rect is in the same unit)
     for (int t = blockIdx.x * 256 + threadIdx.x; t < num_tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);   // empty tiles
@@ -84,48 +82,33 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
     uint32_t agg = 0;
 #pragma unroll
     for (int r = 0; r < DUP_ROUNDS; ++r) agg += s_wtot[r][0] + s_wtot[r][1] + s_wtot[r][2] + s_wtot[r][3];
-    // Decoupled look-back by the WHOLE block, 256 predecessors per step (round 5; was the first wave, 64 per step: with ~1000
-    // blocks in flight at once the last ones walked 15 dependent steps of agent-scope loads).
-    __shared__ unsigned long long s_pm[4];
-    __shared__ uint32_t s_part[4];
-    {
+    if (wv == 0) {                                       // decoupled look-back by the first wave
         uint32_t excl = 0;
-        if (bid > 0) {                                     // (block-uniform)
-            if (threadIdx.x == 0) __hip_atomic_store(status + bid, tag | ST_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bid > 0) {
+            if (lane == 0) __hip_atomic_store(status + bid, tag | ST_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int look = bid - 1;
             for (;;) {
-                const int b = look - (int)threadIdx.x;
+                const int b = look - lane;
                 unsigned long long sv = ST_PREFIX;        // lanes past block 0 count as a zero prefix
                 if (b >= 0) {
                     do { sv = __hip_atomic_load(status + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     while ((sv >> 34) != (unsigned long long)seq || ((sv >> 32) & 3ull) == 0);
                 }
                 const unsigned long long pm = __builtin_amdgcn_ballot_w64(((sv >> 32) & 3ull) == 2);
-                if (lane == 0) s_pm[wv] = pm;
-                __syncthreads();
-                int first = 256;                          // nearest block (smallest distance) that published a full prefix
-#pragma unroll
-                for (int w = 3; w >= 0; --w) if (s_pm[w]) first = 64 * w + __builtin_ctzll(s_pm[w]);
-                uint32_t v = (int)threadIdx.x <= first ? (uint32_t)sv : 0u;
+                const int first = pm ? __builtin_ctzll(pm) : 64;                 // nearest block with a full prefix
+                uint32_t v = lane <= first ? (uint32_t)sv : 0u;
                 for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-                if (lane == 0) s_part[wv] = v;
-                __syncthreads();
-                excl += s_part[0] + s_part[1] + s_part[2] + s_part[3];
-                if (first < 256) break;
-                look -= 256;
-                __syncthreads();                           // (s_pm / s_part are rewritten by the next step)
+                excl += v;
+                if (pm) break;
+                look -= 64;
             }
         }
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             __hip_atomic_store(status + bid, tag | ST_PREFIX | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_prefix = excl;
         }
     }
     __syncthreads();
-    const uint32_t block_base = s_prefix;
-    const bool staged = agg <= (uint32_t)DUP_STAGE;      // (block-uniform: `agg` is the block's total)
-    // `put`: one (key, id) record at output position `at` -- into the block's LDS piece, or straight to memory
-#define VCR_DUP_PUT(AT, REC) do { if (staged) s_out[(AT) - block_base] = (REC); else inst_out[(AT)] = (REC); } while (0)
     uint32_t round_base = s_prefix;
 #pragma unroll
     for (int r = 0; r < DUP_ROUNDS; ++r) {
@@ -143,7 +126,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
                 while (m) {
                     const int k = __builtin_ctzll(m);
                     m &= m - 1;
-                    VCR_DUP_PUT(at, make_uint2((uint32_t)((ymin + k / w) * gx + xmin + k % w), id[r]));      // (cell, Gaussian)
+                    inst_out[at] = make_uint2((uint32_t)((ymin + k / w) * gx + xmin + k % w), id[r]);      // (cell, Gaussian)
                     ++at;
                 }
             } else {
@@ -151,7 +134,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
                 while (m) {
                     const int k = __builtin_ctz(m);
                     m &= m - 1;
-                    VCR_DUP_PUT(at, make_uint2((uint32_t)((ymin + k / w) * gx + xmin + k % w), id[r]));      // (tile, Gaussian)
+                    inst_out[at] = make_uint2((uint32_t)((ymin + k / w) * gx + xmin + k % w), id[r]);      // (tile, Gaussian)
                     ++at;
                 }
             }
@@ -180,13 +163,8 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
             const int ty = s_ymin[wv][lo] + (int)(local / (uint32_t)ww);
             const int tx = s_xmin[wv][lo] + (int)(local % (uint32_t)ww);
             const uint32_t target = s_start[wv][lo] + local;
-            VCR_DUP_PUT(target, make_uint2((uint32_t)(ty * gx + tx), s_id[wv][lo]));
+            inst_out[target] = make_uint2((uint32_t)(ty * gx + tx), s_id[wv][lo]);
         }
-    }
-#undef VCR_DUP_PUT
-    if (staged) {                                          // the block's piece, written as consecutive 8-byte records
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < agg; k += 256) inst_out[block_base + k] = s_out[k];
     }
 }
 
