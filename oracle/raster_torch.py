@@ -267,6 +267,37 @@ def _mark_fragile(fragile, idx, con, dx, dy, power, opac, alpha, valid, a_eff, T
     fragile[idx[mark]] = True
 
 
+@torch.no_grad()
+def _fragile_footprint(s, pre):
+    """Per-Gaussian decisions of the projection that an fp32 evaluation may round the other way: the radius ceil(3 sqrt(lambda))
+    and the four floor()s of the tile rectangle.  A rectangle that differs by one tile changes which pixels the Gaussian is
+    rendered at (it is composited wherever alpha >= 1/255 INSIDE its rectangle), a discrete difference like the ones of
+    _mark_fragile.  -> bool [N]."""
+    u, K = 2.0 ** -24, FRAGILE_K
+    H, W = s.image_height, s.image_width
+    r = pre["radii"].to(pre["px"].dtype)
+    px, py = pre["px"].detach(), pre["py"].detach()
+    vis = pre["vis"]
+    out = torch.zeros_like(vis)
+    # 3 sqrt(lambda) within rounding distance of an integer (the stored radius is its ceil): recompute lambda's root from the conic
+    con = pre["conic"].detach()
+    det_c = con[:, 0] * con[:, 2] - con[:, 1] * con[:, 1]                      # det(conic) = 1 / det(cov2D)
+    ok = det_c > 0
+    a, c = con[:, 2] / det_c.clamp_min(1e-300), con[:, 0] / det_c.clamp_min(1e-300)   # cov2D diagonal
+    b = -con[:, 1] / det_c.clamp_min(1e-300)
+    mid = 0.5 * (a + c)
+    lam = mid + torch.sqrt(torch.clamp(mid * mid - (a * c - b * b), min=0.1))
+    q = 3.0 * torch.sqrt(lam.clamp_min(0))
+    # (the fp32 error of lambda is amplified by the cancellation in a c - b^2 for needle-shaped footprints: scale the bound by it)
+    amp = ((a * c).abs() + b * b) / (a * c - b * b).abs().clamp_min(1e-300)
+    out |= ok & ((q - torch.round(q)).abs() < K * u * q * amp.clamp(1.0, 1e6))
+    for centre, lim in ((px, W), (py, H)):
+        for qq in ((centre - r) / TILE, (centre + r + TILE - 1) / TILE):
+            inside = (qq > -1) & (qq < (lim + TILE - 1) // TILE + 1)               # (clamped away otherwise: no decision)
+            out |= inside & ((qq - torch.round(qq)).abs() < K * u * (centre.abs() + r + TILE) / TILE)
+    return out & vis
+
+
 def composite_tile(s, pre, idx, x0, y0, means2D_densify, dirs, num_sem, num_dist=0, fragile=None):
     """K6 for one 16x16 tile, vectorised over [pixels, list].  `fragile`: optional [N] bool collector, see _mark_fragile."""
     dt = pre["px"].dtype
@@ -362,6 +393,8 @@ def rasterize(s: Settings, means3D, means2D=None, means2D_densify=None, shs=None
     score = torch.zeros(N, dtype=dt)
     rows, cols, vals, tvals = [], [], [], []
     frag = torch.zeros(N, dtype=torch.bool) if fragile else None
+    if fragile:
+        frag |= _fragile_footprint(s, pre)
     for ty in range(gy):
         for tx in range(gx):
             t = ty * gx + tx
