@@ -191,8 +191,8 @@ def valu_block(R, ms_fwd, workload):
 
 
 def pmc_traffic(kernel="composite_fwd_v2_kernel"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r1_pmc_fetch.csv, r1_pmc_write.csv; separate --pmc runs of THIS command on the metric workload).
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes
+    (profiles/r<N>_pmc_fetch.csv, r<N>_pmc_write.csv; separate --pmc runs of THIS command on the metric workload).
     FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane loads, hence
     the x2 the MI355X guide prescribes (uncalibrated for this gather pattern)."""
     import csv
