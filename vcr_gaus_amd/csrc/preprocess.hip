@@ -512,6 +512,9 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
     // (scale, quaternion) and the Jacobian's dependence on the mean are sums of products that cancel for flat / needle-shaped
     // Gaussians.  One lane handles one Gaussian and the kernel streams ~300 B for it: ~400 fp64 operations per Gaussian are
     // free next to that (VCR_BWD_REAL=float: the round-1-4 arithmetic, for the A/B).
+#ifndef VCR_BWD_MIXED
+#define VCR_BWD_MIXED 0            // 1 (with VCR_BWD_REAL=float): experiment, fp64 only up to the conic adjoint (see below)
+#endif
 #ifndef VCR_BWD_REAL
 #define VCR_BWD_REAL double
 #endif
@@ -542,6 +545,57 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
             for (int k = 0; k < a.S; ++k) { dsem[k] = sgrad_sem[(size_t)i * a.S + k]; sgrad_sem[(size_t)i * a.S + k] = 0.f; }
         }
         gr.finish(a.opacities[i]);
+#if VCR_BWD_MIXED
+        // Experiment build (round 5, unmeasured against the suite): fp64 only for what cancels -- Sigma3D, M = J W, Sigma2D, its
+        // determinant and the conic adjoint (ga, gb, gc) -- and the chain behind them in fp32 again (BR = float in this build).
+        float gaf, gbf, gcf;
+        {
+            typedef double DD;
+            const DD pd[3] = {(DD)a.means3D[i3], (DD)a.means3D[i3 + 1], (DD)a.means3D[i3 + 2]};
+            ProjT<DD> prd;
+            project<DD>(a, cam, pd, prd);
+            DD Sd[6], Rd[9], sd[3];
+            load_cov3d<DD>(a, i, Sd, Rd, sd);
+            jacobian_rows<DD>(a, cam, prd);
+            DD SMd0[3], SMd1[3];
+            sym_mul<DD>(Sd, prd.M0, SMd0);
+            sym_mul<DD>(Sd, prd.M1, SMd1);
+            const DD cad = prd.M0[0] * SMd0[0] + prd.M0[1] * SMd0[1] + prd.M0[2] * SMd0[2] + (DD)VCR_LOWPASS;
+            const DD cbd = prd.M0[0] * SMd1[0] + prd.M0[1] * SMd1[1] + prd.M0[2] * SMd1[2];
+            const DD ccd = prd.M1[0] * SMd1[0] + prd.M1[1] * SMd1[1] + prd.M1[2] * SMd1[2] + (DD)VCR_LOWPASS;
+            const DD detd = cad * ccd - cbd * cbd;
+            const DD id2d = 1.0 / (detd * detd);
+            const DD gAd = gr.ca, gBd = gr.cb, gCd = gr.cc;
+            gaf = (float)((-ccd * ccd * gAd + cbd * ccd * gBd - cbd * cbd * gCd) * id2d);
+            gcf = (float)((-cad * cad * gCd + cad * cbd * gBd - cbd * cbd * gAd) * id2d);
+            gbf = (float)((2.0 * cbd * ccd * gAd - (cad * ccd + cbd * cbd) * gBd + 2.0 * cad * cbd * gCd) * id2d);
+        }
+        const BR p[3] = {(BR)a.means3D[i3], (BR)a.means3D[i3 + 1], (BR)a.means3D[i3 + 2]};
+        ProjT<BR> pr;
+        project<BR>(a, cam, p, pr);
+        load_cov3d<BR>(a, i, S, R, s);
+        jacobian_rows<BR>(a, cam, pr);
+        BR SM0[3], SM1[3];
+        sym_mul<BR>(S, pr.M0, SM0);
+        sym_mul<BR>(S, pr.M1, SM1);
+        const BR ga = gaf, gb = gbf, gc = gcf;
+        const BR hb = BR(0.5) * gb;
+        // dSigma = M^T G M
+        const BR* M0 = pr.M0; const BR* M1 = pr.M1;
+        dS[0] = ga * M0[0] * M0[0] + gb * M0[0] * M1[0] + gc * M1[0] * M1[0];
+        dS[3] = ga * M0[1] * M0[1] + gb * M0[1] * M1[1] + gc * M1[1] * M1[1];
+        dS[5] = ga * M0[2] * M0[2] + gb * M0[2] * M1[2] + gc * M1[2] * M1[2];
+        dS[1] = ga * M0[0] * M0[1] + hb * (M0[0] * M1[1] + M1[0] * M0[1]) + gc * M1[0] * M1[1];
+        dS[2] = ga * M0[0] * M0[2] + hb * (M0[0] * M1[2] + M1[0] * M0[2]) + gc * M1[0] * M1[2];
+        dS[4] = ga * M0[1] * M0[2] + hb * (M0[1] * M1[2] + M1[1] * M0[2]) + gc * M1[1] * M1[2];
+        // dM = 2 G M Sigma
+        BR dM0[3], dM1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            dM0[k] = BR(2) * (ga * SM0[k] + hb * SM1[k]);
+            dM1[k] = BR(2) * (hb * SM0[k] + gc * SM1[k]);
+        }
+#else
         const BR p[3] = {(BR)a.means3D[i3], (BR)a.means3D[i3 + 1], (BR)a.means3D[i3 + 2]};
         ProjT<BR> pr;
         project<BR>(a, cam, p, pr);
@@ -576,6 +630,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
             dM0[k] = BR(2) * (ga * SM0[k] + hb * SM1[k]);
             dM1[k] = BR(2) * (hb * SM0[k] + gc * SM1[k]);
         }
+#endif
         // dJ = dM Rv^T, Rv[c][k] = V[k*4+c]
         const BR dJ00 = dM0[0] * (BR)V[0] + dM0[1] * (BR)V[4] + dM0[2] * (BR)V[8];
         const BR dJ02 = dM0[0] * (BR)V[2] + dM0[1] * (BR)V[6] + dM0[2] * (BR)V[10];
