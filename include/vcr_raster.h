@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define VCR_ABI_VERSION 18
+#define VCR_ABI_VERSION 19
 
 /* Buffers whose size depends on the number of tile instances R are obtained through this callback
  * (the Python shim backs it with torch's caching allocator, so no hipMalloc on the hot path).
@@ -401,6 +401,10 @@ int vcr_l1_ssim_backward(int H, int W, const float* img1, const float* img2, con
  * the streaming SH kernel then leaves the remaining CUs to the sort chain.  Returns NULL on error. */
 void* vcr_stream_create_cu_masked(const uint32_t* mask, int nwords);
 int vcr_stream_destroy(void* stream);
+/* (ABI 19) The library keeps a few device blocks per (host thread, device, stream) between calls -- ticket / look-back words and
+ * the backward's per-Gaussian accumulators, (64 + 4 S) x N x 1.25 bytes (80 MB at 1 M Gaussians), see INTEGRATION.md section 3.
+ * This frees the calling thread's blocks on every device (synchronises those devices); later calls allocate them again. */
+int vcr_release_scratch(void);
 
 /* Optional per-stage timing with HIP events recorded on the launch stream (used by bench.py for the
  * live roofline figure; no reference counterpart).  Stage order: preprocess, depth sort+scan,

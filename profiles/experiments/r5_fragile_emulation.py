@@ -14,7 +14,7 @@ from oracle import raster_torch as OR  # noqa: E402
 from tests import util  # noqa: E402
 
 print("# K | case | fragile / N | tensor | fp32-oracle error on all: maxnorm p99 p99.9 | on the non-fragile Gaussians")
-for K in (4.0, 16.0, 64.0):
+for K in ([float(x) for x in sys.argv[1:]] or [4.0, 16.0, 64.0]):
     OR.FRAGILE_K = K
     for case in [(3000, 96, 64, 80.0, 6.0, 0), (1500, 100, 70, 90.0, 10.0, 2), (10000, 256, 256, 221.7, 3.0, 0)]:
         n, W, H, f, sm, sem = case

@@ -16,7 +16,7 @@ c_int_p = C.POINTER(C.c_int32)
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 BUF_GEOM, BUF_BINNING, BUF_IMAGE, BUF_SCRATCH = 0, 1, 2, 3
-ABI_VERSION = 18         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
+ABI_VERSION = 19         # VCR_ABI_VERSION of include/vcr_raster.h this binding was written against
 
 
 class VcrShUpdate(C.Structure):
@@ -148,6 +148,7 @@ SYMBOLS = {
     "vcr_l1_ssim_backward": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 7),
     "vcr_stream_create_cu_masked": (C.c_void_p, [C.POINTER(C.c_uint32), C.c_int]),
     "vcr_stream_destroy": (C.c_int, [C.c_void_p]),
+    "vcr_release_scratch": (C.c_int, []),
     "vcr_profile_enable": (None, [C.c_int]),
     "vcr_profile_select": (None, [C.c_uint]),
     "vcr_profile_num_stages": (C.c_int, []),

@@ -76,21 +76,36 @@ struct StreamScratch {
 };
 constexpr uint32_t SEQ_MAX = (1u << 30) - 1u;
 
+// Keyed by (device, stream): the NULL stream is handle 0 on every device, so the stream alone would hand a call on cuda:1 the
+// blocks that were allocated on cuda:0 (round-5 advisor finding).
+struct ScratchKey { int dev; hipStream_t st; };
 struct ScratchMap {
-    std::vector<std::pair<hipStream_t, StreamScratch*>> sets;
-    ~ScratchMap() {}                 // (process exit: the runtime may already be gone -- nothing is freed here)
+    std::vector<std::pair<ScratchKey, StreamScratch*>> sets;
+    void release() {                 // hipFree synchronises the device
+        for (auto& kv : sets) {
+            int cur = 0;
+            (void)hipGetDevice(&cur);
+            if (cur != kv.first.dev) (void)hipSetDevice(kv.first.dev);
+            (void)hipFree(kv.second->ctr); (void)hipFree(kv.second->blk); (void)hipFree(kv.second->status); (void)hipFree(kv.second->grad);
+            if (cur != kv.first.dev) (void)hipSetDevice(cur);
+            delete kv.second;
+        }
+        sets.clear();
+    }
+    ~ScratchMap() {}                 // (thread / process exit: the runtime may already be gone -- callers that want the memory back
+                                     //  call vcr_release_scratch() from the thread that made the calls)
 };
+ScratchMap& scratch_map() { static thread_local ScratchMap m; return m; }
 
 StreamScratch* stream_scratch(hipStream_t st) {
-    static thread_local ScratchMap m;
-    for (auto& kv : m.sets) if (kv.first == st) return kv.second;
-    if (m.sets.size() >= 64) {       // a caller cycling through streams: start over (hipFree synchronises the device)
-        for (auto& kv : m.sets) { (void)hipFree(kv.second->ctr); (void)hipFree(kv.second->blk); (void)hipFree(kv.second->status); (void)hipFree(kv.second->grad); delete kv.second; }
-        m.sets.clear();
-    }
+    ScratchMap& m = scratch_map();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    for (auto& kv : m.sets) if (kv.first.st == st && kv.first.dev == dev) return kv.second;
+    if (m.sets.size() >= 64) m.release();       // a caller cycling through streams: start over
     StreamScratch* sc = new StreamScratch();
     if (hipMalloc((void**)&sc->ctr, sizeof(uint32_t) * VCR_CTR_WORDS) != hipSuccess) { delete sc; return nullptr; }
-    m.sets.emplace_back(st, sc);
+    m.sets.emplace_back(ScratchKey{dev, st}, sc);
     return sc;
 }
 
@@ -475,8 +490,12 @@ struct VisPool {
     bool ok = false;
 };
 
-VisPool* vis_pool() {
-    static thread_local VisPool p;
+VisPool* vis_pool() {                 // one pool per (host thread, device): streams, events and counter blocks belong to a device
+    constexpr int MAX_DEV = 16;
+    static thread_local VisPool pools[MAX_DEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    VisPool& p = pools[dev];
     if (!p.ok) {
         for (int k = 0; k < VIS_STREAMS; ++k) {
             if (hipStreamCreateWithFlags(&p.st[k], hipStreamNonBlocking) != hipSuccess) return nullptr;
@@ -775,6 +794,8 @@ extern "C" void* vcr_stream_create_cu_masked(const uint32_t* mask, int nwords) {
     if (e != hipSuccess) { vcr_set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e)); return nullptr; }
     return (void*)s;
 }
+extern "C" int vcr_release_scratch(void) { scratch_map().release(); return 0; }
+
 extern "C" int vcr_stream_destroy(void* stream) {
     if (stream) VCR_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
     return 0;

@@ -405,6 +405,271 @@ _Pragma("unroll")                                                               
     }
 }
 
+// ================= forward, TWO-PHASE (round 6): every lane walks the list of ITS OWN candidates =============================
+// The loop above shades one survivor per iteration on all 64 lanes, and 10-12 of them are hit (profiles/r3_hit_histogram_*.txt,
+// profiles/r6_twophase_sim.txt).  Here the survivors of the culling are first collected -- densely, over several 64-entry chunks --
+// in a group of up to VCR_TP_CAP staged records.  When the group is full (or the list ends):
+//   phase 1 (Gaussian x row parallel): lane (j, r) of a step solves the conic of survivor 8 * step + j on pixel row r of the quad
+//     for the interval of columns where alpha can reach 1/255 -- a conservative SUPERSET (slack of quad_touch + a margin): 64
+//     (survivor, row) pairs per ~25-instruction step instead of one survivor per ~30-instruction iteration.  The eight row bytes of a
+//     survivor ARE its 64-pixel candidate mask; a 64-byte transpose through LDS hands pixel lane (x, y) bit x of row y of the
+//     eight survivors of the step, which it appends to its own 64-bit candidate word;
+//   phase 2 (pixel parallel, lists per lane): every lane pops ITS next candidate (v_ffbl), fetches that record from the staged
+//     group with per-lane LDS addresses and runs the v2 loop's arithmetic on it -- exact hit test included, so the superset costs
+//     time, never a result.  An iteration shades 64 different (pixel, Gaussian) pairs; the loop runs max_lane(own candidates)
+//     times per 32-slot half of the group: 0.46-0.53 iterations per survivor on the metric scene instead of 1.
+// Every pixel still sees its contributors in list order with the same fp32 operations as in the v2 kernel: the image, final_T and
+// n_contrib are bit-identical to it (tests/test_raster_parity_gpu.py::test_two_phase_forward_is_bit_identical...).
+#ifndef VCR_FWD_TP
+#define VCR_FWD_TP 1
+#endif
+#define VCR_TP_CAP 64
+#ifndef VCR_TP_WAVES
+#define VCR_TP_WAVES 0           // 0: compiler's choice
+#endif
+#if VCR_TP_WAVES > 0
+#define VCR_TP_ATTR __attribute__((amdgpu_waves_per_eu(VCR_TP_WAVES)))
+#else
+#define VCR_TP_ATTR
+#endif
+#ifndef VCR_TP_PIPE
+#define VCR_TP_PIPE 1            // 1: phase 2 fetches a lane's next candidate while it shades the current one
+#endif
+
+// What phase 1 needs of a survivor, computed once by its culler lane: with the raw conic (A, B, C), tau = ln(255 opacity) and
+// d = centre - pixel, alpha >= 1/255  <=>  A dx^2 + 2 B dx dy + C dy^2 <= 2 tau  <=>  (dx + (B/A) dy)^2 <= 2 tau / A - (det / A^2) dy^2.
+// -> (B / A, 2 tau' / A, det' / A^2): tau' carries the slack of quad_touch, det' is a lower bound of A C - B^2 under fp32
+// cancellation (needle-shaped footprints), so that rounding can only widen an interval.  Degenerate conics get every column.
+__device__ __forceinline__ float4 span_params(const float4 q0, const float4 q1, float X0, float Y0, uint32_t pos1) {
+    const float A = q1.x, B = q1.y, C = q1.z;
+    float4 p;
+    p.w = __uint_as_float(pos1);
+    if (!(A > 0.f) || !(C > 0.f)) { p.x = 0.f; p.y = __builtin_inff(); p.z = 0.f; return p; }
+    const float tau = __logf(255.f * q0.w);
+    const float x0 = X0 - q0.x, x1 = X0 + 7.f - q0.x, y0 = Y0 - q0.y, y1 = Y0 + 7.f - q0.y;
+    const float mx = fmaxf(x0 * x0, x1 * x1), my = fmaxf(y0 * y0, y1 * y1);
+    const float taus = tau + 0.05f + 2e-6f * (A * mx + C * my);
+    const float ia = fast_rcp(A);
+    const float ac = A * C, bb = B * B;
+    p.x = B * ia;
+    p.y = 2.00002f * taus * ia;
+    p.z = ((ac - bb) - 4e-7f * (ac + bb)) * ia * ia * 0.99998f;
+    return p;
+}
+
+template <int S, bool ISECT, int ND, bool QL>
+__global__ void __launch_bounds__(256) VCR_TP_ATTR composite_fwd_tp_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
+                                                               const uint32_t* __restrict__ point_list,
+                                                               const uint2* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ meta,
+                                                               int num_tiles, int gxc, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                               float* __restrict__ moments, float* __restrict__ out) {
+    static_assert(S <= 2, "the two-phase forward keeps the semantic features in the record's pad words");
+    const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
+    int sub;
+    const int tile = work_item(tile_order, meta, num_tiles, sub);
+    if (tile < 0) return;
+    const PixelMap pm = pixel_of_thread(tile, gx, a.W, a.H, sub);
+    const uint2 range = list_range<QL>(ranges, gxc, tile, gx, threadIdx.x >> 6);
+    const int P = a.H * a.W;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ float4 s_rec_all[4 * 5 * VCR_TP_CAP];       // per wave: 5 planes x 64 slots x 16 B
+    __shared__ uint2 s_rb_all[4 * 8];                      // per wave: 8 rows x 8 survivors, one byte each
+    float4* const srec = s_rec_all + wv * 5 * VCR_TP_CAP;
+    uint2* const rbq = s_rb_all + wv * 8;
+    uint8_t* const rbb = reinterpret_cast<uint8_t*>(rbq);
+    const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8 + (sub < 0 ? 0 : (sub & 1) * 4));
+    const float Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8 + (sub < 0 ? 0 : (sub >> 1) * 4));
+    const f2 fxy = {(float)pm.x, (float)pm.y};
+    float rx = 0.f, ry = 0.f, rz = 1.f;
+    if (ISECT && pm.inside) { rx = a.dirs[pm.pix]; ry = a.dirs[P + pm.pix]; rz = a.dirs[2 * P + pm.pix]; }
+
+    float T = 1.f;
+    f2 acc_c01 = {0.f, 0.f}, acc_c2n = {0.f, 0.f}, acc_n12 = {0.f, 0.f}, acc_da = {0.f, 0.f};
+    float SM[S > 0 ? S : 1];
+#pragma unroll
+    for (int k = 0; k < S; ++k) SM[k] = 0.f;
+    float M1 = 0.f, M2 = 0.f;
+    const float zc_map = VCR_ZFAR / (VCR_ZFAR - VCR_ZNEAR);
+    uint32_t last = 0;
+    bool done = !pm.inside;
+    int fill = 0;                                          // staged survivors of the current group (wave-uniform)
+
+    // one candidate of this lane: the staged record of slot SLOT (per-lane LDS addresses), the v2 loop's arithmetic
+#define VCR_TP_FETCH(R, SLOT)                                                                                 \
+    do {                                                                                                      \
+        const int s_ = (SLOT);                                                                                \
+        R##0 = srec[s_]; R##1 = srec[VCR_TP_CAP + s_]; R##2 = srec[2 * VCR_TP_CAP + s_];                      \
+        R##3 = srec[3 * VCR_TP_CAP + s_]; R##p = s_;                                                          \
+        asm volatile("" ::: "memory");                                                                        \
+    } while (0)
+#define VCR_TP_SHADE(R, ACT)                                                                                  \
+    do {                                                                                                      \
+        const float4 r0 = R##0, r1 = R##1, r2 = R##2, r3 = R##3;                                              \
+        const f2 gxy = {r0.x, r0.y}, sAC = {r0.z, r0.w};                                                      \
+        f2 u; float hs;                                                                                       \
+        const float e = gauss_exponent(gxy - fxy, sAC, r1.x, r1.y, u, hs);                                    \
+        const float alpha = fminf(VCR_ALPHA_MAX, __builtin_amdgcn_exp2f(e));                                  \
+        bool hit = (ACT) && !done && hs <= 0.f && alpha >= VCR_ALPHA_MIN;                                     \
+        const float test_T = fmaf(-alpha, T, T);                                                              \
+        if (hit && test_T < VCR_T_EPS) { done = true; hit = false; }                                          \
+        const float w = hit ? alpha * T : 0.f;                                                                \
+        const f2 c01 = {r2.x, r2.y}, c2n = {r2.z, r2.w}, n12 = {r3.x, r3.y};                                  \
+        float dep = r1.z;                                                                                     \
+        if (ISECT) {                                                                                          \
+            const float den = fmaf(c2n.y, rx, fmaf(n12.x, ry, n12.y * rz));                                   \
+            if (den > VCR_PLANE_EPS) dep = r1.w * fast_rcp(den) * rz;                                         \
+        }                                                                                                     \
+        const f2 ww = splat(w);                                                                               \
+        acc_c01 = pk_fma(ww, c01, acc_c01);                                                                   \
+        acc_c2n = pk_fma(ww, c2n, acc_c2n);                                                                   \
+        acc_n12 = pk_fma(ww, n12, acc_n12);                                                                   \
+        acc_da = pk_fma(ww, f2{dep, 1.f}, acc_da);                                                            \
+        if (ND == 2) M2 = fmaf(w * dep, dep, M2);                                                             \
+        if (ND == 1) {                                                                                        \
+            const float md = -zc_map * VCR_ZNEAR * fast_rcp(dep);                                             \
+            M1 = fmaf(w, md, M1); M2 = fmaf(w * md, md, M2);                                                  \
+        }                                                                                                     \
+        if (S > 0) {                                                                                          \
+            const float sv_[2] = {r3.z, r3.w};                                                                \
+_Pragma("unroll")                                                                                             \
+            for (int k = 0; k < S; ++k) SM[k] = fmaf(w, sv_[k], SM[k]);                                       \
+        }                                                                                                     \
+        T = hit ? test_T : T;                                                                                 \
+        lslot = hit ? R##p : lslot;       /* (its list position is looked up once per group)                */ \
+    } while (0)
+    // walk the candidates of one 32-slot half of the group, front to back; a lane whose word is empty idles on slot BASE
+#define VCR_TP_POP(W_, B_, ACT_)                                                                              \
+    do { ACT_ = W_ != 0u; B_ = ACT_ ? __builtin_ctz(W_) : 0; W_ &= W_ - 1u; } while (0)
+#if VCR_TP_PIPE
+#define VCR_TP_WALK(WORD, BASE)                                                                               \
+    do {                                                                                                      \
+        uint32_t w_ = (WORD);                                                                                 \
+        if (__builtin_amdgcn_ballot_w64(w_ != 0u) != 0) {                                                     \
+            float4 A0, A1, A2, A3, B0, B1, B2, B3; int Ap, Bp;                                                \
+            int b_, nb_; bool act_, nact_;                                                                    \
+            VCR_TP_POP(w_, b_, act_);                                                                         \
+            VCR_TP_FETCH(A, (BASE) + b_);                                                                     \
+            for (;;) {                                                                                        \
+                bool more_ = __builtin_amdgcn_ballot_w64(w_ != 0u) != 0;                                      \
+                VCR_TP_POP(w_, nb_, nact_);                                                                   \
+                VCR_TP_FETCH(B, (BASE) + nb_);                                                                \
+                VCR_TP_SHADE(A, act_);                                                                        \
+                if (!more_) break;                                                                            \
+                more_ = __builtin_amdgcn_ballot_w64(w_ != 0u) != 0;                                           \
+                VCR_TP_POP(w_, b_, act_);                                                                     \
+                VCR_TP_FETCH(A, (BASE) + b_);                                                                 \
+                VCR_TP_SHADE(B, nact_);                                                                       \
+                if (!more_) break;                                                                            \
+            }                                                                                                 \
+        }                                                                                                     \
+    } while (0)
+#else
+#define VCR_TP_WALK(WORD, BASE)                                                                               \
+    do {                                                                                                      \
+        uint32_t w_ = (WORD);                                                                                 \
+        while (__builtin_amdgcn_ballot_w64(w_ != 0u) != 0) {                                                  \
+            float4 A0, A1, A2, A3; int Ap;                                                                    \
+            int b_; bool act_;                                                                                \
+            VCR_TP_POP(w_, b_, act_);                                                                         \
+            VCR_TP_FETCH(A, (BASE) + b_);                                                                     \
+            VCR_TP_SHADE(A, act_);                                                                            \
+        }                                                                                                     \
+    } while (0)
+#endif
+    // phase 1 + phase 2 over the `fill` staged survivors
+#define VCR_TP_FLUSH()                                                                                        \
+    do {                                                                                                      \
+        __builtin_amdgcn_wave_barrier();                                                                      \
+        unsigned long long my_ = 0ull;                                                                        \
+        const int steps_ = (fill + 7) >> 3;                                                                   \
+        for (int st_ = 0; st_ < steps_; ++st_) {                                                              \
+            const int slot_ = 8 * st_ + (lane >> 3);                                                          \
+            const float4 g_ = srec[slot_], p_ = srec[4 * VCR_TP_CAP + slot_];                                 \
+            const float dy_ = (g_.y - Y0) - (float)(lane & 7);                                                \
+            const float D_ = fmaf(-p_.z, dy_ * dy_, p_.y);                                                    \
+            const float h_ = __builtin_amdgcn_sqrtf(fmaxf(D_, 0.f)) * 1.00001f + 0.01f;                       \
+            const float xc_ = fmaf(p_.x, dy_, g_.x - X0);                                                     \
+            const float lo_ = fmaxf(ceilf(xc_ - h_), 0.f), hi_ = fminf(floorf(xc_ + h_), 7.f);                \
+            const bool ok_ = D_ >= 0.f && lo_ <= hi_ && slot_ < fill;                                         \
+            const uint32_t row_ = ok_ ? (2u << (int)hi_) - (1u << (int)lo_) : 0u;                             \
+            rbb[(lane & 7) * 8 + (lane >> 3)] = (uint8_t)row_;                                                \
+            __builtin_amdgcn_wave_barrier();                                                                  \
+            const uint2 v_ = rbq[lane >> 3];                                                                  \
+            __builtin_amdgcn_wave_barrier();                                                                  \
+            uint32_t a_ = (v_.x >> (lane & 7)) & 0x01010101u, b2_ = (v_.y >> (lane & 7)) & 0x01010101u;       \
+            a_ |= a_ >> 7; a_ |= a_ >> 14; b2_ |= b2_ >> 7; b2_ |= b2_ >> 14;                                 \
+            my_ |= (unsigned long long)((a_ & 0xFu) | ((b2_ & 0xFu) << 4)) << (8 * st_);                      \
+        }                                                                                                     \
+        if (done) my_ = 0ull;                                                                                 \
+        int lslot = -1;                                                                                       \
+        VCR_TP_WALK((uint32_t)my_, 0);                                                                        \
+        VCR_TP_WALK((uint32_t)(my_ >> 32), 32);                                                               \
+        if (lslot >= 0) last = __float_as_uint(srec[4 * VCR_TP_CAP + lslot].w);                               \
+        fill = 0;                                                                                             \
+    } while (0)
+
+    uint32_t pos = range.x;
+    const float4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    uint32_t id, nid; float4 q0, q1, q2 = zero4, q3 = zero4; bool valid, nvalid;
+    VCR_LOAD_ID(pos + lane, range.y, id, valid);
+    VCR_GATHER_REC(id, q0, q1, q2, q3);
+    VCR_LOAD_ID(pos + 64 + lane, range.y, nid, nvalid);
+    while (pos < range.y) {
+        uint32_t nnid; float4 nq0, nq1, nq2, nq3; bool nnvalid;
+        const uint32_t npos = pos + 64;
+        VCR_GATHER_REC(nid, nq0, nq1, nq2, nq3);                      // records of the next chunk
+        VCR_LOAD_ID(npos + 64 + lane, range.y, nnid, nnvalid);       // ids of the chunk after that
+        float bx0, by0, bw, bh;
+        live_box(__builtin_amdgcn_ballot_w64(!done), X0, Y0, bx0, by0, bw, bh);
+        const bool keep = valid && quad_touch(q0, q1, bx0, by0, bw, bh);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        const int cnt = __popcll(m);
+        if (fill + cnt > VCR_TP_CAP) {                               // (wave-uniform)
+            VCR_TP_FLUSH();
+            if (__builtin_amdgcn_ballot_w64(!done) == 0) { pos = range.y; break; }        // every pixel of the quad has T < 1e-4
+        }
+        if (keep) {
+            const int slot = fill + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            srec[slot] = make_float4(q0.x, q0.y, -VCR_L2E * q1.x, -VCR_L2E * q1.z);
+            srec[VCR_TP_CAP + slot] = make_float4(-VCR_L2E * q1.y, __builtin_amdgcn_logf(q0.w), q0.z, q1.w);
+            srec[2 * VCR_TP_CAP + slot] = make_float4(q2.x, q2.y, q2.z, q3.x);
+            srec[3 * VCR_TP_CAP + slot] = make_float4(q3.y, q3.z, q2.w, q3.w);
+            srec[4 * VCR_TP_CAP + slot] = span_params(q0, q1, X0, Y0, pos - range.x + (uint32_t)lane + 1u);
+        }
+        fill += cnt;
+        pos = npos; id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; valid = nvalid; nid = nnid; nvalid = nnvalid;
+    }
+    if (fill > 0) VCR_TP_FLUSH();
+#undef VCR_TP_FLUSH
+#undef VCR_TP_WALK
+#undef VCR_TP_POP
+#undef VCR_TP_SHADE
+#undef VCR_TP_FETCH
+    if (pm.inside) {
+        final_T[pm.pix] = T;
+        n_contrib[pm.pix] = last;
+        out[0 * (size_t)P + pm.pix] = acc_c01.x + T * a.bg[0];
+        out[1 * (size_t)P + pm.pix] = acc_c01.y + T * a.bg[1];
+        out[2 * (size_t)P + pm.pix] = acc_c2n.x + T * a.bg[2];
+        out[3 * (size_t)P + pm.pix] = acc_da.x;
+        out[4 * (size_t)P + pm.pix] = acc_c2n.y;
+        out[5 * (size_t)P + pm.pix] = acc_n12.x;
+        out[6 * (size_t)P + pm.pix] = acc_n12.y;
+        out[7 * (size_t)P + pm.pix] = acc_da.y;
+#pragma unroll
+        for (int k = 0; k < S; ++k) out[(8 + k) * (size_t)P + pm.pix] = SM[k];
+        if (ND == 2) {
+            out[(8 + S) * (size_t)P + pm.pix] = acc_da.x;
+            out[(9 + S) * (size_t)P + pm.pix] = M2;
+        }
+        if (ND == 1) {
+            out[(8 + S) * (size_t)P + pm.pix] = acc_da.y * M2 - M1 * M1;
+            moments[pm.pix] = M1; moments[P + pm.pix] = M2;
+        }
+    }
+}
+
 // ---- shading macros of the compositing backward (one survivor, all 64 lanes = the whole 8x8 quad) ---------------------------
 // Used by the row-packed kernel below for the chunks where packing does not pay (the round-2 kernel that was built from them
 // alone, `composite_bwd_v2`, left the library in round 5: profiles/r3_bwd_rows_ab.txt holds its A/B).
@@ -772,6 +1037,18 @@ int launch_fwd_fc(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im
     hipLaunchKernelGGL((composite_fwd_v2_kernel<S, ISECT, FC, NDD, Q>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
                        b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, o.out, o.count, o.score, im.t_ckpt)
 #define VCR_FWD(FC, NDD) do { if (gxc) { VCR_FWD_Q(FC, NDD, true); } else { VCR_FWD_Q(FC, NDD, false); } } while (0)
+    if constexpr (VCR_FWD_TP != 0 && S <= 2) {
+        if (a.f_count == 0) {            // the training / evaluation render: two-phase form (the count modes keep the v2 loop)
+            if (gxc)
+                hipLaunchKernelGGL((composite_fwd_tp_kernel<S, ISECT, ND, true>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec,
+                                   b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, o.out);
+            else
+                hipLaunchKernelGGL((composite_fwd_tp_kernel<S, ISECT, ND, false>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec,
+                                   b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, o.out);
+            VCR_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
     switch (a.f_count) {
         case 0: VCR_FWD(0, ND); break;
         case 1: case 2: VCR_FWD(1, 0); break;

@@ -80,8 +80,7 @@ __device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
 __device__ __forceinline__ float gauss_exponent(f2 d, f2 sAC, float sB, float lop, f2& u, float& hs) {
     const f2 t = splat(sB) * d.yx;
     u = pk_fma(sAC, d, t);
-    const f2 h = u * d;
-    hs = h.x + h.y;
+    hs = fmaf(u.x, d.x, u.y * d.y);       // (spelled out: every kernel that evaluates a pair must round it the same way)
     return fmaf(0.5f, hs, lop);
 }
 #define VCR_L2E 1.4426950408889634f

@@ -412,6 +412,13 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(VcrRasterArgs a, Ge
                 uint32_t was = atomicOr(vis_slots + VCR_FAR_FLAG_WORD, 1u);
                 asm volatile("" : "+v"(was));
             }
+            // (This is NOT the HIP memory model's release / acquire: it relies on two gfx9-family facts -- stores are counted in
+            //  vmcnt (gfx10+ count them in vscnt), and device-scope stores / loads go through to the memory side of the L2s (sc1).
+            //  The library is built for gfx950 only; any other target must use __ATOMIC_RELEASE on the ticket and an acquire
+            //  fence in the last workgroup instead.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "the count-rows-before-ticket ordering below is written for gfx942 / gfx950 (stores counted in vmcnt)"
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // two-level ticket (vcr_common.h)
             const uint32_t grp = blockIdx.x % VCR_DONE_GROUPS;
