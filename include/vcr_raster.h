@@ -98,7 +98,12 @@ typedef struct VcrRasterArgs {
                                    internal to a forward / backward pair).  vcr_rasterize_backward MUST be called with the value its forward was
                                    called with: the state buffers hold the lists in that form.  Pays for
                                    small footprints (R / V below ~4 tiles per visible Gaussian); images up to 8192 pixels. */
-    int32_t pad_;
+    int32_t forward_form;       /* (ABI 19) which kernel composites an f_count = 0 frame.  0: the library decides per frame from its
+                                   counts (two-phase below VCR_TP_MAX_TILES_PER_GAUSSIAN = 5 3-sigma tiles per visible Gaussian,
+                                   csrc/composite.hip); 1: the uniform loop (one survivor per iteration on all 64 lanes of a quad);
+                                   2: the two-phase form (row-span candidate masks, per-lane candidate lists; S <= 2).  The two
+                                   write bit-identical images and image state (tests/test_raster_parity_gpu.py), so the value
+                                   need not be repeated to the backward. */
 } VcrRasterArgs;
 
 /* Forward outputs.  `out`, `radii`, counters are caller-allocated. */

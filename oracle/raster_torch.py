@@ -224,7 +224,13 @@ def bin_and_sort(pre):
     return owner, beg, end, R
 
 
-FRAGILE_K = 16.0          # multiples of the fp32 unit roundoff (2^-24) x the magnitude of what is being rounded, see _mark_fragile
+# multiples of the fp32 unit roundoff (2^-24) x the magnitude of what is being rounded, see _mark_fragile.  Round 6 sweeps (fp32 oracle
+# against fp64 oracle): K = 8 is the smallest value at which the error on the UNMARKED Gaussians has plateaued on every swept scene
+# -- c1 plateaus at K = 4 (rotations 2.5e-5 at K = 1, 2; 1.6e-5 from 4 on: profiles/r6_fragile_k_sweep.txt), a 4 000-Gaussian scene
+# at 160 x 128 only at K = 8 (5.3e-4 up to K = 6, 7.3e-5 from 8 on: profiles/r6_fragile_k_sweep_more_scenes.txt) -- and the marked
+# share of c1 falls from the 19 % of round 5's K = 16 to 10 %.  VCR_TEST_FRAGILE_K overrides it for such sweeps (test infrastructure).
+import os as _os
+FRAGILE_K = float(_os.environ.get("VCR_TEST_FRAGILE_K", "8"))
 
 
 @torch.no_grad()

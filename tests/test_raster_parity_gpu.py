@@ -50,6 +50,8 @@ def test_c1_all_four_cameras_forward_and_backward(device, view):
     (out, radii), hl = util.hip_forward(cam, inp, dirs, bg, device, requires_grad=True)
     assert torch.equal(radii.cpu(), rradii) and (hl["record"].R, hl["record"].V) == (st["R"], st["V"])
     assert util.bad_pixels(out, ref) <= util.pixel_budget(ref)
+    # BASELINE.json: "rendered PSNR ... within 1e-4 rel of the reference rasterizer" (`tools/image_utils.py:17`), whole image
+    util.assert_psnr_parity(out[:3], ref[:3], f"c1 view {view}", seed=view)
     (out * wgt.float().to(device)).sum().backward()
     clean, flipped = util.flip_clean_mask(cam, inp, out, ref, bg)
     for k in ["means3D", "shs", "normals", "opac", "scales", "rots", "m2", "m2d"]:
@@ -304,7 +306,10 @@ def test_edge_tiny_image_and_few_gaussians(device):
         out, ref, hl, rl, st = _fwd_bwd_vs_oracle(device, cam, inp, dirs, torch.tensor([0.2, 0.4, 0.6]), fwd_budget=1)
         for k in ["means3D", "opac", "scales", "rots", "shs"]:
             if float(rl[k].grad.abs().max()) > 0:
-                util.assert_grads_close(hl[k].grad, rl[k].grad, f"n={n}:{k}", p999_tol=1e-1, fragile=rl.get("fragile"))
+                # (one to three Gaussians on a 7 x 5 image: every one of them sits under some fragile decision, so there is no
+                #  strict subset here -- min_nonfragile=0 says so; the BOUNDED comparison on all rows is this test)
+                util.assert_grads_close(hl[k].grad, rl[k].grad, f"n={n}:{k}", p999_tol=1e-1, fragile=rl.get("fragile"),
+                                        min_nonfragile=0.0)
 
 
 def test_edge_screen_filling_gaussians(device):
@@ -334,8 +339,11 @@ def test_edge_equal_depths_and_opacity_extremes(device):
     out, ref, hl, rl, st = _fwd_bwd_vs_oracle(device, cam, inp, dirs, torch.tensor([0.0, 0.5, 1.0]))
     assert float(hl["opac"].grad[100:150].abs().max()) == 0.0 and float(rl["opac"].grad[100:150].abs().max()) == 0.0
     assert float(ref[7].max()) > 0.999                            # saturated pixels exist
+    # (half of this scene is exact depth ties and most of the rest shares pixels with them: 92 % of the rows are under a fragile
+    #  ORDER decision by construction, so the strict subset is the 50 rows that are not -- min_nonfragile says so -- and the
+    #  bounded comparison on all rows carries the test)
     for k in ["means3D", "opac", "scales", "rots", "shs", "normals"]:
-        util.assert_grads_close(hl[k].grad, rl[k].grad, k, fragile=rl.get("fragile"))
+        util.assert_grads_close(hl[k].grad, rl[k].grad, k, fragile=rl.get("fragile"), min_nonfragile=0.05)
 
 
 @pytest.mark.parametrize("num_dist", [1, 2])
@@ -444,6 +452,50 @@ def test_quad_granular_binning_gives_the_same_render_and_gradients(device, case)
     (c0, _), _ = util.hip_forward(cam, inp, dirs, bg, device, f_count=3, use_normals=False)
     (c1, _), _ = util.hip_forward(cam, inp, dirs, bg, device, f_count=3, use_normals=False, options=RasterOptions(quad_lists=True))
     assert torch.equal(c0, c1)
+
+
+@pytest.mark.parametrize("case", ["small", "ragged_big_footprints", "semantic_dist1", "semantic_dist2", "no_isect"])
+@pytest.mark.parametrize("ql", [False, True])
+def test_two_phase_forward_is_bit_identical_to_the_uniform_loop(device, case, ql):
+    """Round 6: the two-phase compositing forward (`RasterOptions.forward_form="two_phase"`: row-span candidate masks per survivor,
+    every lane walks the list of its own candidates) against the uniform loop ("uniform": one survivor per iteration on all 64
+    lanes).  Every pixel sees its contributors in list order with the same fp32 operations, so image, final transmittance and
+    n_contrib must agree BIT FOR BIT -- for small footprints, for footprints from a few pixels to most of the frame on an image
+    whose sides are no multiples of 8, with semantic channels and both kinds of depth-moment channels, without intersection
+    depth, per tile and per quad.  "auto" must pick one of the two."""
+    from vcr_gaus_amd import _lib
+    from vcr_gaus_amd.rasterizer import RasterOptions
+    nd, sem, use_normals = 0, 0, True
+    if case == "small":
+        cam, inp, dirs = util.make_case(3000, 96, 64, 80.0, seed=41, scale_mult=6.0)
+    elif case == "ragged_big_footprints":
+        cam, inp, dirs = util.make_case(1500, 203, 117, 150.0, seed=42, scale_mult=5.0)
+        g = torch.Generator().manual_seed(2)
+        inp["scales"] = inp["scales"] * torch.exp(2.2 * torch.rand(1500, 1, generator=g) ** 3)
+    elif case == "no_isect":
+        cam, inp, dirs = util.make_case(2500, 120, 72, 90.0, seed=44, scale_mult=6.0)
+        use_normals = False
+    else:
+        cam, inp, dirs = util.make_case(2500, 96, 64, 80.0, seed=43, scale_mult=6.0, sem=2)
+        nd = 1 if case == "semantic_dist1" else 2
+    bg = torch.tensor([0.3, 0.2, 0.1])
+    H, W = cam.image_height, cam.image_width
+    P = H * W
+    res = {}
+    for form in ("uniform", "two_phase", "auto"):
+        (out, radii), hl = util.hip_forward(cam, inp, dirs, bg, device, requires_grad=True, num_dist=nd, use_normals=use_normals,
+                                            options=RasterOptions(quad_lists=ql, forward_form=form))
+        st = out.grad_fn.state[_lib.BUF_IMAGE]
+        off = (4 * P + 255) // 256 * 256
+        res[form] = (out.detach().clone(), radii.clone(), st[:4 * P].clone(), st[off:off + 4 * P].clone())
+    for k in range(4):
+        assert torch.equal(res["uniform"][k].view(torch.uint8) if res["uniform"][k].dtype != torch.uint8 else res["uniform"][k],
+                           res["two_phase"][k].view(torch.uint8) if res["two_phase"][k].dtype != torch.uint8 else res["two_phase"][k]), \
+            ["image", "radii", "final_T", "n_contrib"][k]
+        assert torch.equal(res["auto"][k], res["uniform"][k])
+    # and the oracle agrees with what both wrote
+    (ref, _, _), _ = util.oracle_forward(cam, inp, dirs, bg, num_dist=nd, use_normals=use_normals)
+    assert util.bad_pixels(res["two_phase"][0][:8], ref[:8]) <= util.pixel_budget(ref)
 
 
 def test_depth_order_beyond_the_27_bit_key_range(device):

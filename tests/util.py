@@ -94,11 +94,35 @@ def pixel_budget(img):
     return max(4, int(1e-3 * img.shape[-1] * img.shape[-2]))
 
 
+PSNR_REL_TOL = 1e-4        # BASELINE.json: "rendered PSNR ... within 1e-4 rel of the reference rasterizer"
+
+
+def assert_psnr_parity(out_rgb, ref_rgb, name, seed=0, noise=0.05):
+    """BASELINE.json's PSNR clause: PSNR(HIP render, gt) against PSNR(oracle render, gt) with the reference's own `psnr`
+    (`tools/image_utils.py:17-19`: per channel, 20 log10(1 / sqrt(mse))), |difference| / PSNR <= 1e-4 for every channel.
+    out_rgb / ref_rgb: [3, ...] colour planes (a whole image or the pixels of the sampled tiles).  gt: the oracle's render plus
+    seeded noise of sigma `noise`, clamped to [0, 1] -- a ground truth at the 26 dB a half-trained model sits at, so that a
+    render error shows in the figure instead of drowning in it.  -> (psnr_hip [3], psnr_oracle [3])."""
+    o = out_rgb.detach().double().cpu().reshape(3, -1)
+    r = ref_rgb.detach().double().cpu().reshape(3, -1)
+    g = torch.Generator().manual_seed(1000 + seed)
+    gt = (r + noise * torch.randn(r.shape, generator=g, dtype=torch.float64)).clamp(0.0, 1.0)
+
+    def psnr(img1, img2):
+        mse = ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
+        return (20 * torch.log10(1.0 / torch.sqrt(mse))).reshape(-1)
+
+    ph, pr = psnr(o, gt), psnr(r, gt)
+    rel = ((ph - pr).abs() / pr.abs()).max()
+    assert float(rel) <= PSNR_REL_TOL, f"{name}: PSNR {ph.tolist()} against the oracle's {pr.tolist()} (rel {float(rel):.2e})"
+    return ph, pr
+
+
 def rel_err(a, b):
-    """max-norm relative error of a tensor against its reference."""
+    """max-norm relative error of a tensor against its reference (empty tensors: nan -- callers must not compare nothing)."""
     a, b = a.double().cpu(), b.double().cpu()
     if a.numel() == 0:
-        return 0.0
+        return float("nan")
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
@@ -119,43 +143,57 @@ def grad_stats(a, b):
     return dict(maxnorm=rel_err(a, b), med=float(q[0]), p99=float(q[1]), p999=float(q[2]), max=float(e.max()) if e.numel() else 0.0)
 
 
-# Gradient acceptance used by every parity test (round 5: rebuilt around FRAGILE DECISIONS).
+# Gradient acceptance used by every parity test.
 #
 # The rasterizer is piecewise smooth: per (pixel, entry) it decides power <= 0, alpha >= 1/255, T' < 1e-4, and per pair of list
 # neighbours the depth order.  Two correct fp32 evaluations that round differently resolve the decisions that sit within
 # rounding distance of their threshold differently, and each such flip moves the gradient of the Gaussians under it by a
-# FINITE amount -- without moving the image beyond the pixel tolerance.  Rounds 1-4 compared all gradients against multiples
-# of "the error of the oracle itself in fp32" and found the HIP path 2-6x noisier on geometry gradients, with exceptions of 5 /
-# 8 / 12 on the factor and a suite that flaked at its tightest entries.  Round 5 took that apart (profiles/r5_*):
-#   * the compositing backward's per-Gaussian sums are as accurate as the fp32 oracle's (r5_grad_stage_errors.txt), and neither
-#     its transmittance recovery nor its atomics matter (anchored / Newton / fp64-recurrence / fp64-accumulation builds:
-#     r5_ratio_*.txt): VERDICT r4's hypothesis is refuted by measurement;
-#   * the excess on scales / rotations / means came from the PROJECTION backward's fp32 adjoint chain -- now fp64;
-#   * what is left, in the HIP path AND in the fp32 oracle, is dominated by flips: leaving out the Gaussians under fragile
-#     decisions drops the fp32 oracle's own max-norm error 10-25x (r5_fragile_emulation.txt).
-# So the fp64 oracle now also reports which Gaussians sit under a fragile decision (oracle/raster_torch.py::_mark_fragile: test
-# quantity within K = 16 unit roundoffs x the magnitude of what an fp32 evaluation rounds), and a comparison has two parts:
-#   STRICT on the non-fragile Gaussians: max-norm relative error < 3e-4 (BASELINE.json's figure is 1e-4: met by 146 of the 162
-#          comparisons of the suite, worst 1.93e-4, see NONFRAGILE_MAXNORM_TOL), element-wise p99 / p99.9
-#          below 3 x the committed fp32-oracle yardstick of that tensor and regime -- factor 3 EVERYWHERE, no exceptions;
+# FINITE amount -- without moving the image beyond the pixel tolerance (round 5: profiles/r5_fragile_emulation.txt, leaving those
+# Gaussians out drops the fp32 ORACLE's own max-norm error 10-25x).  The fp64 oracle therefore reports which Gaussians sit under
+# such a FRAGILE decision (oracle/raster_torch.py::_mark_fragile: test quantity within K unit roundoffs x the magnitude of what an
+# fp32 evaluation rounds; K = 8 since round 6 -- the smallest K at which the fp32 oracle's own error on the unmarked rows has
+# plateaued on every swept scene, profiles/r6_fragile_k_sweep*.txt: c1 loses 10 % of its rows to the mask, not 19 %), and a
+# comparison has two parts:
+#   STRICT on the non-fragile Gaussians -- at least MIN_NONFRAGILE_FRACTION of the rows, asserted --:
+#          max-norm relative error < CONTRACT_MAXNORM = 1e-4, BASELINE.json's figure, for every tensor of every regime ...
+#          ... EXCEPT the comparisons listed BY NAME in tests/golden/grad_known_misses.json: the ones the committed record
+#          profiles/r6_grad_vs_1e-4.txt shows at or above 0.8 x 1e-4 (each with its measured figure and the stage that makes it).
+#          They are held to KNOWN_MISS_BOUND = 3e-4 (round 5's acceptance) and stay listed as misses of the contract;
+#          element-wise p99 / p99.9 below 3 x the committed fp32-oracle yardstick of that tensor and regime (factor 3 everywhere);
 #   BOUNDED on all of them: a flip is a legitimate difference, not an unbounded one -- max-norm < 3e-3, p99 / p99.9 below
 #          max(10 x the yardstick, 1e-3 / 1e-2).
 # Yardstick: tests/golden/grad_yardstick.json (profiles/grad_yardstick.py; regimes "small" / "full" / "step"), floors
-# 2e-5 / 2e-5 / 3e-3.  A comparison without a fragile mask (quantities that do not come out of the rasterizer's backward)
-# uses the strict p99 / p99.9 figures and the tensor's own max-norm yardstick.
+# 2e-5 / 2e-5 / 3e-3 (unchanged since round 5; not re-fitted).  A comparison without a fragile mask (quantities that do not come
+# out of the rasterizer's backward) uses the strict p99 / p99.9 figures and the tensor's own max-norm yardstick.
 import json as _json
+import re as _re
 
-with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "grad_yardstick.json")) as _f:
+_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+with open(os.path.join(_GOLDEN, "grad_yardstick.json")) as _f:
     _YARDSTICK = _json.load(_f)
+with open(os.path.join(_GOLDEN, "grad_known_misses.json")) as _f:
+    _KNOWN_MISSES = _json.load(_f)["misses"]          # {"<test id>|<tensor name>": {"measured": ..., "stage": ...}}
 _FACTOR = 3.0                      # everywhere
 _FACTOR_ALL = 10.0                 # quantile bounds with the fragile Gaussians included
-NONFRAGILE_MAXNORM_TOL = 3e-4      # BASELINE.json asks for 1e-4 rel: measured over the 162 comparisons of the GPU suite (profiles/
-                                   # r5_grad_report_calibration.txt) 146 are below 1e-4, the worst is 1.93e-4 (a normals gradient at 1 M /
-                                   # 1080p); 3e-4 is that worst case with its run-to-run spread, not a target
+CONTRACT_MAXNORM = 1e-4            # BASELINE.json: "per-parameter gradients within 1e-4 rel of the reference rasterizer"
+NONFRAGILE_MAXNORM_TOL = CONTRACT_MAXNORM
+KNOWN_MISS_BOUND = 3e-4            # for the comparisons named in grad_known_misses.json only
+MIN_NONFRAGILE_FRACTION = 0.8      # a strict comparison on fewer rows than this would be vacuous: asserted (never n == 0)
 ALL_MAXNORM_TOL = 3e-3
 _FLOOR = (2e-5, 2e-5, 3e-3)        # p99.9 of a 3 000 - 9 000-element tensor is its 3rd - 9th worst element: an order statistic whose
                                    # run-to-run spread is a factor ~2 (profiles/r5_grad_report_*.txt); 3 x ONE draw of it from the fp32
                                    # oracle is not a bound, 0.3 % of the element's own magnitude is
+
+
+def _current_test():
+    return os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::")[-1]
+
+
+def known_miss(name):
+    """The entry of tests/golden/grad_known_misses.json for this comparison (current test id | tensor name), or None."""
+    return _KNOWN_MISSES.get(f"{_current_test()}|{name}")
+
+
 # other names the tests use for the same tensors
 _ALIAS = {"xyz": "means3D", "f_dc": "shs", "f_rest": "shs", "opacity": "opac", "scaling": "scales", "rotation": "rots",
           "means2D_densify": "m2d", "means2D": "m2", "obj_dc": "sem", "col": "shs", "cov": "scales", "op": "opac", "nrm": "normals"}
@@ -190,11 +228,14 @@ def _report(name, part, st, tols, n):
     assert st["p999"] < tols[2], f"grad {name} [{part}]: element-wise p99.9 err {st['p999']:.2e} >= {tols[2]:.1e} (stats {st})"
 
 
-def assert_grads_close(got, ref, name, maxnorm_tol=None, p999_tol=None, p99_tol=None, scale=1.0, regime="small", fragile=None):
+def assert_grads_close(got, ref, name, maxnorm_tol=None, p999_tol=None, p99_tol=None, scale=1.0, regime="small", fragile=None,
+                       min_nonfragile=None):
     """`got` against the fp64 oracle's `ref` (rows = Gaussians).  `fragile`: bool [rows] from the oracle (see the comment block
     above) -> STRICT comparison on the rest + BOUNDED comparison on everything; without it: one comparison with the strict
     quantile figures.  `regime`: which yardstick applies; `scale`: documented per-test widening factor; explicit *_tol values
-    replace the strict figures (tests of quantities with their own measured bounds)."""
+    replace the strict figures (tests of quantities with their own measured bounds).  `min_nonfragile`: the share of rows the
+    strict part must keep (default MIN_NONFRAGILE_FRACTION; the degenerate edge scenes -- three Gaussians, exact depth ties --
+    pass 0 and say why: there the bounded comparison is the test)."""
     got, ref = torch.as_tensor(got).detach().cpu(), torch.as_tensor(ref).detach().cpu()
     t_max, t_p99, t_p999 = (scale * t for t in grad_tolerance(name, regime))
     if p999_tol is not None and p99_tol is None:
@@ -208,10 +249,16 @@ def assert_grads_close(got, ref, name, maxnorm_tol=None, p999_tol=None, p99_tol=
     fragile = torch.as_tensor(fragile).cpu().bool()
     assert fragile.shape[0] == ref.shape[0], (fragile.shape, ref.shape)
     keep = ~fragile
+    if min_nonfragile is None:
+        min_nonfragile = MIN_NONFRAGILE_FRACTION
+    if not os.environ.get("VCR_GRAD_REPORT"):
+        assert int(keep.sum()) >= max(1 if min_nonfragile > 0 else 0, math.ceil(min_nonfragile * keep.numel())), \
+            f"grad {name}: only {int(keep.sum())} of {keep.numel()} rows are not under a fragile decision -- the strict comparison would be vacuous"
     st = grad_stats(got[keep], ref[keep])
     if maxnorm_tol is None:
-        strict[0] = scale * NONFRAGILE_MAXNORM_TOL
-    _report(name, f"non-fragile {int(keep.sum())}/{keep.numel()}", st, strict, int(ref[keep].numel()))
+        strict[0] = scale * (KNOWN_MISS_BOUND if known_miss(name) is not None else NONFRAGILE_MAXNORM_TOL)
+    if int(keep.sum()) > 0:
+        _report(name, f"non-fragile {int(keep.sum())}/{keep.numel()}", st, strict, int(ref[keep].numel()))
     st_all = grad_stats(got, ref)
     loose = [scale * t for t in grad_tolerance(name, regime, _FACTOR_ALL)]
     loose[0] = max(scale * ALL_MAXNORM_TOL, strict[0])
@@ -281,6 +328,7 @@ def sampled_tile_parity(device, cam, inp, dirs, bg, stride, min_inst, name, min_
     badmask = ((o - r).abs() > 2e-4 + 1e-4 * r.abs()).any(0)
     bad = int(badmask.sum())
     assert bad <= max(4, int(2e-3 * o.shape[1])), f"{bad} of {o.shape[1]} sampled pixels differ"
+    assert_psnr_parity(o[:3], r[:3], name, seed=stride)             # BASELINE.json's PSNR clause on the sampled pixels
     g = torch.Generator().manual_seed(stride)
     wgt = torch.randn(ref.shape, generator=g, dtype=torch.float64) * tmask[None]
     l32 = None
@@ -311,26 +359,8 @@ def sampled_tile_parity(device, cam, inp, dirs, bg, stride, min_inst, name, min_
         t = grad_tolerance(k, "full")
         own = grad_stats(a, b)
         return dict(maxnorm_tol=max(NONFRAGILE_MAXNORM_TOL, 3.0 * own["maxnorm"]), p99_tol=max(t[1], 3.0 * own["p99"]),
-                    p999_tol=max(t[2], 3.0 * own["p999"]))
+                    p999_tol=max(t[2], 3.0 * own["p999"]))        # (a rule the oracle computes; no row is dropped by its error)
 
-    if own_yardstick:
-        # A trained scene is a different scene every run (fp32 atomics steer the training), and its needle-shaped Gaussians are
-        # where a discrete decision can escape the fragility bound (GPUTEST r4 and two of this round's runs tripped on ONE row).
-        # Up to three rows (2e-4 of the ~15 000 of the subset) whose error exceeds the strict max-norm figure are therefore moved
-        # from the strict to the bounded comparison (max-norm < 3e-3 still holds for them); the quantiles judge the rest.
-        rows = int(hit.sum())
-        score = torch.zeros(rows, dtype=torch.float64)
-        for k in ["means3D", "shs", "normals", "opac", "scales", "rots", "m2"]:
-            if rl.get(k) is None or hl[k] is None:
-                continue
-            ref_k = rl[k].grad.reshape(rows, -1)
-            e = (hl[k].grad.cpu()[hit].double().reshape(rows, -1) - ref_k).abs().amax(1) / ref_k.abs().max().clamp_min(1e-30)
-            score = torch.maximum(score, e)
-        score[~clean | fr] = 0.0
-        worst = torch.topk(score, min(3, rows)).indices
-        outl = torch.zeros(rows, dtype=torch.bool)
-        outl[worst] = score[worst] > NONFRAGILE_MAXNORM_TOL
-        fr = fr | outl
     nf = clean & ~fr
     for k in ["means3D", "shs", "normals", "opac", "scales", "rots", "m2", "sem"]:
         if rl.get(k) is None or hl[k] is None:
@@ -342,5 +372,4 @@ def sampled_tile_parity(device, cam, inp, dirs, bg, stride, min_inst, name, min_
     assert_grads_close(hl["m2d"].grad.cpu()[hit][clean][:, :2], rl["m2d"].grad[clean][:, :2], f"{name}:m2d", regime="full",
                        fragile=fr[clean],
                        **tol("m2d", l32["m2d"].grad[nf][:, :2] if l32 is not None else None, rl["m2d"].grad[nf][:, :2]))
-    return dict(instances=inst, flipped=bad, sampled_pixels=int(o.shape[1]), subset=int(hit.sum()), fragile=int(fr.sum()),
-                outliers=int(outl.sum()) if own_yardstick else 0)
+    return dict(instances=inst, flipped=bad, sampled_pixels=int(o.shape[1]), subset=int(hit.sum()), fragile=int(fr.sum()))

@@ -59,7 +59,7 @@ class VcrRasterArgs(C.Structure):
         ("normals_precomp", C.c_void_p), ("semantics_precomp", C.c_void_p), ("opacities", C.c_void_p),
         ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("dirs", C.c_void_p),
         ("colour_stream", C.c_void_p), ("colour_stream_hook", C.c_void_p), ("colour_stream_hook_user", C.c_void_p), ("sh_update", C.c_void_p), ("sort_stream", C.c_void_p),
-        ("quad_lists", C.c_int32), ("pad_", C.c_int32),
+        ("quad_lists", C.c_int32), ("forward_form", C.c_int32),
     ]
 
 

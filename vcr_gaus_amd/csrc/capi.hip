@@ -195,6 +195,7 @@ int validate(const VcrRasterArgs* a) {
     }
     if (a->f_count < 0 || a->f_count > 4) { vcr_set_error("f_count=%d unsupported (0..4)", a->f_count); return 1; }
     if (a->num_dist != 0 && a->f_count != 0) { vcr_set_error("num_dist needs f_count=0"); return 1; }
+    if (a->forward_form < 0 || a->forward_form > 2) { vcr_set_error("forward_form=%d unsupported (0 automatic, 1 uniform loop, 2 two-phase)", a->forward_form); return 1; }
     if (a->N == 0) {                            // empty model: data pointers may legitimately be NULL
         if (!a->bg) { vcr_set_error("bg is NULL"); return 1; }
         return 0;
@@ -456,7 +457,7 @@ extern "C" int vcr_rasterize_forward(const VcrRasterArgs* args, VcrForwardOut* o
         if (split_colour) VCR_HIP_CHECK_JOIN(hipStreamWaitEvent(st, colour_event(1), 0));
         {
             StageTimer tm(ST_COMPOSITE_FWD, st);
-            if (vcr_launch_composite_forward(a, g, b, im, *out, st)) return fail_joined();
+            if (vcr_launch_composite_forward(a, g, b, im, *out, st, a.forward_form == 2 || (a.forward_form == 0 && vcr_forward_two_phase(R, (int64_t)out->num_visible)))) return fail_joined();
         }
 #undef VCR_HIP_CHECK_JOIN
     } else {

@@ -166,6 +166,16 @@ __device__ unsigned int g_hithist[130];
 #else
 #define VCR_COUNT_HITS(BASE, MASK) do { } while (0)
 #endif
+// -DVCR_TPSTATS: instrumented build of the two-phase forward -- per-wave shader-clock sums of its three parts and its work counts,
+// read through vcr_debug_hit_histogram (out[2k], out[2k+1] = low / high word of counter k; profiles/r6_tp_stats.py):
+//   0 waves with a non-empty list, 1 cycles in total, 2 culling + staging, 3 phase 1, 4 phase 2, 5 flushes, 6 phase-2 iterations,
+//   7 survivors staged, 8 chunks, 9 candidates (bits handed to the pixel lanes), 10 longest wave (cycles), 11 hits
+#ifdef VCR_TPSTATS
+__device__ unsigned long long g_tpstats[16];
+#define VCR_TPS(X) X
+#else
+#define VCR_TPS(X)
+#endif
 // Survivors that hit at most this many pixels of the quad skip the 16-value wave reduction of the backward: their few lanes
 // add their 16 values to the GradRec directly (16 masked atomic instructions).  0 disables the path -- the default:
 // measured with 2 on the metric workload (28 % of the survivors hit <= 2 pixels, profiles/r3_hit_histogram_metric.txt):
@@ -424,6 +434,9 @@ _Pragma("unroll")                                                               
 #define VCR_FWD_TP 1
 #endif
 #define VCR_TP_CAP 64
+#ifndef VCR_TP_MAX_TILES_PER_GAUSSIAN
+#define VCR_TP_MAX_TILES_PER_GAUSSIAN 5      // frames with more 3-sigma tiles per visible Gaussian keep the v2 loop (vcr_forward_two_phase)
+#endif
 #ifndef VCR_TP_WAVES
 #define VCR_TP_WAVES 0           // 0: compiler's choice
 #endif
@@ -474,9 +487,9 @@ __global__ void __launch_bounds__(256) VCR_TP_ATTR composite_fwd_tp_kernel(VcrRa
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ float4 s_rec_all[4 * 5 * VCR_TP_CAP];       // per wave: 5 planes x 64 slots x 16 B
-    __shared__ uint2 s_rb_all[4 * 8];                      // per wave: 8 rows x 8 survivors, one byte each
+    __shared__ uint4 s_rb_all[4 * 32];                     // per wave: 8 pixel rows x 64 survivors, one byte each
     float4* const srec = s_rec_all + wv * 5 * VCR_TP_CAP;
-    uint2* const rbq = s_rb_all + wv * 8;
+    uint4* const rbq = s_rb_all + wv * 32;
     uint8_t* const rbb = reinterpret_cast<uint8_t*>(rbq);
     const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8 + (sub < 0 ? 0 : (sub & 1) * 4));
     const float Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8 + (sub < 0 ? 0 : (sub >> 1) * 4));
@@ -494,18 +507,27 @@ __global__ void __launch_bounds__(256) VCR_TP_ATTR composite_fwd_tp_kernel(VcrRa
     uint32_t last = 0;
     bool done = !pm.inside;
     int fill = 0;                                          // staged survivors of the current group (wave-uniform)
+    VCR_TPS(const long long ts_begin = clock64(); long long ts_p1 = 0; long long ts_p2 = 0; unsigned ts_flush = 0; unsigned ts_iter = 0;
+            unsigned ts_surv = 0; unsigned ts_chunks = 0; unsigned ts_cand = 0; unsigned ts_hits = 0;)
 
-    // one candidate of this lane: the staged record of slot SLOT (per-lane LDS addresses), the v2 loop's arithmetic
-#define VCR_TP_FETCH(R, SLOT)                                                                                 \
+    // one candidate of this lane: the staged record of slot SLOT (per-lane LDS addresses), the v2 loop's arithmetic.  The
+    // centre / conic half of a lane's NEXT candidate is fetched while the current one is shaded; the colour / normal half is
+    // fetched at the top of its own iteration (first used ~20 instructions later) into registers both buffers share.
+#define VCR_TP_FETCH01(R, SLOT)                                                                               \
     do {                                                                                                      \
         const int s_ = (SLOT);                                                                                \
-        R##0 = srec[s_]; R##1 = srec[VCR_TP_CAP + s_]; R##2 = srec[2 * VCR_TP_CAP + s_];                      \
-        R##3 = srec[3 * VCR_TP_CAP + s_]; R##p = s_;                                                          \
+        R##0 = srec[s_]; R##1 = srec[VCR_TP_CAP + s_]; R##p = s_;                                             \
+        asm volatile("" ::: "memory");                                                                        \
+    } while (0)
+#define VCR_TP_FETCH23(SLOT)                                                                                  \
+    do {                                                                                                      \
+        const int s_ = (SLOT);                                                                                \
+        C2 = srec[2 * VCR_TP_CAP + s_]; C3 = srec[3 * VCR_TP_CAP + s_];                                       \
         asm volatile("" ::: "memory");                                                                        \
     } while (0)
 #define VCR_TP_SHADE(R, ACT)                                                                                  \
     do {                                                                                                      \
-        const float4 r0 = R##0, r1 = R##1, r2 = R##2, r3 = R##3;                                              \
+        const float4 r0 = R##0, r1 = R##1, r2 = C2, r3 = C3;                                                  \
         const f2 gxy = {r0.x, r0.y}, sAC = {r0.z, r0.w};                                                      \
         f2 u; float hs;                                                                                       \
         const float e = gauss_exponent(gxy - fxy, sAC, r1.x, r1.y, u, hs);                                    \
@@ -535,6 +557,7 @@ __global__ void __launch_bounds__(256) VCR_TP_ATTR composite_fwd_tp_kernel(VcrRa
 _Pragma("unroll")                                                                                             \
             for (int k = 0; k < S; ++k) SM[k] = fmaf(w, sv_[k], SM[k]);                                       \
         }                                                                                                     \
+        VCR_TPS(ts_hits += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(hit)); ++ts_iter;)                  \
         T = hit ? test_T : T;                                                                                 \
         lslot = hit ? R##p : lslot;       /* (its list position is looked up once per group)                */ \
     } while (0)
@@ -546,19 +569,21 @@ _Pragma("unroll")                                                               
     do {                                                                                                      \
         uint32_t w_ = (WORD);                                                                                 \
         if (__builtin_amdgcn_ballot_w64(w_ != 0u) != 0) {                                                     \
-            float4 A0, A1, A2, A3, B0, B1, B2, B3; int Ap, Bp;                                                \
+            float4 A0, A1, B0, B1, C2, C3; int Ap, Bp;                                                        \
             int b_, nb_; bool act_, nact_;                                                                    \
             VCR_TP_POP(w_, b_, act_);                                                                         \
-            VCR_TP_FETCH(A, (BASE) + b_);                                                                     \
+            VCR_TP_FETCH01(A, (BASE) + b_);                                                                   \
             for (;;) {                                                                                        \
                 bool more_ = __builtin_amdgcn_ballot_w64(w_ != 0u) != 0;                                      \
+                VCR_TP_FETCH23(Ap);                                                                           \
                 VCR_TP_POP(w_, nb_, nact_);                                                                   \
-                VCR_TP_FETCH(B, (BASE) + nb_);                                                                \
+                VCR_TP_FETCH01(B, (BASE) + nb_);                                                              \
                 VCR_TP_SHADE(A, act_);                                                                        \
                 if (!more_) break;                                                                            \
                 more_ = __builtin_amdgcn_ballot_w64(w_ != 0u) != 0;                                           \
+                VCR_TP_FETCH23(Bp);                                                                           \
                 VCR_TP_POP(w_, b_, act_);                                                                     \
-                VCR_TP_FETCH(A, (BASE) + b_);                                                                 \
+                VCR_TP_FETCH01(A, (BASE) + b_);                                                               \
                 VCR_TP_SHADE(B, nact_);                                                                       \
                 if (!more_) break;                                                                            \
             }                                                                                                 \
@@ -569,83 +594,160 @@ _Pragma("unroll")                                                               
     do {                                                                                                      \
         uint32_t w_ = (WORD);                                                                                 \
         while (__builtin_amdgcn_ballot_w64(w_ != 0u) != 0) {                                                  \
-            float4 A0, A1, A2, A3; int Ap;                                                                    \
+            float4 A0, A1, C2, C3; int Ap;                                                                    \
             int b_; bool act_;                                                                                \
             VCR_TP_POP(w_, b_, act_);                                                                         \
-            VCR_TP_FETCH(A, (BASE) + b_);                                                                     \
+            VCR_TP_FETCH01(A, (BASE) + b_);                                                                   \
+            VCR_TP_FETCH23(Ap);                                                                               \
             VCR_TP_SHADE(A, act_);                                                                            \
         }                                                                                                     \
     } while (0)
 #endif
-    // phase 1 + phase 2 over the `fill` staged survivors
+    // Phase 1 for the `fill` staged survivors: all steps write their row bytes (row r of the quad owns 64 consecutive bytes, byte
+    // 8 * step + j = survivor 8 * step + j), ONE LDS round trip, then pixel lane (x, y) pulls bit x out of the 64 bytes of row y:
+    // per 4 bytes a shift, a mask and a v_dot4_u32_u8 with the weights (1, 2, 4, 8) / (16, 32, 64, 128).
+#define VCR_TP_ROWBYTE(ST)                                                                                    \
+    do {                                                                                                      \
+        const int slot_ = 8 * (ST) + (lane >> 3);                                                             \
+        const float4 g_ = srec[slot_], p_ = srec[4 * VCR_TP_CAP + slot_];                                     \
+        const float dy_ = (g_.y - Y0) - (float)(lane & 7);                                                    \
+        const float D_ = fmaf(-p_.z, dy_ * dy_, p_.y);                                                        \
+        const float h_ = __builtin_amdgcn_sqrtf(fmaxf(D_, 0.f)) * 1.00001f + 0.01f;                           \
+        const float xc_ = fmaf(p_.x, dy_, g_.x - X0);                                                         \
+        const float lo_ = fmaxf(ceilf(xc_ - h_), 0.f), hi_ = fminf(floorf(xc_ + h_), 7.f);                    \
+        const bool ok_ = D_ >= 0.f && lo_ <= hi_;                                                             \
+        const uint32_t row_ = ok_ ? (2u << (int)hi_) - (1u << (int)lo_) : 0u;                                 \
+        rbb[(lane & 7) * 64 + 8 * (ST) + (lane >> 3)] = (uint8_t)row_;                                        \
+    } while (0)
+#define VCR_TP_BITS(V0, V1, SH)                                                                               \
+    (__builtin_amdgcn_udot4(((V1) >> (lane & 7)) & 0x01010101u, 0x80402010u,                                  \
+                            __builtin_amdgcn_udot4(((V0) >> (lane & 7)) & 0x01010101u, 0x08040201u, 0u, false), false) << (SH))
 #define VCR_TP_FLUSH()                                                                                        \
     do {                                                                                                      \
         __builtin_amdgcn_wave_barrier();                                                                      \
-        unsigned long long my_ = 0ull;                                                                        \
+        VCR_TPS(const long long tf0_ = clock64(); ++ts_flush;)                                                \
         const int steps_ = (fill + 7) >> 3;                                                                   \
-        for (int st_ = 0; st_ < steps_; ++st_) {                                                              \
-            const int slot_ = 8 * st_ + (lane >> 3);                                                          \
-            const float4 g_ = srec[slot_], p_ = srec[4 * VCR_TP_CAP + slot_];                                 \
-            const float dy_ = (g_.y - Y0) - (float)(lane & 7);                                                \
-            const float D_ = fmaf(-p_.z, dy_ * dy_, p_.y);                                                    \
-            const float h_ = __builtin_amdgcn_sqrtf(fmaxf(D_, 0.f)) * 1.00001f + 0.01f;                       \
-            const float xc_ = fmaf(p_.x, dy_, g_.x - X0);                                                     \
-            const float lo_ = fmaxf(ceilf(xc_ - h_), 0.f), hi_ = fminf(floorf(xc_ + h_), 7.f);                \
-            const bool ok_ = D_ >= 0.f && lo_ <= hi_ && slot_ < fill;                                         \
-            const uint32_t row_ = ok_ ? (2u << (int)hi_) - (1u << (int)lo_) : 0u;                             \
-            rbb[(lane & 7) * 8 + (lane >> 3)] = (uint8_t)row_;                                                \
-            __builtin_amdgcn_wave_barrier();                                                                  \
-            const uint2 v_ = rbq[lane >> 3];                                                                  \
-            __builtin_amdgcn_wave_barrier();                                                                  \
-            uint32_t a_ = (v_.x >> (lane & 7)) & 0x01010101u, b2_ = (v_.y >> (lane & 7)) & 0x01010101u;       \
-            a_ |= a_ >> 7; a_ |= a_ >> 14; b2_ |= b2_ >> 7; b2_ |= b2_ >> 14;                                 \
-            my_ |= (unsigned long long)((a_ & 0xFu) | ((b2_ & 0xFu) << 4)) << (8 * st_);                      \
+        for (int st_ = 0; st_ < steps_; ++st_) VCR_TP_ROWBYTE(st_);                                           \
+        __builtin_amdgcn_wave_barrier();                                                                      \
+        uint32_t lo_w = 0u, hi_w = 0u;                                                                        \
+        {                                                                                                     \
+            const uint4 v0_ = rbq[(lane >> 3) * 4], v1_ = rbq[(lane >> 3) * 4 + 1];                           \
+            lo_w = VCR_TP_BITS(v0_.x, v0_.y, 0) | VCR_TP_BITS(v0_.z, v0_.w, 8) | VCR_TP_BITS(v1_.x, v1_.y, 16) | VCR_TP_BITS(v1_.z, v1_.w, 24); \
         }                                                                                                     \
-        if (done) my_ = 0ull;                                                                                 \
+        if (steps_ > 4) {                                                                                     \
+            const uint4 v2_ = rbq[(lane >> 3) * 4 + 2], v3_ = rbq[(lane >> 3) * 4 + 3];                       \
+            hi_w = VCR_TP_BITS(v2_.x, v2_.y, 0) | VCR_TP_BITS(v2_.z, v2_.w, 8) | VCR_TP_BITS(v3_.x, v3_.y, 16) | VCR_TP_BITS(v3_.z, v3_.w, 24); \
+        }                                                                                                     \
+        __builtin_amdgcn_wave_barrier();                                                                      \
+        /* slots >= fill hold the previous group's survivors: cut the words there; pixels that are finished have no candidates */ \
+        const unsigned long long fm_ = fill >= 64 ? ~0ull : (1ull << fill) - 1ull;                            \
+        lo_w = done ? 0u : lo_w & (uint32_t)fm_;                                                              \
+        hi_w = done ? 0u : hi_w & (uint32_t)(fm_ >> 32);                                                      \
         int lslot = -1;                                                                                       \
-        VCR_TP_WALK((uint32_t)my_, 0);                                                                        \
-        VCR_TP_WALK((uint32_t)(my_ >> 32), 32);                                                               \
+        VCR_TPS(const long long tf1_ = clock64(); ts_p1 += tf1_ - tf0_;                                       \
+                { unsigned c_ = (unsigned)(__popc(lo_w) + __popc(hi_w)); for (int o_ = 32; o_ > 0; o_ >>= 1) c_ += (unsigned)__shfl_xor((int)c_, o_); ts_cand += c_; }) \
+        VCR_TP_WALK(lo_w, 0);                                                                                 \
+        if (steps_ > 4) VCR_TP_WALK(hi_w, 32);                                                                \
         if (lslot >= 0) last = __float_as_uint(srec[4 * VCR_TP_CAP + lslot].w);                               \
+        VCR_TPS(ts_p2 += clock64() - tf1_;)                                                                   \
         fill = 0;                                                                                             \
     } while (0)
 
     uint32_t pos = range.x;
+    // Chunk pipeline.  Only the first half of a record -- centre, opacity, conic: what the culling reads -- is gathered ahead of its
+    // chunk (VCR_TP_DEPTH chunks ahead, ids one further); the colour / normal half is fetched for the SURVIVORS only, when their
+    // first half is staged (same 64-byte record: it comes from the L1 / L2), and written to LDS one iteration LATER, behind the
+    // next chunk's culling -- waiting for it on the spot would also drain the head gathers behind it in the in-order vmcnt queue.
+#define VCR_GATHER_HEAD(ID, Q0, Q1)                                                 \
+    do {                                                                            \
+        const float4* _src = reinterpret_cast<const float4*>(rec + (ID));           \
+        Q0 = _src[0]; Q1 = _src[1];                                                 \
+    } while (0)
+#ifndef VCR_TP_DEPTH
+#define VCR_TP_DEPTH 1           // measured: 2 costs the fifth wave per SIMD (106 VGPRs) and loses 4 % (profiles/r6_fwd_variants.txt)
+#endif
     const float4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    uint32_t id, nid; float4 q0, q1, q2 = zero4, q3 = zero4; bool valid, nvalid;
+    uint32_t id, id1, id2 = 0u; float4 q0, q1, h1q0 = zero4, h1q1 = zero4; bool valid, valid1, valid2 = false;
     VCR_LOAD_ID(pos + lane, range.y, id, valid);
-    VCR_GATHER_REC(id, q0, q1, q2, q3);
-    VCR_LOAD_ID(pos + 64 + lane, range.y, nid, nvalid);
+    VCR_GATHER_HEAD(id, q0, q1);
+    VCR_LOAD_ID(pos + 64 + lane, range.y, id1, valid1);
+    if (VCR_TP_DEPTH > 1) {
+        VCR_GATHER_HEAD(id1, h1q0, h1q1);
+        VCR_LOAD_ID(pos + 128 + lane, range.y, id2, valid2);
+    }
+    float4 tq2 = zero4, tq3 = zero4; int tslot = -1;       // colour / normal half in flight for the survivor staged in slot tslot
+#define VCR_TP_LAND_TAILS()                                                                                   \
+    do {                                                                                                      \
+        if (tslot >= 0) {                                                                                     \
+            srec[2 * VCR_TP_CAP + tslot] = make_float4(tq2.x, tq2.y, tq2.z, tq3.x);                           \
+            srec[3 * VCR_TP_CAP + tslot] = make_float4(tq3.y, tq3.z, tq2.w, tq3.w);                           \
+        }                                                                                                     \
+        tslot = -1;                                                                                           \
+    } while (0)
     while (pos < range.y) {
-        uint32_t nnid; float4 nq0, nq1, nq2, nq3; bool nnvalid;
         const uint32_t npos = pos + 64;
-        VCR_GATHER_REC(nid, nq0, nq1, nq2, nq3);                      // records of the next chunk
-        VCR_LOAD_ID(npos + 64 + lane, range.y, nnid, nnvalid);       // ids of the chunk after that
+        uint32_t idn; bool validn; float4 hnq0, hnq1;
+        if (VCR_TP_DEPTH > 1) {
+            VCR_GATHER_HEAD(id2, hnq0, hnq1);                             // heads of chunk c + 2
+            VCR_LOAD_ID(npos + 128 + lane, range.y, idn, validn);        // ids of chunk c + 3
+        } else {
+            VCR_GATHER_HEAD(id1, hnq0, hnq1);                             // heads of chunk c + 1
+            VCR_LOAD_ID(npos + 64 + lane, range.y, idn, validn);         // ids of chunk c + 2
+        }
         float bx0, by0, bw, bh;
         live_box(__builtin_amdgcn_ballot_w64(!done), X0, Y0, bx0, by0, bw, bh);
         const bool keep = valid && quad_touch(q0, q1, bx0, by0, bw, bh);
         const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
         const int cnt = __popcll(m);
+        VCR_TP_LAND_TAILS();                                         // the previous chunk's survivors are complete now
         if (fill + cnt > VCR_TP_CAP) {                               // (wave-uniform)
             VCR_TP_FLUSH();
             if (__builtin_amdgcn_ballot_w64(!done) == 0) { pos = range.y; break; }        // every pixel of the quad has T < 1e-4
         }
         if (keep) {
+            const float4* src = reinterpret_cast<const float4*>(rec + id);
+            tq2 = src[2]; tq3 = src[3];
             const int slot = fill + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            tslot = slot;
             srec[slot] = make_float4(q0.x, q0.y, -VCR_L2E * q1.x, -VCR_L2E * q1.z);
             srec[VCR_TP_CAP + slot] = make_float4(-VCR_L2E * q1.y, __builtin_amdgcn_logf(q0.w), q0.z, q1.w);
-            srec[2 * VCR_TP_CAP + slot] = make_float4(q2.x, q2.y, q2.z, q3.x);
-            srec[3 * VCR_TP_CAP + slot] = make_float4(q3.y, q3.z, q2.w, q3.w);
             srec[4 * VCR_TP_CAP + slot] = span_params(q0, q1, X0, Y0, pos - range.x + (uint32_t)lane + 1u);
         }
         fill += cnt;
-        pos = npos; id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; valid = nvalid; nid = nnid; nvalid = nnvalid;
+        VCR_TPS(ts_surv += (unsigned)cnt; ++ts_chunks;)
+        pos = npos;
+        if (VCR_TP_DEPTH > 1) {
+            id = id1; q0 = h1q0; q1 = h1q1; valid = valid1;
+            id1 = id2; h1q0 = hnq0; h1q1 = hnq1; valid1 = valid2;
+            id2 = idn; valid2 = validn;
+        } else {
+            id = id1; q0 = hnq0; q1 = hnq1; valid = valid1;
+            id1 = idn; valid1 = validn;
+        }
     }
+    VCR_TP_LAND_TAILS();
     if (fill > 0) VCR_TP_FLUSH();
+#undef VCR_TP_LAND_TAILS
+#ifdef VCR_TPSTATS
+    if (lane == 0 && range.y > range.x) {
+        const long long tot = clock64() - ts_begin;
+        atomicAdd(&g_tpstats[0], 1ull); atomicAdd(&g_tpstats[1], (unsigned long long)tot);
+        atomicAdd(&g_tpstats[2], (unsigned long long)(tot - ts_p1 - ts_p2)); atomicAdd(&g_tpstats[3], (unsigned long long)ts_p1);
+        atomicAdd(&g_tpstats[4], (unsigned long long)ts_p2); atomicAdd(&g_tpstats[5], (unsigned long long)ts_flush);
+        atomicAdd(&g_tpstats[6], (unsigned long long)ts_iter); atomicAdd(&g_tpstats[7], (unsigned long long)ts_surv);
+        atomicAdd(&g_tpstats[8], (unsigned long long)ts_chunks); atomicAdd(&g_tpstats[9], (unsigned long long)ts_cand);
+        atomicMax(&g_tpstats[10], (unsigned long long)tot); atomicAdd(&g_tpstats[11], (unsigned long long)ts_hits);
+    }
+#endif
+#undef VCR_GATHER_HEAD
 #undef VCR_TP_FLUSH
+#undef VCR_TP_BITS
+#undef VCR_TP_ROWBYTE
 #undef VCR_TP_WALK
 #undef VCR_TP_POP
 #undef VCR_TP_SHADE
-#undef VCR_TP_FETCH
+#undef VCR_TP_FETCH23
+#undef VCR_TP_FETCH01
     if (pm.inside) {
         final_T[pm.pix] = T;
         n_contrib[pm.pix] = last;
@@ -1031,14 +1133,14 @@ _Pragma("unroll")                                                               
 
 template <int S, bool ISECT, int ND>
 int launch_fwd_fc(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o, int tiles,
-                  hipStream_t st) {
+                  hipStream_t st, bool two_phase) {
     const int gxc = a.quad_lists ? 2 * ((a.W + VCR_TILE - 1) / VCR_TILE) : 0;
 #define VCR_FWD_Q(FC, NDD, Q)                                                                                     \
     hipLaunchKernelGGL((composite_fwd_v2_kernel<S, ISECT, FC, NDD, Q>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
                        b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, o.out, o.count, o.score, im.t_ckpt)
 #define VCR_FWD(FC, NDD) do { if (gxc) { VCR_FWD_Q(FC, NDD, true); } else { VCR_FWD_Q(FC, NDD, false); } } while (0)
     if constexpr (VCR_FWD_TP != 0 && S <= 2) {
-        if (a.f_count == 0) {            // the training / evaluation render: two-phase form (the count modes keep the v2 loop)
+        if (a.f_count == 0 && two_phase) {   // the training / evaluation render of small footprints (the count modes keep the v2 loop)
             if (gxc)
                 hipLaunchKernelGGL((composite_fwd_tp_kernel<S, ISECT, ND, true>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec,
                                    b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, o.out);
@@ -1063,13 +1165,13 @@ int launch_fwd_fc(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im
 
 template <bool ISECT, int ND>
 int launch_fwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o, int tiles,
-                 hipStream_t st) {
+                 hipStream_t st, bool two_phase) {
     switch (a.S) {
-        case 0: return launch_fwd_fc<0, ISECT, ND>(a, g, b, im, o, tiles, st);
-        case 1: return launch_fwd_fc<1, ISECT, ND>(a, g, b, im, o, tiles, st);
-        case 2: return launch_fwd_fc<2, ISECT, ND>(a, g, b, im, o, tiles, st);
-        case 3: return launch_fwd_fc<3, ISECT, ND>(a, g, b, im, o, tiles, st);
-        default: return launch_fwd_fc<4, ISECT, ND>(a, g, b, im, o, tiles, st);
+        case 0: return launch_fwd_fc<0, ISECT, ND>(a, g, b, im, o, tiles, st, two_phase);
+        case 1: return launch_fwd_fc<1, ISECT, ND>(a, g, b, im, o, tiles, st, two_phase);
+        case 2: return launch_fwd_fc<2, ISECT, ND>(a, g, b, im, o, tiles, st, two_phase);
+        case 3: return launch_fwd_fc<3, ISECT, ND>(a, g, b, im, o, tiles, st, two_phase);
+        default: return launch_fwd_fc<4, ISECT, ND>(a, g, b, im, o, tiles, st, two_phase);
     }
 }
 
@@ -1131,7 +1233,18 @@ int vcr_dbg_acc64_end(int N, GradRec* sgrad, hipStream_t st) {
 #endif
 
 extern "C" int vcr_debug_hit_histogram(uint32_t out[130], int reset) {
-#ifdef VCR_HITHIST
+#ifdef VCR_TPSTATS
+    VCR_HIP_CHECK(hipDeviceSynchronize());
+    unsigned long long st[16];
+    VCR_HIP_CHECK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_tpstats), sizeof(st)));
+    for (int k = 0; k < 130; ++k) out[k] = 0;
+    for (int k = 0; k < 16; ++k) { out[2 * k] = (uint32_t)st[k]; out[2 * k + 1] = (uint32_t)(st[k] >> 32); }
+    if (reset) {
+        unsigned long long z[16] = {0};
+        VCR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tpstats), z, sizeof(z)));
+    }
+    return 0;
+#elif defined(VCR_HITHIST)
     VCR_HIP_CHECK(hipDeviceSynchronize());
     VCR_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hithist), sizeof(unsigned int) * 130));
     if (reset) {
@@ -1146,15 +1259,23 @@ extern "C" int vcr_debug_hit_histogram(uint32_t out[130], int reset) {
 #endif
 }
 
+// Which form of the forward shades this frame: the two-phase kernel wins where footprints are small (metric scene, R / V = 2.8
+// tiles per visible Gaussian: 183 against 212 us; c5: R / V = 1.9) and loses where a survivor covers a large part of its quad
+// (dense variant, R / V = 10.5: 289 against 274 us; full-frame variant: 338 against 292) -- profiles/r6_fwd_variants.txt.  Both
+// kernels write bit-identical images and image state, so the choice is invisible to the backward.
+bool vcr_forward_two_phase(int64_t tile_instances, int64_t visible) {
+    return VCR_FWD_TP != 0 && !VCR_T_ANCHOR && tile_instances <= (int64_t)VCR_TP_MAX_TILES_PER_GAUSSIAN * visible;
+}
+
 int vcr_launch_composite_forward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o,
-                                 hipStream_t st) {
+                                 hipStream_t st, bool two_phase) {
     const int tiles = ((a.W + VCR_TILE - 1) / VCR_TILE) * ((a.H + VCR_TILE - 1) / VCR_TILE);
     const bool isect = a.dirs != nullptr && a.normals_precomp != nullptr;
     if (a.num_dist == 2)
-        return isect ? launch_fwd_s<true, 2>(a, g, b, im, o, tiles, st) : launch_fwd_s<false, 2>(a, g, b, im, o, tiles, st);
+        return isect ? launch_fwd_s<true, 2>(a, g, b, im, o, tiles, st, two_phase) : launch_fwd_s<false, 2>(a, g, b, im, o, tiles, st, two_phase);
     if (a.num_dist == 1)
-        return isect ? launch_fwd_s<true, 1>(a, g, b, im, o, tiles, st) : launch_fwd_s<false, 1>(a, g, b, im, o, tiles, st);
-    return isect ? launch_fwd_s<true, 0>(a, g, b, im, o, tiles, st) : launch_fwd_s<false, 0>(a, g, b, im, o, tiles, st);
+        return isect ? launch_fwd_s<true, 1>(a, g, b, im, o, tiles, st, two_phase) : launch_fwd_s<false, 1>(a, g, b, im, o, tiles, st, two_phase);
+    return isect ? launch_fwd_s<true, 0>(a, g, b, im, o, tiles, st, two_phase) : launch_fwd_s<false, 0>(a, g, b, im, o, tiles, st, two_phase);
 }
 
 int vcr_launch_composite_backward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, const float* dL_dout,

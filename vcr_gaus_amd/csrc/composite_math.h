@@ -21,6 +21,17 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
+// Maximum over the 64 lanes (non-negative values), result valid in every lane.
+__device__ __forceinline__ int wave_max_i32(int x) {
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false));   // row_ror:8
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0xf, false));   // row_ror:4
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x122, 0xf, 0xf, false));   // row_ror:2
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x121, 0xf, 0xf, false));   // row_ror:1
+    x = max(x, __shfl_xor(x, 16));
+    x = max(x, __shfl_xor(x, 32));
+    return x;
+}
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 

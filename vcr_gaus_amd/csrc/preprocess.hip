@@ -513,17 +513,24 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
     if (!STAGE && !live) return;
     const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
 
-    // Arithmetic of the adjoint chain below: fp64 (round 5).  profiles/r5_grad_stage_errors.txt separated the stages: the
-    // screen-space sums the compositing backward leaves in the GradRec are as accurate as an fp32 evaluation of the oracle
-    // (error ratio ~1.0), the PARAMETER gradients were 2-5x worse -- the excess was made HERE: conic -> Sigma2D -> Sigma3D ->
-    // (scale, quaternion) and the Jacobian's dependence on the mean are sums of products that cancel for flat / needle-shaped
-    // Gaussians.  One lane handles one Gaussian and the kernel streams ~300 B for it: ~400 fp64 operations per Gaussian are
-    // free next to that (VCR_BWD_REAL=float: the round-1-4 arithmetic, for the A/B).
+    // Arithmetic of the adjoint chain below.  profiles/r5_grad_stage_errors.txt separated the stages: the screen-space sums the
+    // compositing backward leaves in the GradRec are as accurate as an fp32 evaluation of the oracle (error ratio ~1.0), the
+    // PARAMETER gradients were 2-5x worse -- the excess was made HERE: conic -> Sigma2D -> Sigma3D -> (scale, quaternion) and the
+    // Jacobian's dependence on the mean are sums of products that cancel for flat / needle-shaped Gaussians.  Round 5 ran the whole
+    // chain in fp64 (142 VGPRs, 3 waves per SIMD, +21 us at 1 M Gaussians).  Round 6 ships the MIXED form: fp64 only for what
+    // cancels -- Sigma3D, M = J W, Sigma2D, its determinant and the conic adjoint (ga, gb, gc) -- and fp32 behind them (106 VGPRs,
+    // 4 waves per SIMD, 129 against 143 us): the same error figures on c1 (profiles/r5_ratio_mixed_precision_experiment.txt) and
+    // the whole GPU suite in report mode (profiles/r6_grad_report_mixed_k4.txt, r6_grad_vs_1e-4.txt).
+    // -DVCR_BWD_MIXED=0 -DVCR_BWD_REAL=double: round 5's full-fp64 chain; -DVCR_BWD_MIXED=0 -DVCR_BWD_REAL=float: rounds 1-4.
 #ifndef VCR_BWD_MIXED
-#define VCR_BWD_MIXED 0            // 1 (with VCR_BWD_REAL=float): experiment, fp64 only up to the conic adjoint (see below)
+#define VCR_BWD_MIXED 1
 #endif
 #ifndef VCR_BWD_REAL
+#if VCR_BWD_MIXED
+#define VCR_BWD_REAL float
+#else
 #define VCR_BWD_REAL double
+#endif
 #endif
     typedef VCR_BWD_REAL BR;
     BR dp[3] = {0, 0, 0};                          // dL/dmeans3D
@@ -553,8 +560,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(VcrRasterArgs a, Ge
         }
         gr.finish(a.opacities[i]);
 #if VCR_BWD_MIXED
-        // Experiment build (round 5, unmeasured against the suite): fp64 only for what cancels -- Sigma3D, M = J W, Sigma2D, its
-        // determinant and the conic adjoint (ga, gb, gc) -- and the chain behind them in fp32 again (BR = float in this build).
+        // fp64 only for what cancels -- Sigma3D, M = J W, Sigma2D, its determinant and the conic adjoint (ga, gb, gc) -- and the
+        // chain behind them in fp32 again (BR = float in this build)
         float gaf, gbf, gcf;
         {
             typedef double DD;

@@ -225,7 +225,9 @@ int vcr_sort_pairs(int64_t n, const uint32_t* keys_in, const uint32_t* vals_in, 
 // gxc: 8x8 cells per row when `ranges` is per cell (quad-list mode), 0 when it is per tile
 int vcr_launch_tile_order(int T, const uint2* ranges, uint32_t* order, uint32_t* meta, int64_t instances, bool lpt, bool snake,
                           hipStream_t st, int gxc = 0);
+// two_phase: the form of the f_count = 0 forward (composite.hip); vcr_forward_two_phase decides it from the frame's counts
+bool vcr_forward_two_phase(int64_t tile_instances, int64_t visible);
 int vcr_launch_composite_forward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o,
-                                 hipStream_t st);
+                                 hipStream_t st, bool two_phase = false);
 int vcr_launch_composite_backward(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
                                   const float* dL_dout, GradRec* sgrad, float* sgrad_sem, hipStream_t st);

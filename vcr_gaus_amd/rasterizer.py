@@ -91,6 +91,8 @@ class RasterOptions:
       sort_stream      torch.cuda.Stream: depth keys + depth sort run there, beside the projection.
       quad_lists       bin the tile instances per 8x8 quad instead of per 16x16 tile (`VcrRasterArgs.quad_lists`): identical
                        results, fewer gathers in the compositing kernels, more sort entries -- pays for small footprints.
+      forward_form     "auto" (the library picks per frame from its counts), "uniform" or "two_phase": which kernel composites the
+                       frame (`VcrRasterArgs.forward_form`); bit-identical results -- a test / A-B switch.
       tail             an object with `.armed`, `.done` and `.tail()` -> (_lib.VcrGeometryStep, commit) or None (the trainer's
                        `GeometrySink`): when armed, the BACKWARD of this call applies the static tail of the training
                        iteration inside its projection-backward kernel (`vcr_rasterize_backward_tail`), calls `commit()`,
@@ -99,16 +101,20 @@ class RasterOptions:
                        render's fused activation (the trainer's `GeometrySink`): the backward then returns dL/dnormals as the
                        gradient w.r.t. the WORLD-space axis column (`VcrBackwardIO.normals_Rw2c`) -- the form the ranks of a
                        data-parallel step can sum before the one-kernel tail."""
-    __slots__ = ("sh_grad", "colour_stream", "colour_hook", "colour_sh_update", "sort_stream", "quad_lists", "tail", "world_normals")
+    __slots__ = ("sh_grad", "colour_stream", "colour_hook", "colour_sh_update", "sort_stream", "quad_lists", "tail", "world_normals",
+                 "forward_form")
 
     def __init__(self, sh_grad="full", colour_stream=None, colour_hook=None, colour_sh_update=None, sort_stream=None,
-                 quad_lists=False, tail=None, world_normals=None):
+                 quad_lists=False, tail=None, world_normals=None, forward_form="auto"):
         if sh_grad not in ("full", "rgb"):
             raise ValueError("sh_grad must be 'full' or 'rgb'")
         self.sh_grad, self.colour_stream, self.colour_hook = sh_grad, colour_stream, colour_hook
         self.colour_sh_update, self.sort_stream, self.quad_lists = colour_sh_update, sort_stream, bool(quad_lists)
         self.tail = tail
         self.world_normals = world_normals
+        if forward_form not in ("auto", "uniform", "two_phase"):
+            raise ValueError("forward_form must be 'auto', 'uniform' or 'two_phase'")
+        self.forward_form = forward_form
 
 
 DEFAULT_OPTIONS = RasterOptions()
@@ -198,6 +204,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         opts = DEFAULT_OPTIONS if opts is None else opts
         rec = RasterRecord() if rec is None else rec
         a.quad_lists = 1 if (opts.quad_lists and max(H, W) <= 8192) else 0
+        a.forward_form = {"auto": 0, "uniform": 1, "two_phase": 2}[opts.forward_form]
         hook = upd = None
         if opts.sort_stream is not None and fc == 0 and N > 0:
             a.sort_stream = opts.sort_stream.cuda_stream
