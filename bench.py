@@ -26,6 +26,15 @@ HBM_ACHIEVABLE_GBS = 6300.0   # what a streaming kernel reaches on this part (sa
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4.0   # wave64 VALU instructions / ns: 1024 SIMDs, one 4-cycle issue slot each at 2.4 GHz
 
 
+_T0 = time.perf_counter()
+
+
+def mark(what):
+    """progress to stderr (the one JSON line stays alone on stdout)"""
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench {time.perf_counter() - _T0:7.1f} s] {what}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,8 +49,9 @@ def parse():
     ap.add_argument("--arena", action="store_true", help="experiment: reserve the memory arena (Trainer.reserve_arena) at set-up")
     ap.add_argument("--side-cus", type=int, default=0, help="experiment: confine the side stream (SH update + SH -> RGB) to this "
                     "many compute units (0 = the whole chip)")
-    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "rs_ag"], help="collective for the 44 B / Gaussian "
-                    "geometry bucket on N > 1 GPUs: one all-reduce (RCCL's algorithm choice) or reduce-scatter + all-gather")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "allreduce", "rs_ag"], help="collective for the geometry bucket on "
+                    "N > 1 GPUs: one all-reduce (RCCL's algorithm choice), reduce-scatter + all-gather, or (auto) whichever is faster "
+                    "over a few untimed steps of this run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-context", action="store_true", help="skip the untimed context measurements (dense / full-frame variants, "
                     "schedule-inclusive window)")
@@ -57,7 +67,7 @@ def cpu_baseline(raw, cam, dirs, stride):
     value = 1 / (a + b * scale): an estimate of whole-iteration throughput in the metric's unit."""
     from oracle import model_torch as OM
     from oracle import raster_torch as OR
-    cores = min(os.cpu_count() or 1, 32)
+    cores = os.cpu_count() or 1            # SURVEY 8(d): all host cores
     torch.set_num_threads(cores)
     s = OR.Settings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
                     torch.zeros(3), 1.0, cam.world_view_transform.cpu(), cam.full_proj_transform.cpu(), 3,
@@ -105,7 +115,7 @@ def cpu_baseline(raw, cam, dirs, stride):
     t_tiles = min(runs[1:])
     scale = tm["tiles_total"] / max(tm["tiles_done"], 1)
     est = t_pre + t_tiles * scale
-    return {"value": 1.0 / est, "unit": "iters/s", "cores": cores, "kind": "port",
+    return {"value": 1.0 / est, "unit": "iters/s", "cores": cores, "kind": "port", "estimated": True,
             "sample": f"oracle/raster_torch.py fp32, {cores} threads: per-Gaussian stage fwd+bwd on all {N} Gaussians "
                       f"({t_pre:.1f} s, best of 2) + binning/compositing fwd+bwd of {tm['tiles_done']}/{tm['tiles_total']} tiles over "
                       f"the {n2} Gaussians touching them ({t_tiles:.1f} s, best of 2 after a warm-up, scaled x{scale:.0f}); "
@@ -164,7 +174,7 @@ def cpu_loss_chain(H, W):
 
 def pmc_value(counter, kernel="composite_fwd", names=("sq", "grbm")):
     import csv
-    for rnd in ("r5", "r4", "r3", "r2", "r1"):
+    for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):
         for name in names:
             path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{name}.csv")
             if os.path.exists(path):
@@ -190,14 +200,14 @@ def valu_block(R, ms_fwd, workload):
     return out
 
 
-def pmc_traffic(kernel="composite_fwd_v2_kernel"):
+def pmc_traffic(kernel="composite_fwd_"):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes
     (profiles/r<N>_pmc_fetch.csv, r<N>_pmc_write.csv; separate --pmc runs of THIS command on the metric workload).
     FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane loads, hence
     the x2 the MI355X guide prescribes (uncalibrated for this gather pattern)."""
     import csv
     vals = {}
-    rnd = next((r for r in ("r5", "r4", "r3", "r2", "r1") if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_pmc_fetch.csv"))), "r1")
+    rnd = next((r for r in ("r6", "r5", "r4", "r3", "r2", "r1") if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_pmc_fetch.csv"))), "r1")
     pmc_traffic.source = f"profiles/{rnd}_pmc_{{fetch,write}}.csv (rocprofv3 --pmc, separate passes)"
     meta = os.path.join(ROOT, "profiles", f"{rnd}_pmc_meta.json")
     pmc_traffic.meta = json.load(open(meta)) if os.path.exists(meta) else None      # R / R' / camera of the counter passes
@@ -260,7 +270,7 @@ def measure_variant(name, dev, steps=30):
                          "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": alg, "avg_ms": ms_fwd}}
 
 
-def schedule_inclusive(trainer, iters=200, warm_iters=100):
+def schedule_inclusive(trainer, iters=200, warm_iters=100, world=1, dev=None):
     """What a training run costs per iteration WITH the reference's schedule inside the window ('densify
     amortised'): the headline trainer continues with densification switched on at the reference's interval of 100
     (`configs/config_base.yaml`), each densify-and-prune preceded (tnt preset) by the 200 visibility renders at 1500 x 1500 of
@@ -293,10 +303,14 @@ def schedule_inclusive(trainer, iters=200, warm_iters=100):
 
     warm_dt, warm_sizes, warm_event = window(warm_iters, 10 ** 6)
     dt, sizes, events = window(iters, 2 * 10 ** 6)
+    if world > 1:                                        # the slowest rank counts
+        t3 = torch.tensor([warm_dt, dt, events, warm_event], device=dev, dtype=torch.float64)
+        dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+        warm_dt, dt, events, warm_event = (float(x) for x in t3)
     o.densify_from_iter, o.densification_interval, o.densify_until_iter = keep
     dl = o.densify_large
     vis = dl.sample_cams.num if (dl.percent_dense and dl.sample_cams.num > 0) else 0
-    return {"iters": iters, "ms_per_iter": 1e3 * dt / iters, "iters_per_s": iters / dt, "densify_steps": len(sizes),
+    return {"iters": iters, "ms_per_iter": 1e3 * dt / iters, "iters_per_s": iters / dt, "densify_steps": len(sizes), "densification_interval": 100,
             "visibility_renders_per_densify": vis, "gaussians_start": n0, "gaussians_after_each_densify": warm_sizes + sizes,
             "densify_event_ms": 1e3 * events / max(len(sizes), 1),
             "untimed_first_window": {"iters": warm_iters, "ms_per_iter": 1e3 * warm_dt / max(warm_iters, 1),
@@ -353,8 +367,8 @@ def main():
     if smult != 1.0:
         raw["scaling"] = raw["scaling"] + math.log(smult)
     cams = synthetic.make_cameras(max(args.views, world), W, H, focal, radius=synthetic.camera_radius(args.workload), device=dev)
-    trainer = BenchTrainer(raw, cams, dev, world=world, rank=rank, preset=args.preset, exchange=args.exchange, side_cus=args.side_cus,
-                           arena=args.arena)
+    trainer = BenchTrainer(raw, cams, dev, world=world, rank=rank, preset=args.preset,
+                           exchange="allreduce" if args.exchange == "auto" else args.exchange, side_cus=args.side_cus, arena=args.arena)
     if args.quad_below is not None:
         trainer.tr.quad_lists_below = args.quad_below
 
@@ -363,7 +377,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    mark("set-up done, priming")
     trainer.prime()              # set-up (allocator sizes of every camera), then the W warm-up steps of the contract
+    exchange_probe = None
+    if world > 1 and args.exchange == "auto":
+        # which collective carries the geometry bucket: both forms are timed over a few untimed steps of THIS run (xGMI is
+        # point-to-point: the ring all-reduce and reduce-scatter + all-gather load the links differently); every rank sees the
+        # same maxima and therefore makes the same choice
+        exchange_probe = {}
+        for algo in ("allreduce", "rs_ag"):
+            trainer.tr.exchange_algo = algo
+            for i in range(3):
+                trainer.step(-100 - i)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(8):
+                trainer.step(-200 - i)
+            sync()
+            tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            exchange_probe[algo] = 1e3 * float(tt) / 8
+        trainer.tr.exchange_algo = min(exchange_probe, key=exchange_probe.get)
     for i in range(args.warmup):
         trainer.step(i)
     sync()
@@ -393,15 +427,46 @@ def main():
     prof_all = _lib.profile_read()
     prof_all["composite_fwd"] = prof["composite_fwd"]
     _lib.profile_enable(False)
+    exchange_diag = None
+    if world > 1:                 # untimed: the same steps once more with HIP events around every step's collectives
+        trainer.tr.exchange_timing = {"events": []}
+        for i in range(min(args.steps, 20)):
+            trainer.step(args.warmup + 2 * args.steps + i)
+        sync()
+        exchange_diag = trainer.tr.exchange_report()
+        trainer.tr.exchange_timing = None
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)                                  # every rank adds one: how many really took part
+        if exchange_diag is not None:
+            exchange_diag["rccl_ranks_seen"] = int(seen.item())
+            exchange_diag["probe_ms_per_step"] = exchange_probe
+            exchange_diag["chosen"] = trainer.tr.exchange_algo
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt)
+    # SURVEY 8(d) defines the metric "densify amortised": the reference's schedule (densify_and_prune every 100 iterations, each
+    # preceded -- tnt preset -- by the 200 visibility renders of `densify_large`) is measured right here, on every rank (its
+    # visibility cameras are sharded over the ranks and the counts all-reduced), and folded into `value` below
+    # what the timed steps worked on (the schedule measurement below grows the model)
+    mark("timed steps + stage pass done")
+    last_R, last_E, last_V = trainer.last_R, trainer.last_E, trainer.last_V
+    snap = {"exchange": trainer.exchange(), "step": trainer.describe(), "quad_lists": bool(trainer.tr._quad_on),
+            "static_tail": getattr(trainer.tr, "last_tail", None),
+            "activation_prefetch": bool(getattr(trainer.tr, "prefetch_activation", False)) and getattr(trainer.tr, "last_tail", None) != "modular"}
+    shape = trainer.scene_shape() if rank == 0 else None       # one extra (untimed) debug render: longest tile list, covered pixels
+    dense_variant = None
+    if world == 1 and args.workload == "metric_1m_1080p" and not args.no_context:
+        dense_variant = trainer.dense_variant_roofline(3.5, HBM_PEAK_GBS, sem)
+    mark("scene shape / dense variant done")
+    sched = None
+    if not args.no_context:
+        sched = schedule_inclusive(trainer, world=world, dev=dev)
+    mark("schedule-inclusive window done")
 
     if rank == 0:
         P = W * H
-        R = trainer.last_R
-        E, V = trainer.last_E, trainer.last_V
+        R, E, V = last_R, last_E, last_V
         ms_fwd = prof["composite_fwd"][0] / max(prof["composite_fwd"][1], 1)
         alg_bytes = (60 + 4 * sem) * R + (4 * (8 + sem) + 20) * P
         achieved = alg_bytes / (ms_fwd * 1e-3) / 1e9 if ms_fwd > 0 else 0.0
@@ -418,23 +483,35 @@ def main():
         ach_bwd = alg_bwd / (ms_bwd * 1e-3) / 1e9 if ms_bwd > 0 else 0.0
         traffic_bwd = pmc_traffic("composite_bwd_rows_kernel") if args.workload == "metric_1m_1080p" else None
         raster_fwd_ms = sum(stages[k] for k in ["preprocess", "depth_sort_scan", "binning", "composite_fwd"])
-        shape = trainer.scene_shape()            # one extra (untimed) debug render: longest tile list, covered pixels
+        steady_ms = 1e3 * dt / args.steps                       # the K timed steps of the contract (densify / prune not among them)
+        if sched is not None and sched["densify_steps"] > 0:
+            # one iteration in `densification_interval` carries the visibility passes + densify_and_prune instead of being an
+            # ordinary one: amortised ms / iteration = steady + (event - steady) / interval
+            amort_ms = steady_ms + max(sched["densify_event_ms"] - steady_ms, 0.0) / sched["densification_interval"]
+            value_is = ("SURVEY 8(d) 'densify amortised': views/s (= optimizer iterations/s x n_gpus) with the reference's schedule "
+                        "folded in -- ms/iteration = ms_per_step_steady + (densify_event_ms - ms_per_step_steady) / densification_interval; "
+                        "ms_per_step_steady is the wall clock of the K timed steps, densify_event_ms the drained iteration that carries the "
+                        "visibility passes + densify_and_prune, both measured in this run (`schedule_inclusive` holds the raw window)")
+        else:
+            amort_ms = steady_ms
+            value_is = "views/s = optimizer iterations/s x n_gpus over the K timed steps (steady state: --no-context skips the schedule measurement)"
         line = {
-            "metric": "train iters/sec @1M Gaussians 1080p (full step: render fwd, losses, bwd, optimizer)",
-            "value": world * args.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+            "metric": "train iters/sec @1M Gaussians 1080p (full step: render fwd, losses, bwd, optimizer; densify amortised)",
+            "value": world * 1e3 / amort_ms, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             # one camera per rank per optimizer iteration: `value` is the whole-job aggregate in VIEWS (= iterations x ranks)
-            "iters_per_s": args.steps / dt, "views_per_s": world * args.steps / dt,
-            "value_is": "views/s = optimizer iterations/s x views per iteration (n_gpus); equal to iters/s on one GPU",
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "iters_per_s": 1e3 / amort_ms, "views_per_s": world * 1e3 / amort_ms,
+            "value_is": value_is,
+            "value_steady": world * args.steps / dt, "ms_per_step_steady": steady_ms,
+            "warmup": args.warmup, "ms_per_step": amort_ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "preset": args.preset, "scale_mult": smult, "gaussians": n, "width": W, "height": H, "sh_degree": 3,
-                       "views_per_step": world, "tile_instances_R": R, "emitted_instances": trainer.last_E, "visible_V": trainer.last_V,
+                       "views_per_step": world, "tile_instances_R": R, "emitted_instances": E, "visible_V": V,
                        "max_tile_len": shape["max_tile_len"], "covered_pixels": shape["covered_pixels"],
-                       "exchange": trainer.exchange(), "exchange_collective": args.exchange if world > 1 else None,
-                       "step": trainer.describe(), "ranks": world, "side_stream_cus": args.side_cus or None,
-                       "quad_lists_below": trainer.tr.quad_lists_below, "quad_lists": bool(trainer.tr._quad_on), "arena_bytes": trainer.arena_bytes,
-                       "static_tail": getattr(trainer.tr, "last_tail", None),
-                       "activation_prefetch": bool(getattr(trainer.tr, "prefetch_activation", False)) and getattr(trainer.tr, "last_tail", None) != "modular",
+                       "exchange": snap["exchange"], "exchange_collective": trainer.tr.exchange_algo if world > 1 else None,
+                       "step": snap["step"], "ranks": world, "side_stream_cus": args.side_cus or None,
+                       "quad_lists_below": trainer.tr.quad_lists_below, "quad_lists": snap["quad_lists"], "arena_bytes": trainer.arena_bytes,
+                       "static_tail": snap["static_tail"],
+                       "activation_prefetch": snap["activation_prefetch"],
                        "dist_backend": (dist.get_backend() if world > 1 else None), "env_switches": switches()},
             "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": per_step[0], "max": per_step[-1], "slowest_step_index": in_order.index(per_step[-1]),
                         "note": "per-step GPU-timeline spread (events after every step); `value` uses the wall clock of all K steps"},
@@ -463,18 +540,26 @@ def main():
                              "bytes_are": "SURVEY 8(d) K7 lower bound: (60+4S) R + (8 C + 20) P + 2 (60+4S) V"},
         }
         if world == 1 and args.workload == "metric_1m_1080p" and not args.no_context:
-            line["roofline"]["dense_variant"] = trainer.dense_variant_roofline(3.5, HBM_PEAK_GBS, sem)
-            line["schedule_inclusive"] = schedule_inclusive(trainer)
-            # SURVEY 8(d) defines the metric "densify amortised": this is that figure, beside the steady-state `value`
-            line["value_densify_amortised"] = line["schedule_inclusive"]["iters_per_s"]
+            line["roofline"]["dense_variant"] = dense_variant
             del trainer
             torch.cuda.empty_cache()
             line["fullframe_variant"] = measure_variant("fullframe_1m_1080p", dev)
+            mark("full-frame variant done")
+        if sched is not None:
+            line["schedule_inclusive"] = sched
+            line["densify_event_ms"] = sched["densify_event_ms"]
+            # the same metric measured as one wall-clock window of 200 iterations with two real events inside (the later steps run
+            # on the grown model): a cross-check of `value`, not a second definition
+            line["value_densify_amortised"] = world * sched["iters_per_s"]
+        if exchange_diag is not None:
+            line["exchange"] = exchange_diag
         if world == 1 and not args.no_cpu_baseline:
             stride = args.cpu_tile_stride or max(1, ((W + 15) // 16) * ((H + 15) // 16) // 1024)
             dirs = get_all_px_dir(cams[0].intr, H, W)
             line["cpu_baseline"] = cpu_baseline(raw, cams[0], dirs, stride)
+            mark(f"cpu baseline done ({os.cpu_count()} host cores)")
             line["cpu_baseline"]["c1_full"] = cpu_baseline_c1()
+            mark("cpu baseline c1 done")
             line["cpu_baseline"]["loss_chain_ms"] = {"resolution": f"{W}x{H}", "value": cpu_loss_chain(H, W),
                                                       "what": "compute_normals + cos-weighted monosdf + l1 + ssim, fwd+bwd, oracle/losses_torch.py"}
         print(json.dumps(line))

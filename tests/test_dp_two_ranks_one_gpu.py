@@ -178,3 +178,21 @@ def test_bench_launches_the_ranks_it_is_asked_for(device):
     assert abs(line["views_per_s"] - 2 * line["iters_per_s"]) < 1e-6 * line["views_per_s"]
     assert line["config"]["exchange"].startswith("factorised")
     assert line["scaling"] == "weak" and line["value"] == line["views_per_s"]
+    # round 6: the first real multi-GPU run must explain itself -- HIP events around every step's collectives, how many ranks really
+    # took part, bytes per collective, and which of the two bucket collectives the warm-up probe chose
+    ex = line["exchange"]
+    assert ex["rccl_ranks_seen"] == 2 and ex["timed_steps"] >= 1 and ex["exchange_ms_exposed"] > 0.0
+    assert ex["bucket_bytes"] > 0 and ex["gather_bytes"] == 2 * 10_000 * 3 * 4 and ex["collectives_per_step"] >= 2
+    assert set(ex["probe_ms_per_step"]) == {"allreduce", "rs_ag"} and ex["chosen"] == ex["algorithm"] == line["config"]["exchange_collective"]
+    assert ex["chosen"] == min(ex["probe_ms_per_step"], key=ex["probe_ms_per_step"].get)
+    # ... and the headline carries the reference's schedule at every N: the same run WITH the schedule measurement (two ranks share
+    # the visibility cameras of each densification and all-reduce the counts)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "c1_10k_256", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    sch = line["schedule_inclusive"]
+    assert sch["densify_steps"] == 2 and sch["densification_interval"] == 100 and line["densify_event_ms"] > line["ms_per_step_steady"]
+    want = line["ms_per_step_steady"] + (line["densify_event_ms"] - line["ms_per_step_steady"]) / 100
+    assert abs(line["ms_per_step"] - want) < 1e-9 * want and abs(line["value"] - 2e3 / want) < 1e-6 * line["value"]
+    assert line["value"] < line["value_steady"]

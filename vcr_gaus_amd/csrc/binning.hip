@@ -2,8 +2,8 @@
 //
 // MI355X-first ordering scheme (not the 64-bit (tile|depth) key sort of the public rasterizer):
 //   1. radix-sort the N Gaussians once by their 32-bit view depth (8-byte pairs),
-//   2. emit (tile, id) instances in that depth order with a kernel that carries its own offsets scan (decoupled
-//      look-back).  Which tiles of its 3-sigma rectangle a Gaussian really reaches (alpha >= 1/255 at some pixel centre)
+//   2. emit (tile, id) instances in that depth order (offsets: a two-level scan of the per-Gaussian instance counts, round 6;
+//      rounds 2-5: a decoupled look-back inside the emission kernel).  Which tiles of its 3-sigma rectangle a Gaussian really reaches (alpha >= 1/255 at some pixel centre)
 //      was decided EXACTLY by the projection kernel and travels as a bit mask in the 8-byte rectangle record (round 3;
 //      rectangles of more than 32 tiles emit every tile),
 //   3. STABLE radix sort of the emitted R' instances on the tile bits only (ceil(log2 T) <= 14 bits -> 2 passes of
@@ -16,24 +16,53 @@
 
 namespace {
 
-constexpr unsigned long long ST_AGG = 1ull << 32, ST_PREFIX = 2ull << 32;
 constexpr int DUP_ROUNDS = 4;                       // Gaussians per thread: 1024 per block keeps the look-back chain short
 
-// Tile-instance emission with the offsets scan fused in.  A block takes 1024 Gaussians of the depth order (4 rounds of
-// 256), scans their instance counts (popcount of the tile mask, or width x height for the few rectangles without one),
-// obtains the number of instances before it by decoupled look-back over the status words of the earlier blocks (flag |
-// running total in ONE 64-bit word, so no data has to be ordered against the flag; the logical block order comes from an
-// atomic ticket, so forward progress does not depend on the dispatch order of the workgroups), and emits:
+// Tile-instance emission.  A block takes 1024 Gaussians of the depth order (4 rounds of 256), scans their instance counts (popcount
+// of the tile mask, or width x height for the few rectangles without one), adds the instances of the slices before it (see
+// duplicate_count_kernel below) and emits:
 //   * masked rectangles (<= 32 tiles, nearly all): every lane walks the set bits of ITS mask -- a handful of iterations
-//     (round 5 measured two variants of this kernel -- the block's piece of the output assembled in LDS and written as full
-//     lines, and the look-back by the whole block, 256 predecessors per step -- at 80.7 and 82.8 us against 78.4-80.7 us for
-//     this form at 1 M Gaussians: neither the scattered 8-byte stores nor the look-back chain is what the kernel waits for;
+//     (round 5 measured the block's piece of the output assembled in LDS and written as full lines: 80.7 against 78.4-80.7 us
+//     at 1 M Gaussians -- the scattered 8-byte stores are not what the kernel waits for;
 //     profiles/experiments/r5_emission_lds_staging_and_wide_lookback.patch);
 //   * unmasked giants: wave-cooperatively and load-balanced -- the wave's giant counts are prefix-summed in LDS and every
 //     lane binary-searches the Gaussian its slot belongs to, so a screen-filling Gaussian does not serialise a lane.
-// `status`: one 64-bit word per block, [call number `seq`: 30 bits | flag: 2 | value: 32] -- the buffer is library-owned and is
-// NOT cleared between calls (round 5): a word counts only if it carries this call's number (anything an earlier call left
-// reads as "not there yet"); `ticket`: one word, zero between calls (the block that draws the last ticket resets it).
+// `status`: library-owned words, one 32-bit slice sum per block since round 6 (rounds 2-5: 64-bit look-back words tagged with
+// the call number `seq`; `ticket`: their atomic block counter -- both parameters are kept for the callers, unused).
+// Round 6: the offsets of the emission come from a TWO-LEVEL scan instead of a ticketed decoupled look-back.  The look-back made
+// this kernel the most erratic one of the step (profiles/r5_bench_kernel_stats.csv: 95 us on average, 308 us at worst, sigma 36 us
+// for ~28 MB of traffic): a block can only finish when every block before it in ticket order has published, so one late
+// workgroup stalls all its successors.  Now `duplicate_count_kernel` sums the instance counts of each 1024-Gaussian slice of the
+// depth order (one word per slice, written to the library-owned status buffer), and the emission kernel adds up the words of the
+// slices before its own -- at most N / 1024 coalesced 4-byte loads per block -- and never waits for another workgroup.
+template <bool QL>
+__device__ __forceinline__ uint32_t instance_count(uint2 rc, uint32_t mhi) {
+    return (rc.x & VCR_RECT_MASKED) ? (uint32_t)(__popc(rc.y) + (QL ? __popc(mhi) : 0)) : (rc.y & 0xFFFFu) * (rc.y >> 16);
+}
+
+template <bool QL>
+__global__ void __launch_bounds__(256) duplicate_count_kernel(int N, const uint32_t* __restrict__ ids_sorted, const uint2* __restrict__ rect,
+                                                              const uint32_t* __restrict__ rect_hi, uint32_t* __restrict__ slice_sum) {
+    __shared__ uint32_t s_w[4];
+    const int base = blockIdx.x * (256 * 4);
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gi = base + r * 256 + (int)threadIdx.x;
+        if (gi < N) {
+            const uint32_t id = ids_sorted[gi];
+            const uint2 rc = rect[id];
+            uint32_t mhi = 0;
+            if (QL && (rc.x & (VCR_RECT_MASKED | VCR_RECT_MASK64)) == (VCR_RECT_MASKED | VCR_RECT_MASK64)) mhi = rect_hi[id];
+            c += instance_count<QL>(rc, mhi);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) slice_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
 template <bool QL>      // QL: 64-bit cell masks (upper word in rect_hi); the per-tile form compiles to its 32-bit walk
 __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, const uint32_t* __restrict__ ids_sorted,
                                                         unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket,
@@ -42,17 +71,18 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
                                                         int gx_keys) {
     __shared__ uint32_t s_gend[4][64], s_start[4][64], s_id[4][64];
     __shared__ int s_xmin[4][64], s_ymin[4][64], s_w[4][64];
-    __shared__ uint32_t s_wtot[DUP_ROUNDS][4], s_prefix, s_bid;
+    __shared__ uint32_t s_wtot[DUP_ROUNDS][4], s_before[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int gx = gx_keys;                             // keys per row: tiles, or 8x8 cells in quad-list mode (rect is in the same unit)
     for (int t = blockIdx.x * 256 + threadIdx.x; t < num_tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);   // empty tiles
-    if (threadIdx.x == 0) {
-        s_bid = atomicAdd(ticket, 1u);
-        if (s_bid == gridDim.x - 1) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every ticket is out
-    }
-    __syncthreads();
-    const int bid = (int)s_bid;
-    const unsigned long long tag = (unsigned long long)seq << 34;
+    const int bid = (int)blockIdx.x;
+    (void)ticket; (void)seq;
+    // instances emitted by the slices before this one (duplicate_count_kernel wrote one word per slice)
+    const uint32_t* slice_sum = reinterpret_cast<const uint32_t*>(status);
+    uint32_t before = 0;
+    for (int j = (int)threadIdx.x; j < bid; j += 256) before += slice_sum[j];
+    for (int o = 32; o > 0; o >>= 1) before += (uint32_t)__shfl_xor((int)before, o);
+    if (lane == 0) s_before[wv] = before;
     // round r of this block covers the Gaussians base + r*256 + tid of the depth order
     const int base = bid * (256 * DUP_ROUNDS);
     uint32_t id[DUP_ROUNDS], cnt[DUP_ROUNDS], inc[DUP_ROUNDS], mhi[DUP_ROUNDS];
@@ -79,37 +109,8 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
         if (lane == 63) s_wtot[r][wv] = v;
     }
     __syncthreads();
-    uint32_t agg = 0;
-#pragma unroll
-    for (int r = 0; r < DUP_ROUNDS; ++r) agg += s_wtot[r][0] + s_wtot[r][1] + s_wtot[r][2] + s_wtot[r][3];
-    if (wv == 0) {                                       // decoupled look-back by the first wave
-        uint32_t excl = 0;
-        if (bid > 0) {
-            if (lane == 0) __hip_atomic_store(status + bid, tag | ST_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int look = bid - 1;
-            for (;;) {
-                const int b = look - lane;
-                unsigned long long sv = ST_PREFIX;        // lanes past block 0 count as a zero prefix
-                if (b >= 0) {
-                    do { sv = __hip_atomic_load(status + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                    while ((sv >> 34) != (unsigned long long)seq || ((sv >> 32) & 3ull) == 0);
-                }
-                const unsigned long long pm = __builtin_amdgcn_ballot_w64(((sv >> 32) & 3ull) == 2);
-                const int first = pm ? __builtin_ctzll(pm) : 64;                 // nearest block with a full prefix
-                uint32_t v = lane <= first ? (uint32_t)sv : 0u;
-                for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-                excl += v;
-                if (pm) break;
-                look -= 64;
-            }
-        }
-        if (lane == 0) {
-            __hip_atomic_store(status + bid, tag | ST_PREFIX | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_prefix = excl;
-        }
-    }
-    __syncthreads();
-    uint32_t round_base = s_prefix;
+    uint32_t round_base = s_before[0] + s_before[1] + s_before[2] + s_before[3];
+
 #pragma unroll
     for (int r = 0; r < DUP_ROUNDS; ++r) {
         uint32_t wpre = 0;
@@ -221,7 +222,8 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
     const bool no_lpt = true, no_snake = true;       // test-only build: identity launch order (the counting sort of tile_order
                                                      // places tiles of equal length in the order its LDS atomics resolve)
 #else
-    const bool no_lpt = false, no_snake = false;     // (longest-first, folded launch order: DESIGN.md section 4 holds the A/B)
+    static const bool env_no_snake = getenv("VCR_NO_SNAKE") != nullptr;      // (experiment switch, round 6)
+    const bool no_lpt = false, no_snake = env_no_snake;     // (longest-first, folded launch order: DESIGN.md section 4 holds the A/B)
 #endif
     const int gx_tiles = (a.W + VCR_TILE - 1) / VCR_TILE;
     const bool ql = a.quad_lists != 0;
@@ -231,6 +233,10 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
         return vcr_launch_tile_order(num_tiles, ranges, tile_order, meta, 0, false, false, st, ql ? gx_keys : 0);   // identity order
     }
     const int blocks = (a.N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS);
+    if (ql)
+        hipLaunchKernelGGL(duplicate_count_kernel<true>, dim3(blocks), dim3(256), 0, st, a.N, ids_sorted, g.rect, g.rect_hi, (uint32_t*)status);
+    else
+        hipLaunchKernelGGL(duplicate_count_kernel<false>, dim3(blocks), dim3(256), 0, st, a.N, ids_sorted, g.rect, g.rect_hi, (uint32_t*)status);
     if (ql)
         hipLaunchKernelGGL(duplicate_kernel<true>, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, ticket, seq, g.rect,
                            g.rect_hi, inst, ranges, num_keys, gx_keys);

@@ -339,6 +339,10 @@ class Trainer:
         works = []
         gather = None
         drgb_all = None
+        timing = getattr(self, "exchange_timing", None)     # bench.py / tests: HIP events around the collectives of this step
+        if timing is not None:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         self.model.optimizer.grad_scale = 1.0 / self.world
         if self.factorised_sh:
             drgb = rec.take_sh_factors()[0].contiguous()
@@ -408,6 +412,29 @@ class Trainer:
                     self.model.optimizer.step(only={"f_dc", "f_rest"})
         for w in works:
             w.wait()
+        if timing is not None:
+            # launch of the first collective -> the stream has waited for the bucket: the part of the exchange the step cannot hide
+            # (the deferred all-gather of dL/drgb is not waited for here)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            timing["events"].append((ev0, ev1))
+            timing["bucket_bytes"] = int(flat.numel() * flat.element_size())
+            timing["gather_bytes"] = int(drgb_all.numel() * drgb_all.element_size()) if drgb_all is not None else 0
+            timing["collectives_per_step"] = len(works) + (1 if gather is not None else 0) + (1 if self.exchange_algo == "rs_ag" and self.world > 1 else 0)
+            timing["algorithm"] = self.exchange_algo
+            timing["ranks"] = int(dist.get_world_size()) if dist.is_initialized() else 1
+
+    def exchange_report(self):
+        """-> what the timed exchanges of this trainer did (after `exchange_timing = {"events": []}` was set and the stream has been
+        synchronised): mean / max milliseconds between the launch of a step's collectives and the point where the training stream
+        has waited for the bucket, bytes per collective, collectives per step, the algorithm and how many ranks took part."""
+        t = getattr(self, "exchange_timing", None)
+        if not t or not t.get("events"):
+            return None
+        ms = [a.elapsed_time(b) for a, b in t["events"]]
+        return {"exchange_ms_exposed": sum(ms) / len(ms), "exchange_ms_exposed_max": max(ms), "timed_steps": len(ms),
+                "bucket_bytes": t.get("bucket_bytes"), "gather_bytes": t.get("gather_bytes"),
+                "collectives_per_step": t.get("collectives_per_step"), "algorithm": t.get("algorithm"), "rccl_ranks_seen": t.get("ranks")}
 
     def _exchange_grads(self, overlap, surgery, rec=None, sink=None):
         """What happens between backward and the optimizer step.  Two-stream form (`overlap`, no surgery this iteration):
