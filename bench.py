@@ -59,6 +59,32 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Cores this process may really run on: the scheduler affinity mask, further limited by a cgroup CPU quota if one is set.
+    (os.cpu_count() reports the HOST's cores; round 6, first GPU run with torch.set_num_threads(os.cpu_count()): the baseline did
+    not finish within 15 minutes -- hundreds of spinning OpenMP threads on the cores the container is allowed.)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    cap = int(os.environ.get("VCR_CPU_BASELINE_THREADS", "0"))
+    return max(1, min(n, cap) if cap > 0 else n)
+
+
 def cpu_baseline(raw, cam, dirs, stride):
     """Oracle (torch CPU restatement, fp32) on a BOUNDED sample of the SAME workload, timed on the host cores:
       (a) the per-Gaussian stage (activations, normals, projection, SH) forward+backward over ALL N Gaussians;
@@ -67,8 +93,9 @@ def cpu_baseline(raw, cam, dirs, stride):
     value = 1 / (a + b * scale): an estimate of whole-iteration throughput in the metric's unit."""
     from oracle import model_torch as OM
     from oracle import raster_torch as OR
-    cores = os.cpu_count() or 1            # SURVEY 8(d): all host cores
+    cores = usable_cores()                 # SURVEY 8(d): all host cores this process is allowed to use
     torch.set_num_threads(cores)
+    mark(f"cpu baseline on {cores} threads (os.cpu_count() = {os.cpu_count()})")
     s = OR.Settings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
                     torch.zeros(3), 1.0, cam.world_view_transform.cpu(), cam.full_proj_transform.cpu(), 3,
                     cam.camera_center.cpu())
@@ -115,7 +142,7 @@ def cpu_baseline(raw, cam, dirs, stride):
     t_tiles = min(runs[1:])
     scale = tm["tiles_total"] / max(tm["tiles_done"], 1)
     est = t_pre + t_tiles * scale
-    return {"value": 1.0 / est, "unit": "iters/s", "cores": cores, "kind": "port", "estimated": True,
+    return {"value": 1.0 / est, "unit": "iters/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port", "estimated": True,
             "sample": f"oracle/raster_torch.py fp32, {cores} threads: per-Gaussian stage fwd+bwd on all {N} Gaussians "
                       f"({t_pre:.1f} s, best of 2) + binning/compositing fwd+bwd of {tm['tiles_done']}/{tm['tiles_total']} tiles over "
                       f"the {n2} Gaussians touching them ({t_tiles:.1f} s, best of 2 after a warm-up, scaled x{scale:.0f}); "

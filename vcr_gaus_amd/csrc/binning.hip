@@ -43,19 +43,17 @@ __device__ __forceinline__ uint32_t instance_count(uint2 rc, uint32_t mhi) {
 template <bool QL>
 __global__ void __launch_bounds__(256) duplicate_count_kernel(int N, const uint32_t* __restrict__ ids_sorted, const uint2* __restrict__ rect,
                                                               const uint32_t* __restrict__ rect_hi, uint32_t* __restrict__ slice_sum) {
+    // one Gaussian per thread, one word per 256 Gaussians of the depth order (four words per slice of the emission kernel): the
+    // kernel is two dependent gathers deep, so it wants many short workgroups, not few long ones (1 024 per workgroup: 33 us at 1 M)
     __shared__ uint32_t s_w[4];
-    const int base = blockIdx.x * (256 * 4);
+    const int gi = blockIdx.x * 256 + (int)threadIdx.x;
     uint32_t c = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int gi = base + r * 256 + (int)threadIdx.x;
-        if (gi < N) {
-            const uint32_t id = ids_sorted[gi];
-            const uint2 rc = rect[id];
-            uint32_t mhi = 0;
-            if (QL && (rc.x & (VCR_RECT_MASKED | VCR_RECT_MASK64)) == (VCR_RECT_MASKED | VCR_RECT_MASK64)) mhi = rect_hi[id];
-            c += instance_count<QL>(rc, mhi);
-        }
+    if (gi < N) {
+        const uint32_t id = ids_sorted[gi];
+        const uint2 rc = rect[id];
+        uint32_t mhi = 0;
+        if (QL && (rc.x & (VCR_RECT_MASKED | VCR_RECT_MASK64)) == (VCR_RECT_MASKED | VCR_RECT_MASK64)) mhi = rect_hi[id];
+        c = instance_count<QL>(rc, mhi);
     }
     for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
@@ -80,7 +78,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int N, int W, int H, con
     // instances emitted by the slices before this one (duplicate_count_kernel wrote one word per slice)
     const uint32_t* slice_sum = reinterpret_cast<const uint32_t*>(status);
     uint32_t before = 0;
-    for (int j = (int)threadIdx.x; j < bid; j += 256) before += slice_sum[j];
+    for (int j = (int)threadIdx.x; j < DUP_ROUNDS * bid; j += 256) before += slice_sum[j];     // (one word per 256 Gaussians)
     for (int o = 32; o > 0; o >>= 1) before += (uint32_t)__shfl_xor((int)before, o);
     if (lane == 0) s_before[wv] = before;
     // round r of this block covers the Gaussians base + r*256 + tid of the depth order
@@ -189,7 +187,8 @@ size_t vcr_binning_temp_bytes(int N, int64_t R, int tile_bits) {
 }
 
 // look-back status words of the emission kernel
-size_t vcr_duplicate_status_words(int N) { return (size_t)((N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS) + 2); }
+// 64-bit words of the library-owned status buffer: one 32-bit slice sum per 256 Gaussians since round 6
+size_t vcr_duplicate_status_words(int N) { return (size_t)((N + 511) / 512 + 2); }
 
 // depth order of the N Gaussians (ties by index): three stable passes over the 27 low bits of the depth keys (see vcr_common.h).
 // (pair_a, pair_b): N 8-byte records each -- pair_a holds the (key, id) records in that order afterwards; `totals`:
@@ -232,11 +231,11 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
         VCR_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_keys, st));
         return vcr_launch_tile_order(num_tiles, ranges, tile_order, meta, 0, false, false, st, ql ? gx_keys : 0);   // identity order
     }
-    const int blocks = (a.N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS);
+    const int blocks = (a.N + 256 * DUP_ROUNDS - 1) / (256 * DUP_ROUNDS), cblocks = (a.N + 255) / 256;
     if (ql)
-        hipLaunchKernelGGL(duplicate_count_kernel<true>, dim3(blocks), dim3(256), 0, st, a.N, ids_sorted, g.rect, g.rect_hi, (uint32_t*)status);
+        hipLaunchKernelGGL(duplicate_count_kernel<true>, dim3(cblocks), dim3(256), 0, st, a.N, ids_sorted, g.rect, g.rect_hi, (uint32_t*)status);
     else
-        hipLaunchKernelGGL(duplicate_count_kernel<false>, dim3(blocks), dim3(256), 0, st, a.N, ids_sorted, g.rect, g.rect_hi, (uint32_t*)status);
+        hipLaunchKernelGGL(duplicate_count_kernel<false>, dim3(cblocks), dim3(256), 0, st, a.N, ids_sorted, g.rect, g.rect_hi, (uint32_t*)status);
     if (ql)
         hipLaunchKernelGGL(duplicate_kernel<true>, dim3(blocks), dim3(256), 0, st, a.N, a.W, a.H, ids_sorted, status, ticket, seq, g.rect,
                            g.rect_hi, inst, ranges, num_keys, gx_keys);

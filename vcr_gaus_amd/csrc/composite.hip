@@ -208,32 +208,26 @@ __device__ unsigned long long g_tpstats[16];
 #else
 #define VCR_FWD_ATTR
 #endif
+// per wave: 4 (+1 with semantics outside the record) planes x 64 slots x 16 B  (conflict-free b128 writes)
+#define VCR_V2_WREC ((S > 0 && !(S <= 2 && FC == 0)) ? 320 : 256)
+// One work item of the uniform-loop forward: quad `wv` of `tile` (split items: 4x4 sub-block `sub`); `srec`: the wave's LDS planes.
 template <int S, bool ISECT, int FC, int ND, bool QL>
-__global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
-                                                               const float* __restrict__ semv,
-                                                               const uint32_t* __restrict__ point_list,
-                                                               const uint2* __restrict__ ranges,
-                                                               const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ meta,
-                                                               int num_tiles, int gxc, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                               float* __restrict__ moments, float* __restrict__ out,
-                                                               int32_t* __restrict__ count, float* __restrict__ score,
-                                                               float* __restrict__ ckpt) {
+__device__ __forceinline__ void fwd_v2_item(const VcrRasterArgs& a, const GeomRec* __restrict__ rec, const float* __restrict__ semv,
+                                            const uint32_t* __restrict__ point_list, const uint2* __restrict__ ranges, int gxc,
+                                            float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                            float* __restrict__ moments, float* __restrict__ out,
+                                            int32_t* __restrict__ count, float* __restrict__ score, float* __restrict__ ckpt,
+                                            int tile, int sub, int wv, float4* const srec) {
     const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
-    int sub;
-    const int tile = work_item(tile_order, meta, num_tiles, sub);
-    if (tile < 0) return;
-    const PixelMap pm = pixel_of_thread(tile, gx, a.W, a.H, sub);
-    const uint2 range = list_range<QL>(ranges, gxc, tile, gx, threadIdx.x >> 6);
+    const PixelMap pm = pixel_of_quad(tile, gx, a.W, a.H, sub, wv);
+    const uint2 range = list_range<QL>(ranges, gxc, tile, gx, wv);
     // this lane's slot in a checkpoint record: quad-local row-major pixel index
-    float* const ck = FC == 0 ? ckpt + ckpt_base<QL>(range.x, gxc, tile, gx, threadIdx.x >> 6) +
+    float* const ck = FC == 0 ? ckpt + ckpt_base<QL>(range.x, gxc, tile, gx, wv) +
                                     (size_t)((pm.y & 7) * 8 + (pm.x & 7)) : nullptr;
     const int P = a.H * a.W;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     // S <= 2 without count mode: the semantic features come with the record (GeomRec pad slots) and take the place of the id
     constexpr bool SEM_IN_REC = S > 0 && S <= 2 && FC == 0;
-    constexpr int WREC = (S > 0 && !SEM_IN_REC) ? 320 : 256;   // per wave: 4 (+1 with semantics) planes x 64 slots x 16 B
-    __shared__ float4 s_rec_all[4 * WREC];                // (conflict-free b128 writes)
-    float4* const srec = s_rec_all + wv * WREC;
     const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8 + (sub < 0 ? 0 : (sub & 1) * 4));
     const float Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8 + (sub < 0 ? 0 : (sub >> 1) * 4));
     const f2 fxy = {(float)pm.x, (float)pm.y};
@@ -416,6 +410,25 @@ _Pragma("unroll")                                                               
             }
         }
     }
+}
+
+template <int S, bool ISECT, int FC, int ND, bool QL>
+__global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
+                                                               const float* __restrict__ semv,
+                                                               const uint32_t* __restrict__ point_list,
+                                                               const uint2* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ meta,
+                                                               int num_tiles, int gxc, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                               float* __restrict__ moments, float* __restrict__ out,
+                                                               int32_t* __restrict__ count, float* __restrict__ score,
+                                                               float* __restrict__ ckpt) {
+    int sub;
+    const int tile = work_item(tile_order, meta, num_tiles, sub);
+    if (tile < 0) return;
+    const int wv = threadIdx.x >> 6;
+    __shared__ float4 s_rec_all[4 * VCR_V2_WREC];
+    fwd_v2_item<S, ISECT, FC, ND, QL>(a, rec, semv, point_list, ranges, gxc, final_T, n_contrib, moments, out, count, score, ckpt,
+                                      tile, sub, wv, s_rec_all + wv * VCR_V2_WREC);
 }
 
 // ================= forward, TWO-PHASE (round 6): every lane walks the list of ITS OWN candidates =============================
@@ -784,90 +797,6 @@ __global__ void __launch_bounds__(256) VCR_TP_ATTR composite_fwd_tp_kernel(VcrRa
     __shared__ uint4 s_rb_all[4 * 32];                     // per wave: 8 pixel rows x 64 survivors, one byte each
     fwd_tp_item<S, ISECT, ND, QL>(a, rec, point_list, ranges, gxc, final_T, n_contrib, moments, out, tile, sub, wv,
                                   s_rec_all + wv * 5 * VCR_TP_CAP, s_rb_all + wv * 32);
-}
-
-// ================= persistent form (round 6b): waves draw (tile, quad) work items from a queue in longest-first order =============
-// The block form makes every non-empty tile resident at once (1 240 tiles of the metric frame on 1 280 workgroup slots): each wave
-// gets a fifth of its SIMD, the launch lasts as long as its longest wave does at that share (profiles/r4_simd_balance.txt: 1 046
-// survivors against a mean of 424), and the SIMD slots of a tile's three lighter quads idle until its heaviest one is through
-// (slots are released per workgroup).  Here a launch is `k` waves per SIMD that stay for the whole launch and draw items -- one quad
-// of one tile -- from an atomic counter, heaviest tiles first: the long lists start at once with 1 / k of a SIMD each, and everything
-// else is packed around them as slots free up, wave by wave.  Items past the non-empty tiles (84 % of this frame) only write the
-// background and are drawn eight at a time.  Counters: meta[4] (items), meta[5] (background batches), zeroed by tile_order_kernel
-// and again by the wave that draws the last number -- every wave draws exactly one number past the end of each counter.
-// a quad nothing reaches: background colour, T = 1, no contributor (what fwd_tp_item writes for an empty list)
-template <int S, int ND>
-__device__ __forceinline__ void fwd_bg_item(const VcrRasterArgs& a, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                            float* __restrict__ moments, float* __restrict__ out, int tile, int wv) {
-    const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
-    const PixelMap pm = pixel_of_quad(tile, gx, a.W, a.H, -1, wv);
-    const size_t P = (size_t)a.H * a.W;
-    if (!pm.inside) return;
-    final_T[pm.pix] = 1.f;
-    n_contrib[pm.pix] = 0u;
-    out[0 * P + pm.pix] = 0.f + 1.f * a.bg[0];
-    out[1 * P + pm.pix] = 0.f + 1.f * a.bg[1];
-    out[2 * P + pm.pix] = 0.f + 1.f * a.bg[2];
-#pragma unroll
-    for (int k = 3; k < 8 + S + (ND == 2 ? 2 : (ND == 1 ? 1 : 0)); ++k) out[k * P + pm.pix] = 0.f;
-    if (ND == 1) { moments[pm.pix] = 0.f; moments[P + pm.pix] = 0.f; }
-}
-__device__ __forceinline__ uint32_t draw(uint32_t* ctr) {
-    uint32_t v = 0;
-    if ((threadIdx.x & 63) == 0) v = atomicAdd(ctr, 1u);
-    return v;
-}
-__device__ __forceinline__ int item_of(int i, const uint32_t* __restrict__ tile_order, int n_split, int& sub, int& wv) {
-    // the same mapping as work_item() with workgroup i >> 2 and wave i & 3
-    const int b = i >> 2;
-    wv = i & 3;
-    if (b < 4 * n_split) { sub = b & 3; return (int)tile_order[b >> 2]; }
-    sub = -1;
-    return (int)tile_order[b - 3 * n_split];
-}
-#define VCR_BG_BATCH 8
-template <int S, bool ISECT, int ND, bool QL>
-__global__ void __launch_bounds__(256) VCR_TP_ATTR composite_fwd_tp_persistent_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
-                                                               const uint32_t* __restrict__ point_list,
-                                                               const uint2* __restrict__ ranges,
-                                                               const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ meta,
-                                                               int num_tiles, int gxc, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                               float* __restrict__ moments, float* __restrict__ out) {
-    __shared__ float4 s_rec_all[4 * 5 * VCR_TP_CAP];
-    __shared__ uint4 s_rb_all[4 * 32];
-    const int pw = threadIdx.x >> 6;
-    float4* const srec = s_rec_all + pw * 5 * VCR_TP_CAP;
-    uint4* const rbq = s_rb_all + pw * 32;
-    const int n_split = (int)meta[0], n_ne = (int)meta[1];
-    const int n_dyn = 4 * (n_ne + 3 * n_split), n_items = 4 * (num_tiles + 3 * n_split);
-    const uint32_t n_waves = gridDim.x * 4u;
-    uint32_t nxt = draw(meta + 4);
-    for (;;) {
-        const int i = __builtin_amdgcn_readfirstlane((int)nxt);
-        if (i >= n_dyn) {
-            if ((uint32_t)i == (uint32_t)n_dyn + n_waves - 1u && (threadIdx.x & 63) == 0) __hip_atomic_store(meta + 4, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-        nxt = draw(meta + 4);                           // the next number travels while this item is walked
-        int sub, wv;
-        const int tile = item_of(i, tile_order, n_split, sub, wv);
-        fwd_tp_item<S, ISECT, ND, QL>(a, rec, point_list, ranges, gxc, final_T, n_contrib, moments, out, tile, sub, wv, srec, rbq);
-    }
-    const int n_bg = (n_items - n_dyn + VCR_BG_BATCH - 1) / VCR_BG_BATCH;
-    nxt = draw(meta + 5);
-    for (;;) {
-        const int j = __builtin_amdgcn_readfirstlane((int)nxt);
-        if (j >= n_bg) {
-            if ((uint32_t)j == (uint32_t)n_bg + n_waves - 1u && (threadIdx.x & 63) == 0) __hip_atomic_store(meta + 5, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-        nxt = draw(meta + 5);
-        for (int i = n_dyn + j * VCR_BG_BATCH; i < min(n_items, n_dyn + (j + 1) * VCR_BG_BATCH); ++i) {
-            int sub, wv;
-            const int tile = item_of(i, tile_order, n_split, sub, wv);
-            fwd_bg_item<S, ND>(a, final_T, n_contrib, moments, out, tile, wv);
-        }
-    }
 }
 
 // ---- shading macros of the compositing backward (one survivor, all 64 lanes = the whole 8x8 quad) ---------------------------
@@ -1244,60 +1173,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_RO
                                     rows_bias, rows_pair_cost, tile, sub, wv, s_rec_all + wv * VCR_BWD_WREC);
 }
 
-// persistent form (see composite_fwd_tp_persistent_kernel): only the quads of non-empty tiles are work items -- an empty list has no
-// gradient; counter meta[6]
-template <int S, bool ISECT, int ND, bool QL>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_ROWS_WAVES))) composite_bwd_rows_persistent_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
-                                                               const float* __restrict__ semv,
-                                                               const uint32_t* __restrict__ point_list,
-                                                               const uint2* __restrict__ ranges,
-                                                               const uint32_t* __restrict__ tile_order, uint32_t* __restrict__ meta,
-                                                               int num_tiles, int gxc, const float* __restrict__ final_T,
-                                                               const uint32_t* __restrict__ n_contrib,
-                                                               const float* __restrict__ moments, const float* __restrict__ ckpt,
-                                                               const float* __restrict__ dL_dout, GradRec* __restrict__ sgrad,
-                                                               float* __restrict__ sgrad_sem, int rows_bias, int rows_pair_cost) {
-    __shared__ float4 s_rec_all[4 * VCR_BWD_WREC];
-    float4* const srec = s_rec_all + (threadIdx.x >> 6) * VCR_BWD_WREC;
-    const int n_split = (int)meta[0], n_ne = (int)meta[1];
-    const int n_dyn = 4 * (n_ne + 3 * n_split);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    uint32_t nxt = draw(meta + 6);
-    for (;;) {
-        const int i = __builtin_amdgcn_readfirstlane((int)nxt);
-        if (i >= n_dyn) {
-            if ((uint32_t)i == (uint32_t)n_dyn + n_waves - 1u && (threadIdx.x & 63) == 0) __hip_atomic_store(meta + 6, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-        nxt = draw(meta + 6);
-        int sub, wv;
-        const int tile = item_of(i, tile_order, n_split, sub, wv);
-        bwd_rows_item<S, ISECT, ND, QL>(a, rec, semv, point_list, ranges, gxc, final_T, n_contrib, moments, ckpt, dL_dout, sgrad, sgrad_sem,
-                                        rows_bias, rows_pair_cost, tile, sub, wv, srec);
-    }
-}
-
-// Waves per SIMD of the persistent launches (0 = block form).  VCR_PERSIST_FWD / VCR_PERSIST_BWD override the defaults (experiments).
-int persist_k(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-int chip_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus = n;
-    }
-    return cus;
-}
-#ifndef VCR_PERSIST_FWD_DEFAULT
-#define VCR_PERSIST_FWD_DEFAULT 0
-#endif
-#ifndef VCR_PERSIST_BWD_DEFAULT
-#define VCR_PERSIST_BWD_DEFAULT 0
-#endif
-
 template <int S, bool ISECT, int ND>
 int launch_fwd_fc(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im, VcrForwardOut& o, int tiles,
                   hipStream_t st, bool two_phase) {
@@ -1308,17 +1183,6 @@ int launch_fwd_fc(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im
 #define VCR_FWD(FC, NDD) do { if (gxc) { VCR_FWD_Q(FC, NDD, true); } else { VCR_FWD_Q(FC, NDD, false); } } while (0)
     if constexpr (VCR_FWD_TP != 0 && S <= 2) {
         if (a.f_count == 0 && two_phase) {   // the training / evaluation render of small footprints (the count modes keep the v2 loop)
-            static const int pk = persist_k("VCR_PERSIST_FWD", VCR_PERSIST_FWD_DEFAULT);
-            if (pk > 0) {
-                if (gxc)
-                    hipLaunchKernelGGL((composite_fwd_tp_persistent_kernel<S, ISECT, ND, true>), dim3(chip_cus() * pk), dim3(256), 0, st, a, g.rec,
-                                       b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, o.out);
-                else
-                    hipLaunchKernelGGL((composite_fwd_tp_persistent_kernel<S, ISECT, ND, false>), dim3(chip_cus() * pk), dim3(256), 0, st, a, g.rec,
-                                       b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, o.out);
-                VCR_HIP_CHECK(hipGetLastError());
-                return 0;
-            }
             if (gxc)
                 hipLaunchKernelGGL((composite_fwd_tp_kernel<S, ISECT, ND, true>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec,
                                    b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, o.out);
@@ -1370,16 +1234,7 @@ int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
     for (int det = det_first; det < det_last; ++det)                                                             \
         hipLaunchKernelGGL((composite_bwd_rows_kernel<SS, ISECT, ND, Q>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
                            b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, im.t_ckpt, dL_dout, sgrad, sgrad_sem, rows_bias, rows_pair_cost, det);
-#ifdef VCR_DETERMINISTIC_BWD
-    const int pk = 0;
-#else
-    static const int pk = persist_k("VCR_PERSIST_BWD", VCR_PERSIST_BWD_DEFAULT);
-#endif
-#define VCR_BWD_PQ(SS, Q)                                                                                        \
-        hipLaunchKernelGGL((composite_bwd_rows_persistent_kernel<SS, ISECT, ND, Q>), dim3(chip_cus() * pk), dim3(256), 0, st, a, g.rec, g.sem, \
-                           b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, im.t_ckpt, dL_dout, sgrad, sgrad_sem, rows_bias, rows_pair_cost);
-#define VCR_BWD(SS) do { if (pk > 0) { if (gxc) { VCR_BWD_PQ(SS, true) } else { VCR_BWD_PQ(SS, false) } }           \
-                         else if (gxc) { VCR_BWD_Q(SS, true) } else { VCR_BWD_Q(SS, false) } } while (0)
+#define VCR_BWD(SS) do { if (gxc) { VCR_BWD_Q(SS, true) } else { VCR_BWD_Q(SS, false) } } while (0)
     switch (a.S) {
         case 0: VCR_BWD(0); break;
         case 1: VCR_BWD(1); break;
@@ -1388,7 +1243,6 @@ int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
         default: VCR_BWD(4); break;
     }
 #undef VCR_BWD
-#undef VCR_BWD_PQ
 #undef VCR_BWD_Q
     VCR_HIP_CHECK(hipGetLastError());
     return 0;

@@ -286,8 +286,7 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2* __
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (!lpt) {
         for (int i = t; i < T; i += 1024) order[i] = (uint32_t)i;
-        // (meta[1]: the persistent compositing launches treat the first meta[1] tiles of the order as work items -- all of them here)
-        if (t < VCR_BIN_META_WORDS) meta[t] = t == 3 ? (uint32_t)gxc : (t == 1 && instances > 0 ? (uint32_t)T : 0u);
+        if (t < VCR_BIN_META_WORDS) meta[t] = t == 3 ? (uint32_t)gxc : 0u;
         return;
     }
     __shared__ uint32_t s_ne, s_max, s_empty;
@@ -316,7 +315,6 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int T, const uint2* __
         // SIMDs stay full to the end and the 1.9x work of the split items costs more than their shorter chains return)
         if ((unsigned long long)s_max * (unsigned)split_slots <= (gxc ? 1ull : 4ull) * instances) S = 0;
         meta[0] = (uint32_t)S; meta[1] = s_ne; meta[2] = s_max; meta[3] = (uint32_t)gxc;
-        meta[4] = 0u; meta[5] = 0u; meta[6] = 0u; meta[7] = 0u;     // work counters of the persistent compositing launches
         s_empty = s_ne;                                  // the empty tiles follow the non-empty ones in launch order
     }
     // exclusive scan of the 2048 classes: 2 per lane, wave scan, 16 wave totals
