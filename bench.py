@@ -81,8 +81,7 @@ def usable_cores():
             break
         except (OSError, ValueError, IndexError):
             continue
-    cap = int(os.environ.get("VCR_CPU_BASELINE_THREADS", "0"))
-    return max(1, min(n, cap) if cap > 0 else n)
+    return max(1, n)
 
 
 def cpu_baseline(raw, cam, dirs, stride):

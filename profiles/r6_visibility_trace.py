@@ -27,4 +27,15 @@ for r in range(reps + 1):
     visi = tr.visibility_mask(vcams)
     torch.cuda.synchronize()
     dt = 1e3 * (time.perf_counter() - t0)
+    if r == reps:                      # what the cameras look like to the rasterizer: instances per camera, visible Gaussians
+        from vcr_gaus_amd.gaussian_renderer import visibility_counts  # noqa: F401
+        from vcr_gaus_amd import rasterizer as RZ
+        st = vcams[0]._stack
+        import math
+        from vcr_gaus_amd.gaussian_renderer import fused_activate, _cam_rotation
+        sc, ro, op = fused_activate(tr.model, vcams[0].camera_center, _cam_rotation(vcams[0], dev), False)
+        cnt, nr, nv = RZ.visibility_batch(st[0][:16], st[1][:16], st[2][:16], [math.tan(c.FoVx * 0.5) for c in vcams[:16]],
+                                          [math.tan(c.FoVy * 0.5) for c in vcams[:16]], int(vcams[0].image_height), int(vcams[0].image_width),
+                                          tr.model.get_xyz, op, sc, ro, None, 1.0, True, None, 0)
+        print("first 16 cameras: 3-sigma tile instances", nr, "visible", nv, flush=True)
     print(f"visibility batch {r}: {len(vcams)} cameras, {dt:.1f} ms, {dt / len(vcams) * 1e3:.0f} us per camera, visible {int(visi.sum())} of {visi.numel()}", flush=True)

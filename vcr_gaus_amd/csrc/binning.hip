@@ -221,8 +221,9 @@ int vcr_duplicate_and_sort(const VcrRasterArgs& a, GeomState g, const int32_t* r
     const bool no_lpt = true, no_snake = true;       // test-only build: identity launch order (the counting sort of tile_order
                                                      // places tiles of equal length in the order its LDS atomics resolve)
 #else
-    static const bool env_no_snake = getenv("VCR_NO_SNAKE") != nullptr;      // (experiment switch, round 6)
-    const bool no_lpt = false, no_snake = env_no_snake;     // (longest-first, folded launch order: DESIGN.md section 4 holds the A/B)
+    const bool no_lpt = false, no_snake = false;     // (longest-first, folded launch order: DESIGN.md section 4 holds the A/B; round 6 with
+                                                     //  the two-phase forward: fold on / off 178.7 / 178.3 us forward, 401 / 414 backward at
+                                                     //  the metric scene, profiles/r6_persistent_ab.txt rows blk / blkns)
 #endif
     const int gx_tiles = (a.W + VCR_TILE - 1) / VCR_TILE;
     const bool ql = a.quad_lists != 0;

@@ -331,6 +331,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                 None, None)
 
 
+# Defaults of the batched visibility passes: cameras in flight (0 = the library's 8) and 8x8-cell lists.  Round 6 measured both knobs
+# on the 200 virtual cameras of a densification at 1 M Gaussians (profiles/r6_visibility_ab.txt): 8 / 16 / 4 in flight 59.9 / 59.6 /
+# 66.5 ms per batch, cell lists 69.6 ms -- the defaults stay.
+VIS_INFLIGHT = 0
+VIS_QUAD_LISTS = 0
+
+
 @torch.no_grad()
 def visibility_batch(viewmatrices, projmatrices, campos, tanfovx, tanfovy, image_height, image_width, means3D, opacities,
                      scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0, flags_only=False, count=None,
@@ -359,7 +366,7 @@ def visibility_batch(viewmatrices, projmatrices, campos, tanfovx, tanfovy, image
     tx, ty = (_ct.c_float * max(B, 1))(*map(float, tanfovx)), (_ct.c_float * max(B, 1))(*map(float, tanfovy))
     nr, nv = (_ct.c_int64 * max(B, 1))(), (_ct.c_int32 * max(B, 1))()
     a = _lib.VcrVisibilityBatch(N=N, H=int(image_height), W=int(image_width), B=B, flags_only=int(bool(flags_only)),
-                                inflight=int(inflight), scale_modifier=float(scale_modifier), tanfovx=tx, tanfovy=ty,
+                                inflight=int(inflight) or VIS_INFLIGHT, quad_lists=VIS_QUAD_LISTS, scale_modifier=float(scale_modifier), tanfovx=tx, tanfovy=ty,
                                 viewmatrix=_ptr(t[0]), projmatrix=_ptr(t[1]), campos=_ptr(t[2]), means3D=_ptr(t[3]),
                                 opacities=_ptr(t[4]), scales=_ptr(t[5]), rotations=_ptr(t[6]), cov3D_precomp=_ptr(t[7]),
                                 count=count.data_ptr(), num_rendered=nr, num_visible=nv)
