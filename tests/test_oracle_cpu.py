@@ -259,6 +259,38 @@ def test_virtual_visibility_cameras_look_at_box_floor():
     assert SampleCam.batch(T[:0], 8, 8, 1.0, 1.0, device="cpu") == []
 
 
+def test_visibility_cameras_formed_ahead_are_the_on_demand_ones():
+    """Round 6: the trainer forms the NEXT densification's virtual cameras on a worker thread (`Trainer._visibility_cameras`).
+    Three consecutive requests with the worker on give the cameras three on-demand requests give -- same generator, same order."""
+    from types import SimpleNamespace
+    from vcr_gaus_amd.trainer import Trainer
+    sc = SimpleNamespace(random=True, num=7, up=True, around=True)
+
+    def requests(ahead, change_box_at=None):
+        me = SimpleNamespace(model=SimpleNamespace(trans=torch.tensor([0.2, -0.1, 0.3]), scale=torch.tensor([2.0, 1.5, 1.0])),
+                             gen=torch.Generator().manual_seed(5), device=torch.device("cpu"), prefetch_visibility_cameras=ahead,
+                             _vis_ahead=None)
+        out = []
+        for k in range(3):
+            if k == change_box_at:          # (a box that changed since the worker ran: its cameras are dropped, not used)
+                me.model.scale = torch.tensor([1.0, 1.0, 4.0])
+            out.append(Trainer._visibility_cameras(me, sc))
+        if me._vis_ahead is not None:
+            me._vis_ahead["thread"].join()
+        return out
+
+    a, b = requests(True), requests(False)
+    for ca, cb in zip(a, b):
+        assert len(ca) == len(cb) >= 7          # (up + around placement rounds its two shares)
+        for x, y in zip(ca, cb):
+            for f in ("world_view_transform", "full_proj_transform", "camera_center", "R_w2c"):
+                assert torch.equal(getattr(x, f), getattr(y, f)), f
+    assert not torch.equal(a[0][0].world_view_transform, a[1][0].world_view_transform)
+    c = requests(True, change_box_at=1)
+    assert bool(((c[1][0].camera_center - torch.tensor([0.2, -0.1, 0.3])).abs() <= torch.tensor([1.0, 1.0, 4.0]) + 1e-5).all())
+    assert not any(torch.equal(x.world_view_transform, y.world_view_transform) for x, y in zip(c[1], a[1]))    # (not the worker's cameras)
+
+
 def test_lazy_dictionaries_and_scoped_modes():
     """Host logic of the trimmed step: render / loss dictionaries materialise derived entries on read, rasterizer modes
     travel with the call (no module state), scratch sizes are rounded to 1/8-octave steps."""

@@ -179,6 +179,15 @@ def bb_camera_random(n, trans, scale, up=False, around=True, boundary=0.9, gener
 def sample_cameras(n, trans, scale, up=False, around=True, look_mode="target", sample_mode="random", bidirect=True,
                    device="cuda", generator=None, size=1500, fov=2.5):
     """`Trainer.sample_cameras` (`trainer.py:621-634`)."""
+    return SampleCam.batch_from_host(sample_cameras_host(n, trans, scale, up=up, around=around, look_mode=look_mode,
+                                                         sample_mode=sample_mode, bidirect=bidirect, generator=generator, size=size,
+                                                         fov=fov), device)
+
+
+def sample_cameras_host(n, trans, scale, up=False, around=True, look_mode="target", sample_mode="random", bidirect=True,
+                        generator=None, size=1500, fov=2.5):
+    """The host half of `sample_cameras` (placement + camera matrices, no device work): what a trainer runs ahead of a
+    densification on a worker thread; `SampleCam.batch_from_host` finishes it."""
     w2cs = bb_camera(n, trans.detach().float().cpu(), scale.detach().float().cpu(), up=up, around=around,
                      look_mode=look_mode, sample_mode=sample_mode, bidirect=bidirect, generator=generator)
-    return SampleCam.batch(w2cs, size, size, fov, fov, device=device)
+    return SampleCam.batch_host(w2cs, size, size, fov, fov)

@@ -58,7 +58,13 @@ class SampleCam:
         device matmul and a device-to-host round trip per camera: 0.2 ms each, 40 ms for the 200 cameras of one visibility
         pass -- as long as the renders themselves).  Every camera's tensors are views into the stacked ones, which
         `gaussian_renderer.visibility_counts` recognises (`_stack`) and hands to the library without re-stacking."""
-        dev = torch.device(device)
+        return cls.batch_from_host(cls.batch_host(w2cs, width, height, FoVx, FoVy), device)
+
+    @staticmethod
+    def batch_host(w2cs, width, height, FoVx, FoVy):
+        """The host arithmetic of `batch` (no device work): -> a bundle `batch_from_host` turns into cameras.  Split off so that a
+        trainer can form the 200 cameras of the NEXT densification on a worker thread while the GPU runs training steps (round 6:
+        8 ms of the densification event were this arithmetic)."""
         w2cs = w2cs.to(torch.float32).cpu()
         B = w2cs.shape[0]
         wv = w2cs.transpose(1, 2).contiguous()
@@ -68,11 +74,18 @@ class SampleCam:
         #  constructor's arithmetic to the bit)
         centre = torch.stack([torch.inverse(wv[i])[3, :3] for i in range(B)]) if B else wv.new_zeros(0, 3)
         rot = w2cs[:, :3, :3].contiguous()
-        R_np = rot.transpose(1, 2).numpy()
-        stack = tuple(t.to(dev) for t in (wv, full, centre, rot))
-        proj_d = proj.to(dev)
+        return {"stack": (wv, full, centre, rot), "proj": proj, "R": rot.transpose(1, 2).numpy(), "size": (int(width), int(height)),
+                "fov": (FoVx, FoVy)}
+
+    @classmethod
+    def batch_from_host(cls, host, device="cuda"):
+        dev = torch.device(device)
+        stack = tuple(t.to(dev) for t in host["stack"])
+        proj_d = host["proj"].to(dev)
+        R_np = host["R"]
+        (width, height), (FoVx, FoVy) = host["size"], host["fov"]
         cams = []
-        for i in range(B):
+        for i in range(stack[0].shape[0]):
             c = cls.__new__(cls)
             c.FoVx, c.FoVy = FoVx, FoVy
             c.image_width, c.image_height = int(width), int(height)

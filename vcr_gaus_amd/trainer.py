@@ -62,6 +62,8 @@ class Trainer:
         self.background = torch.tensor([1.0, 1.0, 1.0] if cfg.model.white_background else [0.0, 0.0, 0.0], device=device)
         self.rng = random.Random(seed)            # identical on every rank
         self.gen = torch.Generator(device="cpu").manual_seed(seed)
+        self.prefetch_visibility_cameras = True    # the next densification's virtual cameras on a worker thread (`_visibility_cameras`)
+        self._vis_ahead = None
         # random backgrounds (`trainer.py:334`) are drawn once on the host and kept on the device: a per-step H2D copy
         # of a pageable tensor is a stream synchronisation that stops the host from running ahead of the GPU
         self.bg_table = torch.rand(4096, 3, generator=self.gen).to(device)
@@ -578,6 +580,9 @@ class Trainer:
         # the camera drawn ahead for the activation prefetch belongs to the run that was interrupted by this load
         self._prefetched = None
         self.model._act_cache = None
+        ahead, self._vis_ahead = getattr(self, "_vis_ahead", None), None
+        if ahead is not None:
+            ahead["thread"].join()       # (its cameras belonged to the interrupted run; the generator is left where that run put it)
 
     # ---- visibility / importance passes (`tools/prune.py:6-69`, `trainer.py:688-702`), camera-sharded ------------
     @torch.no_grad()
@@ -614,11 +619,43 @@ class Trainer:
 
     def _visibility_cameras(self, sc):
         """`Trainer.get_visi_mask_acc` (`trainer.py:688-702`): virtual bounding-box cameras when
-        `sample_cams.random`, else `num` training cameras drawn with replacement.  Seeded identically on every rank."""
+        `sample_cams.random`, else `num` training cameras drawn with replacement.  Seeded identically on every rank.
+        Round 6: the host half of the random cameras (placement, 200 matrix inverses: ~8 ms) is formed AHEAD on a worker thread
+        -- right after the previous request, from the same generator in the same order, so the cameras are the ones an
+        on-demand call would have produced -- and only the four host-to-device copies remain in the densification step."""
         if sc.random:
-            from .camera_utils import sample_cameras
-            return sample_cameras(sc.num, self.model.trans, self.model.scale, up=getattr(sc, "up", False),
-                                  around=getattr(sc, "around", True), device=self.device, generator=self.gen)
+            from .camera_utils import sample_cameras_host
+            from .cameras import SampleCam
+            key = (int(sc.num), bool(getattr(sc, "up", False)), bool(getattr(sc, "around", True)))
+            trans, scale = self.model.trans.detach().float().cpu().clone(), self.model.scale.detach().float().cpu().clone()
+
+            def host():
+                return sample_cameras_host(key[0], trans, scale, up=key[1], around=key[2], generator=self.gen)
+
+            pending, self._vis_ahead = getattr(self, "_vis_ahead", None), None
+            bundle = None
+            if pending is not None:
+                pending["thread"].join()
+                if pending["key"] == key and torch.equal(pending["trans"], trans) and torch.equal(pending["scale"], scale) and \
+                        "error" not in pending:
+                    bundle = pending["bundle"]
+            if bundle is None:
+                bundle = host()
+            cams = SampleCam.batch_from_host(bundle, self.device)
+            if self.prefetch_visibility_cameras:
+                import threading
+                nxt = {"key": key, "trans": trans, "scale": scale}
+
+                def work():
+                    try:
+                        nxt["bundle"] = host()
+                    except Exception as e:          # (the consumer falls back to the on-demand path)
+                        nxt["error"] = e
+
+                nxt["thread"] = threading.Thread(target=work, daemon=True)
+                nxt["thread"].start()
+                self._vis_ahead = nxt
+            return cams
         return [self.cameras[self.rng.randrange(len(self.cameras))] for _ in range(sc.num)]
 
     def v_imp_score(self, imp, v_pow):
