@@ -873,7 +873,7 @@ _Pragma("unroll")                                                               
 #define VCR_SHADE_BWD(R, B)                                                                                              \
 do {                                                                                                             \
     const float4 r0 = R##0, r1 = R##1, r2 = R##2, r3 = R##3; const int sb_ = (B);                                \
-    const uint32_t idx1 = (uint32_t)chunk * 64u + (uint32_t)sb_ + 1u;                                            \
+    const uint32_t idx1 = VCR_BWD_IDX1(sb_);                                                                     \
     const f2 gxy = {r0.x, r0.y}, sAC = {r0.z, r0.w};                                                             \
     const f2 d = gxy - fxy;                                                                                      \
     f2 u; float hs;                                                                                              \
@@ -976,6 +976,8 @@ __device__ __forceinline__ float row_reduce16(const f2 v[8], int lane) {
     return (h4 ? c1 : c0) + dpp_get<0xB1>(h4 ? c0 : c1);                // quad_perm [1,0,3,2]
 }
 
+// 1-based list position of the staged survivor in slot SLOT (third plane of its record in `r3`): per-chunk staging -- slot = position in the chunk
+#define VCR_BWD_IDX1(SLOT) ((uint32_t)chunk * 64u + (uint32_t)(SLOT) + 1u)
 // One work item of the row-packed backward: quad `wv` of `tile` (split items: its 4x4 sub-block `sub`), walked back to front by the
 // calling wave; `srec` = the wave's private LDS planes (WREC float4).
 template <int S, bool ISECT, int ND, bool QL>
@@ -1103,7 +1105,7 @@ __device__ __forceinline__ void bwd_rows_item(const VcrRasterArgs& a, const Geom
 #define VCR_SHADE_BWD_ROWS(R, B, ACT)                                                                                     \
             do {                                                                                                           \
                 const float4 r0 = R##0, r1 = R##1, r2 = R##2, r3 = R##3;                                                   \
-                const uint32_t idx1 = (uint32_t)chunk * 64u + (uint32_t)(B) + 1u;                                          \
+                const uint32_t idx1 = VCR_BWD_IDX1(B);                                                                     \
                 const f2 gxy = {r0.x, r0.y}, sAC = {r0.z, r0.w};                                                           \
                 const f2 d = gxy - fxy;                                                                                    \
                 f2 u; float hs;                                                                                            \
@@ -1145,6 +1147,177 @@ _Pragma("unroll")                                                               
     }
 }
 
+// ---- the same work item with the survivors GROUPED across chunks (round 6) ------------------------------------------------------------
+// bwd_rows_item shades what one 64-entry chunk leaves: ~16 survivors, each in ~1.9 of the four row lists, so the row-packed loop runs
+// max_r |list_r| ~ 10 iterations for a mean of 7.6 (a quarter of its row-slots idle) and pays its prologue -- masks, the choice between
+// the two loops, the first LDS fetch -- per chunk.  Here the survivors of consecutive chunks are compacted, back to front, into the 64
+// staging slots (slot 0 = the LAST list entry of the group) and shaded when the next chunk's survivors would not fit: the row lists
+// are ~4x longer and their maximum is closer to their mean.  A slot carries its 1-based list position and its four row bits in the
+// pad word of plane 3.  Every pixel still meets its contributors in list order, back to front, with the same arithmetic: T, the
+// suffix sums and every per-pair value are those of bwd_rows_item; only the order of the fp32 atomics differs.
+// Measured (profiles/r6_bwd_group_ab.txt, 4 cameras): metric 396.8 -> 389.2 us, c5 925.9 -> 892.2, dense 634.7 -> 613.8, full-frame
+// 751.2 -> 727.1, c2 288.9 -> 283.6.  A second form that tested every entry once per chunk (bounding box of all live pixels) and ran the
+// four sub-block tests once per group on the compacted survivors was NOT faster (metric 400.5, per-quad lists 396 against 382): the
+// wider boxes let more survivors through than the three saved tests per chunk are worth.
+template <int S, bool ISECT, int ND, bool QL>
+__device__ __forceinline__ void bwd_group_item(const VcrRasterArgs& a, const GeomRec* __restrict__ rec, const float* __restrict__ semv,
+                                              const uint32_t* __restrict__ point_list, const uint2* __restrict__ ranges, int gxc,
+                                              const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                                              const float* __restrict__ moments, const float* __restrict__ ckpt,
+                                              const float* __restrict__ dL_dout, GradRec* __restrict__ sgrad,
+                                              float* __restrict__ sgrad_sem, int rows_bias, int rows_pair_cost,
+                                              int tile, int sub, int wv, float4* const srec) {
+    const int gx = (a.W + VCR_TILE - 1) / VCR_TILE;
+    const PixelMap pm = pixel_of_thread_rows(tile, gx, a.W, a.H, sub, wv);
+    const uint2 range = list_range<QL>(ranges, gxc, tile, gx, wv);
+    if (range.x == range.y) return;                        // wave-uniform: nothing reaches this quad
+    static_assert(!VCR_T_ANCHOR, "the grouped backward has no per-chunk transmittance anchoring");
+    (void)ckpt;
+    const int P = a.H * a.W;
+    const int lane = threadIdx.x & 63, row = lane >> 4;
+    constexpr bool SEM_IN_REC = false;
+    constexpr int FC = 0;
+    const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8);
+    const float Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8);
+    const f2 fxy = {(float)pm.x, (float)pm.y};
+    float rx = 0.f, ry = 0.f, rz = 1.f;
+    if (ISECT && pm.inside) { rx = a.dirs[pm.pix]; ry = a.dirs[P + pm.pix]; rz = a.dirs[2 * P + pm.pix]; }
+
+    float g[8 + (S > 0 ? S : 0)];
+#pragma unroll
+    for (int c = 0; c < 8 + S; ++c) g[c] = pm.inside ? dL_dout[c * (size_t)P + pm.pix] : 0.f;
+    float gm2 = 0.f;
+    if (ND == 2 && pm.inside) { g[3] += dL_dout[(8 + S) * (size_t)P + pm.pix]; gm2 = dL_dout[(9 + S) * (size_t)P + pm.pix]; }
+    const float Tf = pm.inside ? final_T[pm.pix] : 1.f;
+    float gm1 = 0.f;
+    const float zc_map = VCR_ZFAR / (VCR_ZFAR - VCR_ZNEAR);
+    if (ND == 1 && pm.inside) {
+        const float gd = dL_dout[(8 + S) * (size_t)P + pm.pix];
+        const float m1 = moments[pm.pix], m2 = moments[P + pm.pix];
+        gm1 = -2.f * m1 * gd; gm2 = (1.f - Tf) * gd; g[7] += m2 * gd;
+    }
+    const uint32_t lastc = pm.inside ? n_contrib[pm.pix] : 0u;
+    const float bgdot = Tf * (a.bg[0] * g[0] + a.bg[1] * g[1] + a.bg[2] * g[2]);
+    uint32_t maxc = lastc;
+    for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, o));
+    if (maxc == 0) return;                                 // wave-uniform
+    float T = Tf, Bsuf = bgdot;
+    double Td = (double)Tf, Bd = (double)bgdot;      // (VCR_DBG_PIX64 only; dead otherwise)
+    (void)Td; (void)Bd;
+    const f2 g01 = {g[0], g[1]}, g24 = {g[2], g[4]}, g56 = {g[5], g[6]}, ryz = {ry, rz};
+
+    // 1-based list position of the staged survivor being shaded (28 bits of the pad word of `r3`; the row bits sit above them)
+#undef VCR_BWD_IDX1
+#define VCR_BWD_IDX1(SLOT) (__float_as_uint(r3.w) & 0x0FFFFFFFu)
+#undef VCR_ROW_NEXT
+#define VCR_ROW_NEXT(B, ACT)                                                           \
+            do {                                                                        \
+                ACT = mrow != 0;                                                        \
+                B = ACT ? __builtin_ctzll(mrow) : B;                                    \
+                mrow = ACT ? mrow & (mrow - 1ull) : 0ull;                               \
+            } while (0)
+    // shade the `fill` staged survivors (slot order = back to front) and empty the group
+#define VCR_BWD_FLUSH()                                                                                              \
+    do {                                                                                                             \
+        __builtin_amdgcn_wave_barrier();                                                                             \
+        const uint32_t rb_ = lane < fill ? __float_as_uint(srec[3 * 64 + lane].w) >> 28 : 0u;                        \
+        unsigned long long mr[4];                                                                                    \
+_Pragma("unroll")                                                                                                    \
+        for (int r = 0; r < 4; ++r) mr[r] = __builtin_amdgcn_ballot_w64((rb_ >> r) & 1u);                            \
+        const unsigned long long many = mr[0] | mr[1] | mr[2] | mr[3];                                               \
+        const int iters = max(max(__popcll(mr[0]), __popcll(mr[1])), max(__popcll(mr[2]), __popcll(mr[3])));         \
+        const int pairs = __popcll(mr[0]) + __popcll(mr[1]) + __popcll(mr[2]) + __popcll(mr[3]);                     \
+        if (many && iters * 16 + pairs * rows_pair_cost > __popcll(many) * rows_bias) {                              \
+            unsigned long long m = many;                                                                             \
+            float4 A0, A1, A2, A3, A4 = {0.f, 0.f, 0.f, 0.f}, B0, B1, B2, B3, B4 = {0.f, 0.f, 0.f, 0.f};             \
+            int b = __builtin_ctzll(m);                                                                              \
+            m &= m - 1ull;                                                                                           \
+            VCR_LDS_FETCH(A, b);                                                                                     \
+            for (;;) {                                                                                               \
+                int nb = m ? __builtin_ctzll(m) : 0;                                                                 \
+                bool more = m != 0;                                                                                  \
+                m &= m - 1ull;                                                                                       \
+                VCR_LDS_FETCH(B, nb);                                                                                \
+                VCR_SHADE_BWD(A, b);                                                                                 \
+                if (!more) break;                                                                                    \
+                b = nb;                                                                                              \
+                nb = m ? __builtin_ctzll(m) : 0;                                                                     \
+                more = m != 0;                                                                                       \
+                m &= m - 1ull;                                                                                       \
+                VCR_LDS_FETCH(A, nb);                                                                                \
+                VCR_SHADE_BWD(B, b);                                                                                 \
+                if (!more) break;                                                                                    \
+                b = nb;                                                                                              \
+            }                                                                                                        \
+        } else if (many) {                                                                                           \
+            unsigned long long mrow = row == 0 ? mr[0] : (row == 1 ? mr[1] : (row == 2 ? mr[2] : mr[3]));            \
+            int b = __builtin_ctzll(many);                                                                           \
+            bool act;                                                                                                \
+            float4 A0, A1, A2, A3, A4 = {0.f, 0.f, 0.f, 0.f}, B0, B1, B2, B3, B4 = {0.f, 0.f, 0.f, 0.f};             \
+            int nb = b; bool nact;                                                                                   \
+            VCR_ROW_NEXT(b, act);                                                                                    \
+            VCR_LDS_FETCH(A, b);                                                                                     \
+            for (int it = 0;;) {                                                                                     \
+                nb = b;                                                                                              \
+                VCR_ROW_NEXT(nb, nact);                                                                              \
+                VCR_LDS_FETCH(B, nb);                                                                                \
+                VCR_SHADE_BWD_ROWS(A, b, act);                                                                       \
+                if (++it >= iters) break;                                                                            \
+                b = nb;                                                                                              \
+                VCR_ROW_NEXT(b, act);                                                                                \
+                VCR_LDS_FETCH(A, b);                                                                                 \
+                VCR_SHADE_BWD_ROWS(B, nb, nact);                                                                     \
+                if (++it >= iters) break;                                                                            \
+            }                                                                                                        \
+        }                                                                                                            \
+        __builtin_amdgcn_wave_barrier();                                                                             \
+        fill = 0;                                                                                                    \
+    } while (0)
+    int fill = 0;                                          // staged survivors of the current group (wave-uniform)
+    int chunk = (int)((maxc - 1) / 64);
+    uint32_t id, nid; float4 q0, q1, q2, q3, qs = {0.f, 0.f, 0.f, 0.f}; bool valid, nvalid;
+    const uint32_t lim = range.x + maxc;
+    VCR_LOAD_ID(range.x + (uint32_t)chunk * 64u + lane, lim, id, valid);
+    VCR_GATHER_REC(id, q0, q1, q2, q3);
+    VCR_GATHER_SEM(id, qs);
+    VCR_LOAD_ID(chunk > 0 ? range.x + (uint32_t)(chunk - 1) * 64u + lane : lim, lim, nid, nvalid);
+    for (; chunk >= 0; --chunk) {
+        uint32_t nnid; float4 nq0, nq1, nq2, nq3, nqs = {0.f, 0.f, 0.f, 0.f}; bool nnvalid;
+        VCR_GATHER_REC(nid, nq0, nq1, nq2, nq3);
+        VCR_GATHER_SEM(nid, nqs);
+        VCR_LOAD_ID(chunk > 1 ? range.x + (uint32_t)(chunk - 2) * 64u + lane : lim, lim, nnid, nnvalid);
+        // cull against the live box of each 4x4 sub-block (as bwd_rows_item); the four row bits travel with the staged record
+        const unsigned long long live = __builtin_amdgcn_ballot_w64(lastc > (uint32_t)chunk * 64u);
+        uint32_t rbits = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned lr = (unsigned)(live >> (16 * r)) & 0xFFFFu;
+            if (lr != 0) {                                   // wave-uniform
+                float bx0, by0, bw, bh;
+                live_box16(lr, X0 + (float)((r & 1) * 4), Y0 + (float)((r >> 1) * 4), bx0, by0, bw, bh);
+                if (valid && quad_touch(q0, q1, bx0, by0, bw, bh)) rbits |= 1u << r;
+            }
+        }
+        const unsigned long long km = __builtin_amdgcn_ballot_w64(rbits != 0);
+        const int cnt = __popcll(km);
+        if (fill + cnt > 64) VCR_BWD_FLUSH();                // (wave-uniform)
+        if (rbits != 0) {
+            // back to front: the chunk's highest lane is its last entry and takes the lowest free slot
+            const int slot = fill + (lane == 63 ? 0 : __popcll(km >> (lane + 1)));
+            srec[0 * 64 + slot] = make_float4(q0.x, q0.y, -VCR_L2E * q1.x, -VCR_L2E * q1.z);
+            srec[1 * 64 + slot] = make_float4(-VCR_L2E * q1.y, __builtin_amdgcn_logf(q0.w), q0.z, q1.w);
+            srec[2 * 64 + slot] = make_float4(q2.x, q2.y, q2.z, q3.x);
+            srec[3 * 64 + slot] = make_float4(q3.y, q3.z, __uint_as_float(id), __uint_as_float((rbits << 28) | ((uint32_t)chunk * 64u + (uint32_t)lane + 1u)));
+            if (S > 0) srec[4 * 64 + slot] = qs;
+        }
+        fill += cnt;
+        id = nid; q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3; qs = nqs; valid = nvalid; nid = nnid; nvalid = nnvalid;
+    }
+    if (fill > 0) VCR_BWD_FLUSH();
+#undef VCR_BWD_FLUSH
+#undef VCR_BWD_IDX1
+}
+
 #define VCR_BWD_WREC (S > 0 ? 320 : 256)
 template <int S, bool ISECT, int ND, bool QL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_ROWS_WAVES))) composite_bwd_rows_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
@@ -1171,6 +1344,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_RO
     __shared__ float4 s_rec_all[4 * VCR_BWD_WREC];
     bwd_rows_item<S, ISECT, ND, QL>(a, rec, semv, point_list, ranges, gxc, final_T, n_contrib, moments, ckpt, dL_dout, sgrad, sgrad_sem,
                                     rows_bias, rows_pair_cost, tile, sub, wv, s_rec_all + wv * VCR_BWD_WREC);
+}
+
+template <int S, bool ISECT, int ND, bool QL>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VCR_ROWS_WAVES))) composite_bwd_group_kernel(VcrRasterArgs a, const GeomRec* __restrict__ rec,
+                                                               const float* __restrict__ semv,
+                                                               const uint32_t* __restrict__ point_list,
+                                                               const uint2* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ meta,
+                                                               int num_tiles, int gxc, const float* __restrict__ final_T,
+                                                               const uint32_t* __restrict__ n_contrib,
+                                                               const float* __restrict__ moments, const float* __restrict__ ckpt,
+                                                               const float* __restrict__ dL_dout, GradRec* __restrict__ sgrad,
+                                                               float* __restrict__ sgrad_sem, int rows_bias, int rows_pair_cost, int det_sel) {
+#ifdef VCR_DETERMINISTIC_BWD
+    if ((int)(blockIdx.x * 4 + (threadIdx.x >> 6)) != det_sel) return;
+#else
+    (void)det_sel;
+#endif
+    int sub;
+    const int tile = work_item(tile_order, meta, num_tiles, sub);
+    if (tile < 0) return;
+    const int wv = threadIdx.x >> 6;
+    __shared__ float4 s_rec_all[4 * VCR_BWD_WREC];
+    bwd_group_item<S, ISECT, ND, QL>(a, rec, semv, point_list, ranges, gxc, final_T, n_contrib, moments, ckpt, dL_dout, sgrad, sgrad_sem,
+                                     rows_bias, rows_pair_cost, tile, sub, wv, s_rec_all + wv * VCR_BWD_WREC);
 }
 
 template <int S, bool ISECT, int ND>
@@ -1234,7 +1432,13 @@ int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
     for (int det = det_first; det < det_last; ++det)                                                             \
         hipLaunchKernelGGL((composite_bwd_rows_kernel<SS, ISECT, ND, Q>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
                            b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, im.t_ckpt, dL_dout, sgrad, sgrad_sem, rows_bias, rows_pair_cost, det);
-#define VCR_BWD(SS) do { if (gxc) { VCR_BWD_Q(SS, true) } else { VCR_BWD_Q(SS, false) } } while (0)
+#define VCR_BWD_GQ(SS, Q)                                                                                        \
+    for (int det = det_first; det < det_last; ++det)                                                             \
+        hipLaunchKernelGGL((composite_bwd_group_kernel<SS, ISECT, ND, Q>), dim3(tiles + 3 * VCR_SPLIT_MAX), dim3(256), 0, st, a, g.rec, g.sem, \
+                           b.point_list, b.ranges, b.tile_order, b.meta, tiles, gxc, im.final_T, im.n_contrib, im.moments, im.t_ckpt, dL_dout, sgrad, sgrad_sem, rows_bias, rows_pair_cost, det);
+    constexpr bool grouped = !VCR_T_ANCHOR;                 // (anchored experiment builds keep the per-chunk form: checkpoints are per chunk)
+#define VCR_BWD(SS) do { if (grouped) { if (gxc) { VCR_BWD_GQ(SS, true) } else { VCR_BWD_GQ(SS, false) } }           \
+                         else if (gxc) { VCR_BWD_Q(SS, true) } else { VCR_BWD_Q(SS, false) } } while (0)
     switch (a.S) {
         case 0: VCR_BWD(0); break;
         case 1: VCR_BWD(1); break;
@@ -1243,6 +1447,7 @@ int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
         default: VCR_BWD(4); break;
     }
 #undef VCR_BWD
+#undef VCR_BWD_GQ
 #undef VCR_BWD_Q
     VCR_HIP_CHECK(hipGetLastError());
     return 0;

@@ -51,13 +51,13 @@ __device__ __forceinline__ float edge_min(float a2, float c2, float b, float xe,
 
 
 // Can this Gaussian reach alpha >= 1/255 at any pixel centre of the rectangle [X0,X0+bw]x[Y0,Y0+bh]?  Conservative.
-__device__ __forceinline__ bool quad_touch(const float4 q0, const float4 q1, float X0, float Y0, float bw = 7.f,
-                                           float bh = 7.f) {
-    const float A = q1.x, B = q1.y, C = q1.z;
-    const float tau = __logf(255.f * q0.w);
+// (`tau` = ln(255 opacity) >= 0 and the raw conic as arguments: the grouped backward keeps them per staged survivor and repeats
+//  the test on its four 4x4 sub-blocks with exactly this arithmetic.)
+__device__ __forceinline__ bool quad_touch_tau(float px, float py, float A, float B, float C, float tau, float X0, float Y0,
+                                               float bw = 7.f, float bh = 7.f) {
     if (!(tau >= 0.f)) return false;                      // opacity below 1/255 never contributes
     if (!(A > 0.f) || !(C > 0.f)) return true;            // degenerate conic: leave it to the per-pixel test
-    const float x0 = X0 - q0.x, x1 = X0 + bw - q0.x, y0 = Y0 - q0.y, y1 = Y0 + bh - q0.y;
+    const float x0 = X0 - px, x1 = X0 + bw - px, y0 = Y0 - py, y1 = Y0 + bh - py;
     if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return true;
     const float ia = 1.f / A, ic = 1.f / C;
     float qm = edge_min(A, C, B, x0, ic, y0, y1);
@@ -66,6 +66,10 @@ __device__ __forceinline__ bool quad_touch(const float4 q0, const float4 q1, flo
     qm = fminf(qm, edge_min(C, A, B, y1, ia, x0, x1));
     const float mx = fmaxf(x0 * x0, x1 * x1), my = fmaxf(y0 * y0, y1 * y1);
     return qm <= tau + 0.05f + 2e-6f * (A * mx + C * my);
+}
+__device__ __forceinline__ bool quad_touch(const float4 q0, const float4 q1, float X0, float Y0, float bw = 7.f,
+                                           float bh = 7.f) {
+    return quad_touch_tau(q0.x, q0.y, q1.x, q1.y, q1.z, __logf(255.f * q0.w), X0, Y0, bw, bh);
 }
 
 // Can the Gaussian reach alpha >= 1/255 at a pixel centre of tile (tx, ty)?  The same conservative conic-minimum test the
