@@ -226,17 +226,25 @@ def valu_block(R, ms_fwd, workload):
     return out
 
 
+# FETCH_SIZE -> bytes.  The counter's unit is KiB, but what it counts depends on the access pattern (calibrated in round 6 on kernels
+# of known byte count, profiles/microbench/fetch_calib.hip -> profiles/r6_fetch_calib.txt): a gather of 64-B records, whole or the
+# first half of each, reads 1.04 x the counter (it counts the 64-B lines that were fetched); streaming 16 B per lane reads 2.00 x (the
+# MI355X guide's correction).  The compositing kernels' fetch side is the record gather; rounds 1-5 applied the x 2 to it.
+FETCH_FACTOR_GATHER, FETCH_FACTOR_STREAM = 1.04, 2.0
+
+
 def pmc_traffic(kernel="composite_fwd_"):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes
-    (profiles/r<N>_pmc_fetch.csv, r<N>_pmc_write.csv; separate --pmc runs of THIS command on the metric workload).
-    FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane loads, hence
-    the x2 the MI355X guide prescribes (uncalibrated for this gather pattern)."""
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes (profiles/r<N>_pmc_fetch.csv,
+    r<N>_pmc_write.csv; separate --pmc runs of THIS command on the metric workload), with the gather factor above for the
+    compositing kernels.  `pmc_traffic.meta`: R / E / V of the frame the passes saw (they run 9 steps, the bench line K + W + ...,
+    so the last camera differs); `pmc_traffic.pass_R` is that R."""
     import csv
     vals = {}
     rnd = next((r for r in ("r6", "r5", "r4", "r3", "r2", "r1") if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_pmc_fetch.csv"))), "r1")
-    pmc_traffic.source = f"profiles/{rnd}_pmc_{{fetch,write}}.csv (rocprofv3 --pmc, separate passes)"
+    pmc_traffic.source = f"profiles/{rnd}_pmc_{{fetch,write}}.csv (rocprofv3 --pmc, separate passes; FETCH_SIZE x {FETCH_FACTOR_GATHER} for this gather)"
     meta = os.path.join(ROOT, "profiles", f"{rnd}_pmc_meta.json")
     pmc_traffic.meta = json.load(open(meta)) if os.path.exists(meta) else None      # R / R' / camera of the counter passes
+    pmc_traffic.pass_R = (pmc_traffic.meta or {}).get("fetch", {}).get("tile_instances_R")
     for name in ("fetch", "write"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{name}.csv")
         if not os.path.exists(path):
@@ -246,7 +254,8 @@ def pmc_traffic(kernel="composite_fwd_"):
                 vals[r["counter"]] = float(r["avg_per_dispatch"])
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    factor = FETCH_FACTOR_GATHER if kernel.startswith("composite_") else FETCH_FACTOR_STREAM
+    return (factor * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
 def measure_variant(name, dev, steps=30):
@@ -296,7 +305,7 @@ def measure_variant(name, dev, steps=30):
                          "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": alg, "avg_ms": ms_fwd}}
 
 
-def schedule_inclusive(trainer, iters=200, warm_iters=100, world=1, dev=None):
+def schedule_inclusive(trainer, iters=400, warm_iters=100, world=1, dev=None):
     """What a training run costs per iteration WITH the reference's schedule inside the window ('densify
     amortised'): the headline trainer continues with densification switched on at the reference's interval of 100
     (`configs/config_base.yaml`), each densify-and-prune preceded (tnt preset) by the 200 visibility renders at 1500 x 1500 of
@@ -507,7 +516,9 @@ def main():
         alg_bwd = (60 + 4 * sem) * R + (8 * (8 + sem) + 20) * P + 2 * (60 + 4 * sem) * V
         alg_bwd_emitted = alg_bwd - (60 + 4 * sem) * (R - E)
         ach_bwd = alg_bwd / (ms_bwd * 1e-3) / 1e9 if ms_bwd > 0 else 0.0
-        traffic_bwd = pmc_traffic("composite_bwd_rows_kernel") if args.workload == "metric_1m_1080p" else None
+        traffic_bwd = pmc_traffic("composite_bwd_") if args.workload == "metric_1m_1080p" else None
+        traffic_fwd = pmc_traffic() if args.workload == "metric_1m_1080p" else None
+        pass_R = getattr(pmc_traffic, "pass_R", None)
         raster_fwd_ms = sum(stages[k] for k in ["preprocess", "depth_sort_scan", "binning", "composite_fwd"])
         steady_ms = 1e3 * dt / args.steps                       # the K timed steps of the contract (densify / prune not among them)
         if sched is not None and sched["densify_steps"] > 0:
@@ -548,9 +559,12 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "frac_emitted": ach_emitted / HBM_PEAK_GBS, "algorithmic_bytes_emitted": alg_emitted,
                          "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
-                         "traffic": pmc_traffic() if args.workload == "metric_1m_1080p" else None,
+                         "traffic": traffic_fwd,
                          "traffic_source": getattr(pmc_traffic, "source", None),
                          "traffic_pass": getattr(pmc_traffic, "meta", None),
+                         # the same frame on both sides: counter bytes of the PMC passes over the algorithmic bytes at THEIR R
+                         "traffic_over_algorithmic_at_pass": (traffic_fwd / ((60 + 4 * sem) * pass_R + (4 * (8 + sem) + 20) * P))
+                         if (traffic_fwd and pass_R) else None,
                          "algorithmic_bytes": alg_bytes, "avg_ms": ms_fwd,
                          # the kernel is VALU-bound in practice.  `naive_*`: the algorithm's (pixel, Gaussian) pair
                          # evaluations (256 per tile instance, ~30 wave64 VALU instructions per 64 pairs) priced at the issue
@@ -574,7 +588,7 @@ def main():
         if sched is not None:
             line["schedule_inclusive"] = sched
             line["densify_event_ms"] = sched["densify_event_ms"]
-            # the same metric measured as one wall-clock window of 200 iterations with two real events inside (the later steps run
+            # the same metric measured as one wall-clock window of `schedule_inclusive.iters` iterations with real events inside (the later steps run
             # on the grown model): a cross-check of `value`, not a second definition
             line["value_densify_amortised"] = world * sched["iters_per_s"]
         if exchange_diag is not None:
