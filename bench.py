@@ -305,7 +305,7 @@ def measure_variant(name, dev, steps=30):
                          "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": alg, "avg_ms": ms_fwd}}
 
 
-def schedule_inclusive(trainer, iters=400, warm_iters=100, world=1, dev=None):
+def schedule_inclusive(trainer, iters=200, warm_iters=100, world=1, dev=None):
     """What a training run costs per iteration WITH the reference's schedule inside the window ('densify
     amortised'): the headline trainer continues with densification switched on at the reference's interval of 100
     (`configs/config_base.yaml`), each densify-and-prune preceded (tnt preset) by the 200 visibility renders at 1500 x 1500 of
