@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 6, call 16: l1 + ssim kernels with the conflict-free LDS layout (halo stride 45, row-sum planes stored [o][j]) against the old layout
+# (libvcr_raster_ssimold.so: the default objects with losses.o compiled from the committed losses.hip; libvcr_raster.so: the re-laid-out
+#  kernels, which were reverted after this call -- profiles/r6_ssim_lds_layout_negative.txt)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r6_run16
 mkdir -p $OUT

@@ -1422,6 +1422,8 @@ int launch_bwd_s(const VcrRasterArgs& a, GeomState g, BinState b, ImageState im,
     // per chunk: row-packed loop iff 16 * max_r |list_r| + pair * sum_r |list_r| <= bias * |union_r list_r| (the second term
     // prices the atomics: an iteration with all four rows live issues 64 atomic lanes instead of 16).  bias 0 = never,
     // (64, 0) = always; (20, 2) from the sweep in profiles/r3_bwd_rows_ab.txt
+    // (re-swept for the grouped form in round 6, profiles/r6_rows_sweep.txt: (20, 2) again -- (28, 2) gains 1 % at the metric scene and
+    //  loses 36 % on the full-frame variant, (16, 2) loses 13 %)
     constexpr int rows_bias = 20, rows_pair_cost = 2;
 #ifdef VCR_DETERMINISTIC_BWD
     const int det_first = 0, det_last = 4 * (tiles + 3 * VCR_SPLIT_MAX);      // one launch per (workgroup, wave), in order
