@@ -450,6 +450,10 @@ __global__ void __launch_bounds__(256) VCR_FWD_ATTR composite_fwd_v2_kernel(VcrR
 #define VCR_FWD_TP 1
 #endif
 #define VCR_TP_CAP 64
+// Plane stride of the staged group: one slot more than the group holds.  Slot VCR_TP_CAP is a DUMMY record whose alpha is 0 (log2 of its
+// opacity = -1e30): a lane without a candidate left walks it, so phase 2 carries no "this lane is active" flag from the pop to the hit test
+// (two VALU and two scalar instructions per iteration less; same results -- the dummy hits nothing and contributes w = 0).
+#define VCR_TP_STRIDE (VCR_TP_CAP + 1)
 #ifndef VCR_TP_MAX_TILES_PER_GAUSSIAN
 #define VCR_TP_MAX_TILES_PER_GAUSSIAN 5      // frames with more 3-sigma tiles per visible Gaussian keep the v2 loop (vcr_forward_two_phase)
 #endif
@@ -487,7 +491,7 @@ __device__ __forceinline__ float4 span_params(const float4 q0, const float4 q1, 
 }
 
 // One work item of the two-phase forward: quad `wv` of `tile` (or its 4x4 sub-block `sub`), walked by the calling wave; `srec` / `rbq`
-// are the wave's private LDS planes (5 x VCR_TP_CAP float4 and 32 uint4).
+// are the wave's private LDS planes (5 x VCR_TP_STRIDE float4 and 32 uint4).
 template <int S, bool ISECT, int ND, bool QL>
 __device__ __forceinline__ void fwd_tp_item(const VcrRasterArgs& a, const GeomRec* __restrict__ rec, const uint32_t* __restrict__ point_list,
                                             const uint2* __restrict__ ranges, int gxc, float* __restrict__ final_T,
@@ -500,6 +504,22 @@ __device__ __forceinline__ void fwd_tp_item(const VcrRasterArgs& a, const GeomRe
     const int P = a.H * a.W;
     const int lane = threadIdx.x & 63;
     uint8_t* const rbb = reinterpret_cast<uint8_t*>(rbq);
+    if (range.x == range.y) {                              // (wave-uniform) nothing reaches this quad -- 84 % of the metric frame's waves:
+        if (pm.inside) {                                   // background, T = 1, no contributor; exactly what the general path would write
+            final_T[pm.pix] = 1.f;
+            n_contrib[pm.pix] = 0u;
+            out[0 * (size_t)P + pm.pix] = 0.f + 1.f * a.bg[0];
+            out[1 * (size_t)P + pm.pix] = 0.f + 1.f * a.bg[1];
+            out[2 * (size_t)P + pm.pix] = 0.f + 1.f * a.bg[2];
+#pragma unroll
+            for (int k = 3; k < 8 + S + (ND == 2 ? 2 : (ND == 1 ? 1 : 0)); ++k) out[k * (size_t)P + pm.pix] = 0.f;
+            if (ND == 1) { moments[pm.pix] = 0.f; moments[P + pm.pix] = 0.f; }
+        }
+        return;
+    }
+    // the dummy record: alpha = 2^-1e30 = 0, everything else finite -- depth 1, so that the mapped depth of the distortion channel
+    // (num_dist = 1: 1 / depth) stays finite and w = 0 times it stays 0
+    if (lane < 4) srec[lane * VCR_TP_STRIDE + VCR_TP_CAP] = make_float4(0.f, lane == 1 ? -1e30f : 0.f, lane == 1 ? 1.f : 0.f, 0.f);
     const float X0 = (float)((tile % gx) * VCR_TILE + (wv & 1) * 8 + (sub < 0 ? 0 : (sub & 1) * 4));
     const float Y0 = (float)((tile / gx) * VCR_TILE + (wv >> 1) * 8 + (sub < 0 ? 0 : (sub >> 1) * 4));
     const f2 fxy = {(float)pm.x, (float)pm.y};
@@ -525,13 +545,13 @@ __device__ __forceinline__ void fwd_tp_item(const VcrRasterArgs& a, const GeomRe
 #define VCR_TP_FETCH01(R, SLOT)                                                                               \
     do {                                                                                                      \
         const int s_ = (SLOT);                                                                                \
-        R##0 = srec[s_]; R##1 = srec[VCR_TP_CAP + s_]; R##p = s_;                                             \
+        R##0 = srec[s_]; R##1 = srec[VCR_TP_STRIDE + s_]; R##p = s_;                                             \
         asm volatile("" ::: "memory");                                                                        \
     } while (0)
 #define VCR_TP_FETCH23(SLOT)                                                                                  \
     do {                                                                                                      \
         const int s_ = (SLOT);                                                                                \
-        C2 = srec[2 * VCR_TP_CAP + s_]; C3 = srec[3 * VCR_TP_CAP + s_];                                       \
+        C2 = srec[2 * VCR_TP_STRIDE + s_]; C3 = srec[3 * VCR_TP_STRIDE + s_];                                       \
         asm volatile("" ::: "memory");                                                                        \
     } while (0)
 #define VCR_TP_SHADE(R, ACT)                                                                                  \
@@ -570,13 +590,14 @@ _Pragma("unroll")                                                               
         T = hit ? test_T : T;                                                                                 \
         lslot = hit ? R##p : lslot;       /* (its list position is looked up once per group)                */ \
     } while (0)
-    // walk the candidates of one 32-slot half of the group, front to back; a lane whose word is empty idles on slot BASE
+    // walk the candidates of one 32-slot half of the group, front to back; a lane whose word is empty walks the dummy slot
 #define VCR_TP_POP(W_, B_, ACT_)                                                                              \
-    do { ACT_ = W_ != 0u; B_ = ACT_ ? __builtin_ctz(W_) : 0; W_ &= W_ - 1u; } while (0)
+    do { ACT_ = true; B_ = W_ != 0u ? __builtin_ctz(W_) : dummy_rel_; W_ &= W_ - 1u; } while (0)
 #if VCR_TP_PIPE
 #define VCR_TP_WALK(WORD, BASE)                                                                               \
     do {                                                                                                      \
         uint32_t w_ = (WORD);                                                                                 \
+        const int dummy_rel_ = VCR_TP_CAP - (BASE);       /* the dummy slot, relative to this half             */ \
         if (__builtin_amdgcn_ballot_w64(w_ != 0u) != 0) {                                                     \
             float4 A0, A1, B0, B1, C2, C3; int Ap, Bp;                                                        \
             int b_, nb_; bool act_, nact_;                                                                    \
@@ -602,6 +623,7 @@ _Pragma("unroll")                                                               
 #define VCR_TP_WALK(WORD, BASE)                                                                               \
     do {                                                                                                      \
         uint32_t w_ = (WORD);                                                                                 \
+        const int dummy_rel_ = VCR_TP_CAP - (BASE);                                                           \
         while (__builtin_amdgcn_ballot_w64(w_ != 0u) != 0) {                                                  \
             float4 A0, A1, C2, C3; int Ap;                                                                    \
             int b_; bool act_;                                                                                \
@@ -618,7 +640,7 @@ _Pragma("unroll")                                                               
 #define VCR_TP_ROWBYTE(ST)                                                                                    \
     do {                                                                                                      \
         const int slot_ = 8 * (ST) + (lane >> 3);                                                             \
-        const float4 g_ = srec[slot_], p_ = srec[4 * VCR_TP_CAP + slot_];                                     \
+        const float4 g_ = srec[slot_], p_ = srec[4 * VCR_TP_STRIDE + slot_];                                     \
         const float dy_ = (g_.y - Y0) - (float)(lane & 7);                                                    \
         const float D_ = fmaf(-p_.z, dy_ * dy_, p_.y);                                                        \
         const float h_ = __builtin_amdgcn_sqrtf(fmaxf(D_, 0.f)) * 1.00001f + 0.01f;                           \
@@ -657,7 +679,7 @@ _Pragma("unroll")                                                               
                 { unsigned c_ = (unsigned)(__popc(lo_w) + __popc(hi_w)); for (int o_ = 32; o_ > 0; o_ >>= 1) c_ += (unsigned)__shfl_xor((int)c_, o_); ts_cand += c_; }) \
         VCR_TP_WALK(lo_w, 0);                                                                                 \
         if (steps_ > 4) VCR_TP_WALK(hi_w, 32);                                                                \
-        if (lslot >= 0) last = __float_as_uint(srec[4 * VCR_TP_CAP + lslot].w);                               \
+        if (lslot >= 0) last = __float_as_uint(srec[4 * VCR_TP_STRIDE + lslot].w);                               \
         VCR_TPS(ts_p2 += clock64() - tf1_;)                                                                   \
         fill = 0;                                                                                             \
     } while (0)
@@ -688,8 +710,8 @@ _Pragma("unroll")                                                               
 #define VCR_TP_LAND_TAILS()                                                                                   \
     do {                                                                                                      \
         if (tslot >= 0) {                                                                                     \
-            srec[2 * VCR_TP_CAP + tslot] = make_float4(tq2.x, tq2.y, tq2.z, tq3.x);                           \
-            srec[3 * VCR_TP_CAP + tslot] = make_float4(tq3.y, tq3.z, tq2.w, tq3.w);                           \
+            srec[2 * VCR_TP_STRIDE + tslot] = make_float4(tq2.x, tq2.y, tq2.z, tq3.x);                           \
+            srec[3 * VCR_TP_STRIDE + tslot] = make_float4(tq3.y, tq3.z, tq2.w, tq3.w);                           \
         }                                                                                                     \
         tslot = -1;                                                                                           \
     } while (0)
@@ -719,8 +741,8 @@ _Pragma("unroll")                                                               
             const int slot = fill + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             tslot = slot;
             srec[slot] = make_float4(q0.x, q0.y, -VCR_L2E * q1.x, -VCR_L2E * q1.z);
-            srec[VCR_TP_CAP + slot] = make_float4(-VCR_L2E * q1.y, __builtin_amdgcn_logf(q0.w), q0.z, q1.w);
-            srec[4 * VCR_TP_CAP + slot] = span_params(q0, q1, X0, Y0, pos - range.x + (uint32_t)lane + 1u);
+            srec[VCR_TP_STRIDE + slot] = make_float4(-VCR_L2E * q1.y, __builtin_amdgcn_logf(q0.w), q0.z, q1.w);
+            srec[4 * VCR_TP_STRIDE + slot] = span_params(q0, q1, X0, Y0, pos - range.x + (uint32_t)lane + 1u);
         }
         fill += cnt;
         VCR_TPS(ts_surv += (unsigned)cnt; ++ts_chunks;)
@@ -793,10 +815,10 @@ __global__ void __launch_bounds__(256) VCR_TP_ATTR composite_fwd_tp_kernel(VcrRa
     const int tile = work_item(tile_order, meta, num_tiles, sub);
     if (tile < 0) return;
     const int wv = threadIdx.x >> 6;
-    __shared__ float4 s_rec_all[4 * 5 * VCR_TP_CAP];       // per wave: 5 planes x 64 slots x 16 B
+    __shared__ float4 s_rec_all[4 * 5 * VCR_TP_STRIDE];    // per wave: 5 planes x (64 slots + the dummy) x 16 B
     __shared__ uint4 s_rb_all[4 * 32];                     // per wave: 8 pixel rows x 64 survivors, one byte each
     fwd_tp_item<S, ISECT, ND, QL>(a, rec, point_list, ranges, gxc, final_T, n_contrib, moments, out, tile, sub, wv,
-                                  s_rec_all + wv * 5 * VCR_TP_CAP, s_rb_all + wv * 32);
+                                  s_rec_all + wv * 5 * VCR_TP_STRIDE, s_rb_all + wv * 32);
 }
 
 // ---- shading macros of the compositing backward (one survivor, all 64 lanes = the whole 8x8 quad) ---------------------------
